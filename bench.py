@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the multifm channel hot path on N MI355X GPUs.
+
+One "step" = one pass of the fused FIR + derotator + FM-discriminator kernel over one block of
+synthetic wideband int16 IQ (default 2^24 samples = 64 MiB) for every channel a GPU owns.
+
+  N = 1 : BASELINE.json configs[1] - 64 channels, 128-tap 25 kHz LPF, decimation 96, 2.4 MS/s-shaped IQ.
+  N > 1 : the same 64 channels PER GPU (weak scaling; N = 8 with --channels-per-gpu 128 is configs[2]).
+          The wideband block lives on rank 0 and is broadcast to the other ranks with RCCL
+          (torch.distributed backend "nccl") into the engines' input buffers, double-buffered against
+          the kernel; each rank demodulates only its own contiguous channel range - no other collective.
+
+Metric (BASELINE.json): input IQ MSamp/s x channels demodulated, whole job.  The JSON line also carries
+the HBM roofline of the dominant kernel (algorithmic bytes / HIP-event kernel time), the integer-VALU
+roofline next to it, and - on rank 0 at N = 1 - the oracle's CPU path timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_DOT2_PEAK = 256 * 4 * 32 * 2.4e9  # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--channels-per-gpu", type=int, default=64)
+    ap.add_argument("--block-log2", type=int, default=24, help="log2 of wideband samples per step")
+    ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
+    """The oracle (a port of the reference's per-channel loop) on the host cores, thread-per-channel
+    like multifm/receiver.c:89-95, on a bounded sample of the same workload."""
+    from __graft_entry__ import load_oracle
+    ora = load_oracle()
+    cores = os.cpu_count() or 1
+    nch = len(offs)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    threads = min(cores, nch)
+    n_cal = 1 << 19
+    iq = pkg.synth.synth_iq(n_cal, fs, offs[:4], seed=7)
+    t0 = time.perf_counter()
+    ora.run_channels(iq, cre, cim, incr, decim, threads=threads)
+    t_cal = time.perf_counter() - t0
+    n = int(min(1 << 25, max(n_cal, n_cal * target_s / max(t_cal, 1e-3))))
+    reps = -(-n // n_cal)
+    big = np.tile(iq, (reps, 1))[:n]
+    t0 = time.perf_counter()
+    ora.run_channels(big, cre, cim, incr, decim, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
+            "sample": f"{n} IQ samples x {nch} channels, oracle/liboracle.so (-O2 -march=x86-64-v3), "
+                      f"{threads} threads thread-per-channel, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the multifm engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    cpg = args.channels_per_gpu
+    total_ch = cpg * world
+    fs, decim, taps, all_offs, all_gains = pkg.synth.plan(args.config, nr_channels=total_ch)
+    lo, hi = pkg.dist.shard_range(total_ch, rank, world)
+    offs, gains = all_offs[lo:hi], all_gains[lo:hi]
+    block = 1 << args.block_log2
+    T = len(taps)
+
+    # engine input buffers are torch tensors so RCCL can write straight into them
+    lib = pkg.load_library()
+    in_bytes = lib.mfm_engine_input_bytes(block, T)
+    bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+    eng = pkg.Engine(fs, decim, block, device=local_rank,
+                     flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING,
+                     ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+
+    # synthetic wideband IQ, resident in HBM before the timed region (rank 0 is the ingest GPU)
+    if rank == 0:
+        base = pkg.synth.synth_iq(1 << 22, fs, all_offs[:: max(1, total_ch // 8)][:8], seed=7)
+        reps = -(-(in_bytes // 4) // base.shape[0])
+        host = np.tile(base, (reps, 1))[: in_bytes // 4].reshape(-1)
+        for b in bufs:
+            b.copy_(torch.from_numpy(host))
+    torch.cuda.synchronize()
+
+    def step():
+        ptr, cap = eng.acquire_input()
+        if world > 1:
+            which = 0 if ptr < bufs[0].data_ptr() + in_bytes and ptr >= bufs[0].data_ptr() else 1
+            off = (ptr - bufs[which].data_ptr()) // 2
+            view = bufs[which][off: off + 2 * block]
+            pkg.dist.broadcast_block(view, src=0)
+        eng.submit(block, producer_stream=torch.cuda.current_stream().cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        eng.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    st0 = eng.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st1 = eng.stats()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    launches = st1["launches"] - st0["launches"]
+    k_ms = (st1["kernel_ms"] - st0["kernel_ms"]) / max(1, launches)
+    outs = (st1["outputs"] - st0["outputs"]) / max(1, launches)
+    bytes_per_launch = block * 4 + len(offs) * outs * 2        # 4 + 2*C_g/D bytes per input sample
+    dot2_per_launch = 2.0 * len(offs) * T * outs               # two v_dot2 lane-ops per complex tap per output
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    msamp = args.steps * block / dt / 1e6
+
+    if rank == 0:
+        line = {
+            "metric": "input IQ MSamp/s x channels demodulated",
+            "value": msamp * total_ch,
+            "unit": "MSamp/s x channels",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cpg} FM channels per GPU ({total_ch} total), {T}-tap 25 kHz LPF, "
+                                   f"decimation {decim}, fs {fs} Hz-shaped int16 IQ, block 2^{args.block_log2} samples",
+                       "channels_per_gpu": cpg, "channels_total": total_ch, "block_samples": block,
+                       "input_msamp_per_s": msamp,
+                       "parallelism": "1 GPU" if world == 1 else f"channel shards x{world} + RCCL broadcast of IQ"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "mfm_channel_kernel", "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
+            "valu_roofline": {"bound": "v_dot2_i32_i16", "achieved": dot2_per_launch / (k_ms * 1e-3) / 1e12,
+                              "peak": VALU_DOT2_PEAK / 1e12, "unit": "T lane-ops/s",
+                              "frac": dot2_per_launch / (k_ms * 1e-3) / VALU_DOT2_PEAK},
+            "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],
+                         "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, fs, decim, taps, offs, gains, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

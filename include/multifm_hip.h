@@ -1,0 +1,180 @@
+/*
+ * multifm_hip.h - C ABI of the MI355X multifm channel engine (libmultifm_hip.so).
+ *
+ * This is the drop-in boundary for multifm's per-channel hot path.  In the reference
+ * (pvachon/tsl-sdr) every channel is a pthread that runs
+ *
+ *     demod_thread_process()            multifm/demod.c:48-121
+ *       direct_fir_push_sample_buf()    filter/direct_fir.c:118-146
+ *       direct_fir_process()            filter/direct_fir.c:422-453   (complex-tap decimating FIR
+ *                                                                      + Q14 derotator)
+ *       multifm_fm_demod_process()      multifm/fm_demod.c:36-85      (fast_atan2f discriminator)
+ *       write(fifo_fd, pcm)             multifm/demod.c:93
+ *
+ * on every struct sample_buf that receiver_sample_buf_deliver() (multifm/receiver.c:78-98) hands it.
+ * Here ONE engine object owns all channels of a receiver and runs that whole loop as one fused HIP
+ * kernel per block of wideband samples.  The entry points below are what a reference-side
+ * replacement of demod.c / receiver.c binds:
+ *
+ *   reference call                                   engine call
+ *   ------------------------------------------------ -----------------------------------------
+ *   demod_thread_new(.., offset_hz, samp_hz,         mfm_engine_add_channel()
+ *       out_fifo, decimation, lpf_taps, nr_taps,
+ *       fir_debug_output, gain)   demod.h:104-116
+ *   (receiver_start)              receiver.c:268      mfm_engine_commit()
+ *   receiver_sample_buf_deliver() receiver.c:78-98    mfm_engine_push() | acquire_input()+submit()
+ *   write(fifo_fd, ...)           demod.c:93          mfm_engine_fetch() / mfm_engine_release()
+ *   demod_thread_delete()         demod.c:163-190     mfm_engine_destroy()
+ *
+ * Conventions follow the reference's aresult_t style: every call returns an int, 0 (MFM_OK) on
+ * success and a negative MFM_E_* on failure; nothing throws; handles are opaque; plain pointers and
+ * sizes only.  All sample data is interleaved int16 I,Q exactly as in struct sample_buf::data_buf
+ * (filter/sample_buf.h:59-102).  Output PCM is the same int16 stream a channel thread writes to its
+ * FIFO; optional filtered IQ is the signalDebugFile stream (demod.c:75-81).
+ *
+ * The library has no CPU fallback: without a usable HIP device mfm_engine_create() fails with
+ * MFM_E_DEVICE.
+ */
+#ifndef MULTIFM_HIP_H
+#define MULTIFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFM_OK 0
+#define MFM_E_INVAL (-1)  /* bad argument (TSL_ASSERT_ARG failures in the reference) */
+#define MFM_E_NOMEM (-2)  /* host or device allocation failed */
+#define MFM_E_BUSY (-3)   /* no free output slot / input buffer (direct_fir.c:136 A_E_BUSY analogue) */
+#define MFM_E_DEVICE (-4) /* HIP runtime error or no device */
+#define MFM_E_STATE (-5)  /* call not valid in this state (e.g. add_channel after commit) */
+#define MFM_E_DONE (-6)   /* nothing to fetch (A_E_DONE analogue) */
+
+#define MFM_ABI_VERSION 1
+
+/* flags for mfm_engine_config::flags */
+#define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
+#define MFM_F_TIMING 0x2u      /* bracket every kernel launch with HIP events */
+
+struct mfm_engine_config {
+    uint32_t abi_version;       /* MFM_ABI_VERSION */
+    int32_t device;             /* HIP device ordinal */
+    uint32_t sample_rate_hz;    /* receiver sampleRateHz, receiver.c:138 */
+    uint32_t decimation;        /* decimationFactor, receiver.c:160-172 */
+    uint32_t max_block_samples; /* largest block one push()/submit() may carry */
+    uint32_t flags;             /* MFM_F_* */
+    /* Optional caller-owned device memory for the two input staging buffers, each at least
+     * mfm_engine_input_bytes() bytes (lets a caller hand in torch/RCCL-registered memory).
+     * NULL = the engine allocates. */
+    void *ext_input[2];
+};
+
+struct mfm_engine; /* opaque */
+
+struct mfm_block {
+    uint64_t first_output; /* stream index of pcm[.][0] */
+    size_t nr_outputs;     /* outputs per channel in this block */
+    size_t stride;         /* elements between consecutive channels */
+    const int16_t *pcm;    /* [nr_channels][stride] host memory, valid until release() */
+    const int16_t *iq;     /* [nr_channels][2*stride] filtered I,Q or NULL */
+};
+
+struct mfm_stats {
+    uint64_t samples_in;       /* wideband samples accepted */
+    uint64_t outputs;          /* outputs produced per channel */
+    uint64_t launches;         /* kernel launches */
+    double kernel_ms;          /* sum of launch durations (MFM_F_TIMING), HIP events */
+    uint32_t nr_channels;
+    uint32_t nr_taps;
+    uint32_t outputs_per_tile; /* kernel geometry, informational */
+    uint32_t lds_bytes;
+    uint32_t grid_last;        /* workgroups of the last launch */
+    uint32_t tail_samples;     /* unconsumed samples carried to the next block */
+    uint64_t rot_table_entries;
+};
+
+/* Size in bytes of one input staging buffer for this configuration and tap count. */
+size_t mfm_engine_input_bytes(uint32_t max_block_samples, uint32_t nr_taps);
+
+int mfm_engine_create(struct mfm_engine **pe, const struct mfm_engine_config *cfg);
+void mfm_engine_destroy(struct mfm_engine **pe);
+
+/*
+ * Register a channel the way demod_thread_new() does (multifm/demod.h:104-116): real low-pass taps
+ * are rotated to offset_hz and quantised to Q14 (demod.c:204-269), the derotator increment is
+ * derived from offset_hz and the decimation (direct_fir.c:72-79).  want_iq != 0 asks for the
+ * filtered-IQ stream too (fir_debug_output).  Returns the channel index (>= 0) or MFM_E_*.
+ * All channels of one engine share nr_taps (the reference shares lpfTaps, receiver.c:175-184).
+ */
+int mfm_engine_add_channel(struct mfm_engine *e, int32_t offset_hz, const double *lpf_taps, size_t nr_taps,
+                           double channel_gain, int want_iq);
+
+/* Same, from already-quantised Q14 taps and rotator increment (fixtures, tests). */
+int mfm_engine_add_channel_q14(struct mfm_engine *e, const int16_t *coeff_re, const int16_t *coeff_im,
+                               size_t nr_taps, int16_t rot_incr_re, int16_t rot_incr_im, int want_iq);
+
+/* Read back what a channel was programmed with (Q14 taps, rotator increment as {re, im}). */
+int mfm_engine_get_channel(struct mfm_engine *e, uint32_t chan, int16_t *coeff_re, int16_t *coeff_im,
+                           int16_t rot_incr[2]);
+
+/* Freeze the channel set: build tap/rotator tables, allocate device buffers. */
+int mfm_engine_commit(struct mfm_engine *e);
+
+/*
+ * Zero-copy ingest.  acquire_input() returns device memory where the caller (an H2D copy, an RCCL
+ * broadcast, a generator kernel) must write the next block; submit() then processes nr_samples of
+ * it.  If producer_stream is non-NULL it is a hipStream_t the data was produced on: the engine's
+ * compute stream waits for it (no host sync).  Blocks are processed in submit order.
+ */
+int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacity_samples);
+int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream);
+
+/* Host ingest: copies nr_samples interleaved int16 IQ pairs (any count <= max_block_samples) and
+ * submits them.  Returns as soon as the copy has been staged; never blocks longer than a memcpy. */
+int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples);
+
+/* Oldest finished block, in submit order (blocks with zero outputs are skipped).  Waits for the
+ * device.  MFM_E_DONE when nothing is pending.  The block stays valid until release(). */
+int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk);
+int mfm_engine_release(struct mfm_engine *e);
+
+/* Device-resident view of the most recent submit's outputs (MFM_F_DEVICE_ONLY users). */
+int mfm_engine_last_output_device(struct mfm_engine *e, void **d_pcm, size_t *stride, size_t *nr_outputs,
+                                  void **d_iq);
+
+/* Wait for everything submitted so far. */
+int mfm_engine_sync(struct mfm_engine *e);
+
+/* Forget the stream: history tail, rotator phase and discriminator state go back to a fresh
+ * stream (what restarting the reference does). Pending blocks are dropped. */
+int mfm_engine_reset(struct mfm_engine *e);
+
+int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st);
+
+/* The engine's compute stream (hipStream_t) for callers that order their own work after it. */
+void *mfm_engine_stream(struct mfm_engine *e);
+
+const char *mfm_strerror(int err);
+const char *mfm_last_error(void); /* thread-local detail of the last failure */
+
+/*
+ * Host twins of the kernel's scalar numerics (compiled from the same header the kernel uses).
+ * They exist so the test-suite can check, on the CPU, that the device formulas reproduce the
+ * reference's expressions bit for bit; they are not a compute path.
+ */
+int32_t mfm_hosttwin_discriminate(int32_t s_re, int32_t s_im);
+void mfm_hosttwin_discriminate_batch(const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *out);
+int16_t mfm_hosttwin_r14(int32_t a);
+/* out[i] = pcm of the non-negative angle whose float bit pattern is first_bits + i */
+void mfm_hosttwin_pcm_range(uint32_t first_bits, uint32_t count, int16_t *out);
+void mfm_hosttwin_atan_table(float tbl[257]);
+int mfm_hosttwin_atan_table_ok(void); /* 1 if the generated table matches the pinned hash */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MULTIFM_HIP_H */

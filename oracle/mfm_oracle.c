@@ -110,6 +110,16 @@ int16_t mfmo_phi_to_pcm(float phi)
     return (int16_t)phi_scaled;
 }
 
+void mfmo_phi_to_pcm_range(uint32_t first_bits, uint32_t count, int16_t *out)
+{
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t b = first_bits + i;
+        float phi;
+        memcpy(&phi, &b, sizeof(phi));
+        out[i] = mfmo_phi_to_pcm(phi);
+    }
+}
+
 int16_t mfmo_fm_step(int16_t a_re16, int16_t a_im16, int32_t last_re, int32_t last_im)
 {
     /* multifm/fm_demod.c:55-72 */
@@ -118,6 +128,16 @@ int16_t mfmo_fm_step(int16_t a_re16, int16_t a_im16, int32_t last_re, int32_t la
     int32_t s_im = (int32_t)((uint32_t)(a_re * b_im) + (uint32_t)(a_im * b_re));
     float phi = mfmo_fast_atan2f((float)s_im, (float)s_re);
     return mfmo_phi_to_pcm(phi);
+}
+
+void mfmo_discriminate_batch(const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *out, int fused)
+{
+    /* multifm/fm_demod.c:68-72 on precomputed s = a * conj(prev) */
+    pthread_once(&g_atan_once, atan_tbl_init);
+    for (size_t i = 0; i < n; i++) {
+        float phi = atan2_core((float)s_im[i], (float)s_re[i], fused);
+        out[i] = mfmo_phi_to_pcm(phi);
+    }
 }
 
 /* ------------------------------------------------------------------------------------- */

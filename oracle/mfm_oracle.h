@@ -49,6 +49,13 @@ float mfmo_fast_atan2f_fma(float y, float x);
 /* multifm/fm_demod.c:71-72: (int16)(float)(((double)phi / M_PI) * 16384.0). */
 int16_t mfmo_phi_to_pcm(float phi);
 
+/* out[i] = mfmo_phi_to_pcm(float with bit pattern first_bits + i); exhaustive-scan helper */
+void mfmo_phi_to_pcm_range(uint32_t first_bits, uint32_t count, int16_t *out);
+
+/* out[i] = pcm of fast_atan2f((float)s_im[i], (float)s_re[i]) (fm_demod.c:68-72); fused selects the
+ * fma variant of fast_atan2f.c:131 */
+void mfmo_discriminate_batch(const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *out, int fused);
+
 /* One discriminator step, multifm/fm_demod.c:55-72.  prev/cur are (re,im) int16 pairs. */
 int16_t mfmo_fm_step(int16_t a_re, int16_t a_im, int32_t last_re, int32_t last_im);
 

@@ -1,0 +1,166 @@
+"""ctypes wrapper of oracle/liboracle.so and oracle/_ref (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_ATAN2_SO = os.path.join(ROOT, "oracle", "_ref", "libref_fast_atan2f.so")
+
+_i16p = C.POINTER(C.c_int16)
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            raise RuntimeError(f"{ORACLE_SO} missing: run `make -C oracle`")
+        o = C.CDLL(ORACLE_SO)
+        o.mfmo_r14.argtypes = [C.c_int32]
+        o.mfmo_r14.restype = C.c_int16
+        o.mfmo_atan_table.argtypes = [C.POINTER(C.c_float)]
+        o.mfmo_fast_atan2f.argtypes = [C.c_float, C.c_float]
+        o.mfmo_fast_atan2f.restype = C.c_float
+        o.mfmo_fast_atan2f_fma.argtypes = [C.c_float, C.c_float]
+        o.mfmo_fast_atan2f_fma.restype = C.c_float
+        o.mfmo_phi_to_pcm.argtypes = [C.c_float]
+        o.mfmo_phi_to_pcm.restype = C.c_int16
+        o.mfmo_phi_to_pcm_range.argtypes = [C.c_uint32, C.c_uint32, _i16p]
+        o.mfmo_phi_to_pcm_range.restype = None
+        o.mfmo_discriminate_batch.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, _i16p, C.c_int]
+        o.mfmo_discriminate_batch.restype = None
+        o.mfmo_fm_step.argtypes = [C.c_int16, C.c_int16, C.c_int32, C.c_int32]
+        o.mfmo_fm_step.restype = C.c_int16
+        o.mfmo_make_taps.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_int32, C.c_uint32, C.c_double, _i16p, _i16p]
+        o.mfmo_make_taps.restype = None
+        o.mfmo_rot_incr.argtypes = [C.c_int32, C.c_uint32, C.c_uint, _i16p, _i16p]
+        o.mfmo_rot_incr.restype = None
+        o.mfmo_gain_from_db.argtypes = [C.c_double]
+        o.mfmo_gain_from_db.restype = C.c_double
+        o.mfmo_rot_step.argtypes = [_i16p, _i16p, C.c_int16, C.c_int16]
+        o.mfmo_rot_step.restype = None
+        o.mfmo_chan_new.argtypes = [_i16p, _i16p, C.c_size_t, C.c_uint, C.c_int16, C.c_int16]
+        o.mfmo_chan_new.restype = C.c_void_p
+        o.mfmo_chan_free.argtypes = [C.c_void_p]
+        o.mfmo_chan_free.restype = None
+        o.mfmo_chan_feed.argtypes = [C.c_void_p, _i16p, C.c_size_t, _i16p, _i16p, C.c_size_t]
+        o.mfmo_chan_feed.restype = C.c_size_t
+        o.mfmo_chan_rot.argtypes = [C.c_void_p, _i16p, _i16p]
+        o.mfmo_chan_rot.restype = None
+        o.mfmo_run_channels.argtypes = [_i16p, C.c_size_t, C.c_size_t, _i16p, _i16p, C.c_size_t, C.c_uint, _i16p,
+                                        _i16p, _i16p, C.c_size_t, C.c_uint]
+        o.mfmo_run_channels.restype = C.c_size_t
+        o.mfmo_twoslot_run.argtypes = [_i16p, C.c_size_t, C.c_size_t, _i16p, _i16p, C.c_size_t, C.c_uint, C.c_int16,
+                                       C.c_int16, _i16p, _i16p, C.c_size_t]
+        o.mfmo_twoslot_run.restype = C.c_size_t
+        _lib = o
+    return _lib
+
+
+def ref_atan2():
+    """The reference's own fast_atan2f object code (oracle/_ref), or None if it was not built."""
+    global _ref
+    if _ref is None and os.path.exists(REF_ATAN2_SO):
+        r = C.CDLL(REF_ATAN2_SO)
+        r.fast_atan2f.argtypes = [C.c_float, C.c_float]
+        r.fast_atan2f.restype = C.c_float
+        _ref = r
+    return _ref
+
+
+def p16(a):
+    return a.ctypes.data_as(_i16p)
+
+
+def make_taps(lpf_taps, offset_hz, sample_rate, gain=1.0):
+    h = np.ascontiguousarray(lpf_taps, dtype=np.float64)
+    cre = np.zeros(h.size, np.int16)
+    cim = np.zeros(h.size, np.int16)
+    lib().mfmo_make_taps(h.ctypes.data_as(C.POINTER(C.c_double)), h.size, int(offset_hz), int(sample_rate),
+                         float(gain), p16(cre), p16(cim))
+    return cre, cim
+
+
+def rot_incr(offset_hz, sample_rate, decimation):
+    a = np.zeros(2, np.int16)
+    lib().mfmo_rot_incr(int(offset_hz), int(sample_rate), int(decimation), p16(a[0:1]), p16(a[1:2]))
+    return a
+
+
+def atan_table():
+    t = (C.c_float * 257)()
+    lib().mfmo_atan_table(t)
+    return np.frombuffer(t, dtype=np.float32).copy()
+
+
+def expected_outputs(nr_samples, nr_taps, decimation):
+    return 0 if nr_samples < nr_taps else (nr_samples - nr_taps) // decimation + 1
+
+
+def run_channels(iq, cre, cim, incr, decimation, threads=1, want_iq=False):
+    """Whole-buffer oracle run.  iq: (n,2) int16; cre/cim: (C,T); incr: (C,2). Returns (pcm[C][N], iq[C][N][2]|None)."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    cre = np.ascontiguousarray(cre, dtype=np.int16)
+    cim = np.ascontiguousarray(cim, dtype=np.int16)
+    incr = np.ascontiguousarray(incr, dtype=np.int16)
+    nch, T = cre.shape
+    n = iq.shape[0]
+    nout = expected_outputs(n, T, decimation)
+    pcm = np.zeros((nch, max(nout, 1)), np.int16)
+    iqo = np.zeros((nch, max(nout, 1), 2), np.int16) if want_iq else None
+    got = lib().mfmo_run_channels(p16(iq), n, nch, p16(cre), p16(cim), T, decimation, p16(incr), p16(pcm),
+                                  p16(iqo) if want_iq else None, max(nout, 1), threads)
+    assert got == nout, (got, nout)
+    return pcm[:, :nout], (iqo[:, :nout] if want_iq else None)
+
+
+class Channel:
+    """Streaming oracle channel (arbitrary chunking)."""
+
+    def __init__(self, cre, cim, decimation, incr):
+        self.cre = np.ascontiguousarray(cre, dtype=np.int16)
+        self.cim = np.ascontiguousarray(cim, dtype=np.int16)
+        self.h = lib().mfmo_chan_new(p16(self.cre), p16(self.cim), self.cre.size, decimation, int(incr[0]), int(incr[1]))
+        if not self.h:
+            raise ValueError("mfmo_chan_new rejected the configuration")
+        self.decim = decimation
+
+    def feed(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+        cap = iq.shape[0] // self.decim + 2 + self.cre.size
+        pcm = np.zeros(cap, np.int16)
+        q = np.zeros((cap, 2), np.int16)
+        n = lib().mfmo_chan_feed(self.h, p16(iq), iq.shape[0], p16(pcm), p16(q), cap)
+        return pcm[:n], q[:n]
+
+    def rot(self):
+        a = np.zeros(2, np.int16)
+        lib().mfmo_chan_rot(self.h, p16(a[0:1]), p16(a[1:2]))
+        return a
+
+    def close(self):
+        if self.h:
+            lib().mfmo_chan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def twoslot_run(iq, buf_samples, cre, cim, decimation, incr):
+    iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+    nb = iq.shape[0] // buf_samples
+    cre = np.ascontiguousarray(cre, dtype=np.int16)
+    cim = np.ascontiguousarray(cim, dtype=np.int16)
+    cap = iq.shape[0] // decimation + 2
+    pcm = np.zeros(cap, np.int16)
+    q = np.zeros((cap, 2), np.int16)
+    n = lib().mfmo_twoslot_run(p16(iq), buf_samples, nb, p16(cre), p16(cim), cre.size, decimation, int(incr[0]),
+                               int(incr[1]), p16(pcm), p16(q), cap)
+    return pcm[:n], q[:n]

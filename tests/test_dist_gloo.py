@@ -1,0 +1,89 @@
+"""World-size-2 test of the N>1 plumbing on CPU (gloo): channel partition, in-place broadcast of the
+wideband block from the ingest rank, per-rank processing of its own channel range, max-over-ranks
+timing.  The per-rank processing stands in the oracle for the HIP engine (no GPU here); what is under
+test is that shard ranges tile the channel set and that every rank sees the ingest rank's bytes, so the
+concatenated shard outputs equal the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_tile_the_channel_set(pkg):
+    for n in (1, 2, 63, 64, 65, 1024, 2048):
+        for world in (1, 2, 3, 4, 8):
+            got = []
+            for r in range(world):
+                lo, hi = pkg.dist.shard_range(n, r, world)
+                got.extend(range(lo, hi))
+                assert 0 <= hi - lo <= -(-n // world)
+            assert got == list(range(n))
+    with pytest.raises(ValueError):
+        pkg.dist.shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from __graft_entry__ import load_package
+    import oracle_lib as ora
+    pkg = load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=10)
+        lo, hi = pkg.dist.shard_range(len(offs), rank, world)
+        block, nblocks = 20000, 3
+        chans = [ora.Channel(*ora.make_taps(taps, int(o), fs, float(g)), decim, ora.rot_incr(int(o), fs, decim))
+                 for o, g in zip(offs[lo:hi], gains[lo:hi])]
+        outs = [[] for _ in chans]
+        buf = torch.zeros(2 * block + 64, dtype=torch.int16)
+        for b in range(nblocks):
+            view = buf[32: 32 + 2 * block]  # a sub-view, like the engine's [tail | block] buffer
+            if rank == 0:
+                iq = pkg.synth.synth_iq(block, fs, offs[:3], seed=100 + b)
+                view.copy_(torch.from_numpy(iq.reshape(-1)))
+            else:
+                view.fill_(-1)
+            pkg.dist.broadcast_block(view, src=0)
+            got = view.numpy().reshape(-1, 2)
+            for k, ch in enumerate(chans):
+                outs[k].append(ch.feed(got)[0])
+        t = pkg.dist.max_over_ranks(1.0 + rank)
+        assert t == float(world)
+        pcm = np.stack([np.concatenate(o) for o in outs]) if chans else np.zeros((0, 0), np.int16)
+        np.save(os.path.join(out_dir, f"pcm_{rank}.npy"), pcm)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_and_sharded_demod(pkg, ora, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"pcm_{r}.npy") for r in range(world)]
+    got = np.concatenate(parts, axis=0)
+    # single-process reference over all channels
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=10)
+    iq = np.concatenate([pkg.synth.synth_iq(20000, fs, offs[:3], seed=100 + b) for b in range(3)])
+    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    assert got.shape == ref.shape and np.array_equal(got, ref)

@@ -1,0 +1,216 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle on the same seeded
+input.  Bar: bit-exact PCM and filtered IQ (the float stage is reproduced exactly, see
+tests/test_numerics_host.py, so no tolerance is needed; north_star would allow 1 LSB)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_iq=False, flags=0):
+    eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
+    gains = gains if gains is not None else [1.0] * len(offs)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
+    eng.commit()
+    return eng
+
+
+def _oracle_tables(eng, nch):
+    cre = np.stack([eng.get_channel(c)[0] for c in range(nch)])
+    cim = np.stack([eng.get_channel(c)[1] for c in range(nch)])
+    incr = np.stack([eng.get_channel(c)[2] for c in range(nch)])
+    return cre, cim, incr
+
+
+def _check(pkg, ora, fs, decim, taps, offs, iq, block, gains=None, want_iq=True, threads=8):
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=max(block, 1), want_iq=want_iq)
+    cre, cim, incr = _oracle_tables(eng, len(offs))
+    pcm, q = eng.run(iq, block)
+    ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=threads, want_iq=want_iq)
+    eng.close()
+    assert pcm.shape == ref.shape, (pcm.shape, ref.shape)
+    if not np.array_equal(pcm, ref):
+        bad = np.argwhere(pcm != ref)
+        raise AssertionError(f"{len(bad)} PCM samples differ; first at (chan, n) = {bad[0]}: "
+                             f"hip {pcm[tuple(bad[0])]} oracle {ref[tuple(bad[0])]}")
+    if want_iq:
+        assert q is not None and np.array_equal(q, refq), "filtered IQ stream differs"
+    return pcm
+
+
+def test_golden_path_vector(pkg, ora, golden_dir):
+    g = np.load(os.path.join(golden_dir, "path_oracle.npz"))
+    fs, decim = int(g["fs"]), int(g["decim"])
+    eng = pkg.Engine(fs, decim, 1 << 15, device=0)
+    for c in range(len(g["offsets"])):
+        eng.add_channel_q14(g["cre"][c], g["cim"][c], g["incr"][c], want_iq=True)
+    eng.commit()
+    pcm, q = eng.run(g["iq"], 1 << 15)
+    eng.close()
+    assert np.array_equal(pcm, g["pcm"]) and np.array_equal(q, g["filt_iq"])
+
+
+@pytest.mark.parametrize("name", ["multifm_1ch", "multifm_1ch_2400k", "pocsag_rtlsdr"])
+def test_reference_shaped_configs(pkg, ora, name):
+    """BASELINE configs[0] and [3]: etc/multifm_1ch.json values (fs 1.0 MS/s, D 40) and its 2.4 MS/s / D 96
+    variant, etc/pocsag_rtlsdr.json (fs 1.2 MS/s, D 25, dBGain 4.0 on channel 0), file_if-sized 4096-sample
+    buffers (multifm/file_if.c:18)."""
+    fs, decim, taps, offs, gains = pkg.synth.plan(name)
+    iq = pkg.synth.synth_iq(4096 * 60, fs, offs, seed=21)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 4096, gains=gains)
+
+
+def test_cfg2_64_channels(pkg, ora):
+    """BASELINE configs[1]: 64 channels, 25 kHz LPF (128 taps), D=96, 2.4 MS/s, 1 GPU."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch")
+    iq = pkg.synth.synth_iq((1 << 20) + 4321, fs, offs[::7], seed=22)
+    pcm = _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 18, want_iq=False)
+    assert pcm.shape == (64, ora.expected_outputs(len(iq), 128, decim))
+
+
+def test_cfg3_shard_of_1024_channels(pkg, ora):
+    """BASELINE configs[2]: one GPU's 128-channel shard of the 1024-channel plan."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg3_1024ch")
+    shard = offs[3 * 128:4 * 128]
+    iq = pkg.synth.synth_iq(1 << 18, fs, shard[::16], seed=23)
+    _check(pkg, ora, fs, decim, taps, shard, iq, 1 << 17, want_iq=False)
+
+
+def test_cfg5_airspy_rate(pkg, ora):
+    """BASELINE configs[4] (int16 path): fs 10 MS/s, D=400, 512 taps."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=24)
+    iq = pkg.synth.synth_iq(400 * 900 + 512, fs, offs[:3], seed=24)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17)
+
+
+@pytest.mark.parametrize("decim,ntaps", [(1, 16), (2, 9), (7, 33), (25, 128), (40, 128), (96, 96), (97, 128), (128, 128)])
+def test_odd_geometries(pkg, ora, decim, ntaps):
+    """decimationFactor 1 (etc/multifm_file.json), taps == decimation, odd tap counts, D not dividing anything."""
+    fs = 1000000
+    taps = pkg.synth.design_lpf(ntaps, 20000.0, fs)
+    offs = [12345, -250000, 100000]
+    n = max(decim * 700 + ntaps + 5, 3000)
+    iq = pkg.synth.synth_iq(n, fs, offs, seed=decim)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 8192)
+
+
+def test_full_scale_random_input_wraps_like_int32(pkg, ora):
+    """Uniform full-scale int16 noise with a wide, high-gain filter overflows the accumulator and hits every
+    atan2 octant, including exact ties."""
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 400000.0, fs)
+    offs = [0, 101000, -600000, 37500]
+    gains = [5.0, 1.0, 4.0, 0.5]
+    iq = pkg.synth.random_iq(96 * 3000 + 128, seed=31, full_scale=True)
+    iq[5000:6000] = 32767
+    iq[7000:8000] = -32768
+    iq[9000:9500] = 0  # all-zero stretch: atan2(0, 0) path
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains)
+
+
+def test_ragged_blocks_and_blocks_shorter_than_the_filter(pkg, ora):
+    """Chunking independence through the engine: 1-sample blocks, blocks < taps (no output), the rtl_sdr /
+    file_if / uhd buffer sizes (131072 / 4096 / 16384), a prime size."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=9)
+    n = 300000
+    iq = pkg.synth.synth_iq(n, fs, offs[:3], seed=41)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, want_iq=True, max_block=131072)
+    cre, cim, incr = _oracle_tables(eng, len(offs))
+    ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=4, want_iq=True)
+    sizes = [1, 1, 100, 26, 1, 4096, 131072, 16384, 7919, 5, 127, 128, 129, 60000, 1000]
+    pcm_parts, q_parts, pos, k = [], [], 0, 0
+    while pos < n:
+        m = min(sizes[k % len(sizes)], n - pos)
+        rc = eng.push(iq[pos:pos + m])
+        if rc == pkg.binding.MFM_E_BUSY:
+            got = eng.fetch()
+            pcm_parts.append(got[1])
+            q_parts.append(got[2])
+            continue
+        assert rc == 0, eng.lib.mfm_last_error()
+        pos += m
+        k += 1
+    while True:
+        got = eng.fetch()
+        if got is None:
+            break
+        pcm_parts.append(got[1])
+        q_parts.append(got[2])
+    st = eng.stats()
+    eng.close()
+    pcm = np.concatenate(pcm_parts, axis=1)
+    q = np.concatenate(q_parts, axis=1)
+    assert np.array_equal(pcm, ref) and np.array_equal(q, refq)
+    assert st["samples_in"] == n and st["outputs"] == ref.shape[1]
+    assert st["tail_samples"] == n - ref.shape[1] * decim
+
+
+def test_long_stream_crosses_rotator_preperiod(pkg, ora):
+    """A stream long enough that the tabulated rotator leaves its pre-period and wraps its cycle several
+    times (offset 101 kHz: pre-period 53 105 outputs, period 25; offset 777 Hz: 71 743 / 740)."""
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 12500.0, fs)
+    offs = [101000, 777, 3125, 37500]
+    n = 96 * 160000 + 128
+    iq = pkg.synth.synth_iq(n, fs, offs[:2], seed=51, noise=2000)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 20, want_iq=True)
+
+
+def test_reset_restarts_the_stream(pkg, ora):
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=5)
+    iq = pkg.synth.synth_iq(96 * 400 + 200, fs, offs, seed=61)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 15)
+    a, _ = eng.run(iq, 5000)
+    eng.reset()
+    b, _ = eng.run(iq, 1 << 15)
+    eng.close()
+    assert np.array_equal(a, b)
+
+
+def test_device_resident_submit_path(pkg, ora):
+    """acquire_input()/submit() with the block already in HBM (what bench.py and an RCCL broadcast use)."""
+    import torch
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=16)
+    blk = 1 << 16
+    iq = pkg.synth.synth_iq(blk * 3, fs, offs[:4], seed=71)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=blk, flags=pkg.binding.MFM_F_DEVICE_ONLY)
+    cre, cim, incr = _oracle_tables(eng, len(offs))
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
+    src = torch.from_numpy(iq.reshape(-1)).cuda()
+    outs = []
+    for b in range(3):
+        ptr, cap = eng.acquire_input()
+        assert cap >= blk
+        hip = torch.cuda.current_stream().cuda_stream
+        # device-to-device placement of the block on torch's stream, then submit ordered after it
+        dst = torch.empty(0, dtype=torch.int16, device="cuda")
+        import ctypes as C
+        rt = C.CDLL("libamdhip64.so")
+        rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        assert rt.hipMemcpyAsync(ptr, src[b * blk * 2:].data_ptr(), blk * 4, 3, hip) == 0
+        eng.submit(blk, producer_stream=hip)
+        eng.sync()
+        dptr, stride, nout, _ = eng.last_output_device()
+        host = np.empty((len(offs), stride), np.int16)
+        rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert rt.hipMemcpy(host.ctypes.data, dptr, host.nbytes, 2) == 0
+        outs.append(host[:, :nout].copy())
+        del dst
+    eng.close()
+    assert np.array_equal(np.concatenate(outs, axis=1), ref)
+
+
+def test_full_size_block_properties(pkg, ora):
+    """BASELINE full size (64 channels, 2^24-sample blocks): bit-exact against the threaded oracle, and
+    the size-independent property that re-blocking the same stream leaves the PCM unchanged."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch")
+    n = (1 << 24) + 12345
+    iq = pkg.synth.synth_iq(n, fs, offs[::9], seed=81)
+    big = _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 24, want_iq=False)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 20)
+    small, _ = eng.run(iq, (1 << 20) - 77)
+    eng.close()
+    assert np.array_equal(big, small)

@@ -1,0 +1,89 @@
+"""The kernel's scalar numerics (tsl-sdr_amd/csrc/mfm_numerics.h), compiled for the host inside
+libmultifm_hip.so as mfm_hosttwin_*, against the oracle.  No GPU needed: these are the same source
+lines the device code is built from."""
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def test_atan_table_matches_oracle_and_pinned_hash(pkg, ora):
+    lib = pkg.load_library()
+    t = (C.c_float * 257)()
+    lib.mfm_hosttwin_atan_table(t)
+    assert np.array_equal(np.frombuffer(t, dtype=np.uint32), ora.atan_table().view(np.uint32))
+    assert lib.mfm_hosttwin_atan_table_ok() == 1
+
+
+def test_r14_matches_oracle(pkg, ora):
+    lib = pkg.load_library()
+    rng = np.random.RandomState(3)
+    vals = list(rng.randint(-(1 << 31), (1 << 31) - 1, size=20000)) + [0, 1, -1, 8191, 8192, 8193, -8192, -8193,
+                                                                        (1 << 31) - 1, -(1 << 31), 1 << 29]
+    for v in vals:
+        assert lib.mfm_hosttwin_r14(int(v)) == ora.lib().mfmo_r14(int(v))
+
+
+def test_angle_to_pcm_is_exact_for_every_float_in_0_pi(pkg, ora):
+    """(int)fmaf(m, hi, m*lo) == (int16)(float)(((double)m / M_PI) * 16384.0) (fm_demod.c:71-72) for all
+    1 078 530 012 floats m in [0, (float)pi] - the only values |fast_atan2f| can take."""
+    lib, o = pkg.load_library(), ora.lib()
+    top = int(np.float32(3.14159265358979323846).view(np.uint32))
+    step = 1 << 24
+    starts = list(range(0, top + 1, step))
+
+    def work(s):
+        n = min(step, top + 1 - s)
+        a = np.empty(n, np.int16)
+        b = np.empty(n, np.int16)
+        lib.mfm_hosttwin_pcm_range(s, n, a.ctypes.data_as(C.POINTER(C.c_int16)))
+        o.mfmo_phi_to_pcm_range(s, n, b.ctypes.data_as(C.POINTER(C.c_int16)))
+        return int((a != b).sum())
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        bad = sum(ex.map(work, starts))
+    assert bad == 0
+
+
+def _disc_both(pkg, ora, sre, sim):
+    lib, o = pkg.load_library(), ora.lib()
+    sre = np.ascontiguousarray(sre, dtype=np.int32)
+    sim = np.ascontiguousarray(sim, dtype=np.int32)
+    a = np.empty(len(sre), np.int16)
+    b = np.empty(len(sre), np.int16)
+    p32 = C.POINTER(C.c_int32)
+    lib.mfm_hosttwin_discriminate_batch(sre.ctypes.data_as(p32), sim.ctypes.data_as(p32), len(sre),
+                                        a.ctypes.data_as(C.POINTER(C.c_int16)))
+    o.mfmo_discriminate_batch(sre.ctypes.data_as(p32), sim.ctypes.data_as(p32), len(sre), ora.p16(b), 0)
+    return a, b
+
+
+def test_discriminator_matches_oracle_random(pkg, ora):
+    rng = np.random.RandomState(17)
+    parts = []
+    for bits in (3, 8, 14, 20, 26, 31):
+        lim = 1 << bits
+        parts.append(rng.randint(-lim, lim - 1, size=(400000, 2)))
+    s = np.concatenate(parts).astype(np.int32)
+    a, b = _disc_both(pkg, ora, s[:, 0], s[:, 1])
+    assert np.array_equal(a, b), f"{int((a != b).sum())} of {len(a)} differ"
+
+
+def test_discriminator_matches_oracle_edges(pkg, ora):
+    e = [0, 1, -1, 2, -2, 255, -255, 256, 32767, -32768, 65535, (1 << 24) - 1, 1 << 24, (1 << 24) + 1,
+         (1 << 30), -(1 << 30), (1 << 31) - 1, -(1 << 31), -(1 << 31) + 1, 1073741823, 16777217, 33554433]
+    sre, sim = np.meshgrid(np.array(e, np.int64), np.array(e, np.int64))
+    a, b = _disc_both(pkg, ora, sre.reshape(-1), sim.reshape(-1))
+    assert np.array_equal(a, b)
+    # exact table knots and the small-angle threshold: y/x = k/255
+    k = np.arange(-255, 256)
+    for scale in (1, 3, 1000, 1 << 16):
+        a, b = _disc_both(pkg, ora, np.full(k.shape, 255 * scale), k * scale)
+        assert np.array_equal(a, b)
+        a, b = _disc_both(pkg, ora, k * scale, np.full(k.shape, -255 * scale))
+        assert np.array_equal(a, b)
+    # dense small grid: every (s_re, s_im) in [-300, 300]^2
+    g = np.arange(-300, 301)
+    sre, sim = np.meshgrid(g, g)
+    a, b = _disc_both(pkg, ora, sre.reshape(-1), sim.reshape(-1))
+    assert np.array_equal(a, b)

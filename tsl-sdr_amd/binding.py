@@ -1,0 +1,257 @@
+"""ctypes binding of include/multifm_hip.h (libmultifm_hip.so).
+
+Used by tests/, bench.py and __graft_entry__.py.  It is a thin mirror of the C ABI: one Python
+method per entry point, errors raised as MfmError carrying the library's message.  There is no
+fallback: if the shared library is missing, importing the engine fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmultifm_hip.so")
+
+MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_DONE = 0, -1, -2, -3, -4, -5, -6
+MFM_ABI_VERSION = 1
+MFM_F_DEVICE_ONLY = 0x1
+MFM_F_TIMING = 0x2
+
+# every symbol include/multifm_hip.h declares (tests check the library exports each one)
+ABI_SYMBOLS = [
+    "mfm_engine_input_bytes", "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
+    "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
+    "mfm_engine_submit", "mfm_engine_push", "mfm_engine_fetch", "mfm_engine_release",
+    "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
+    "mfm_engine_stream", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
+    "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
+]
+
+
+class MfmError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__(f"{what}: {detail} (code {code})")
+        self.code = code
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("sample_rate_hz", C.c_uint32),
+                ("decimation", C.c_uint32), ("max_block_samples", C.c_uint32), ("flags", C.c_uint32),
+                ("ext_input", C.c_void_p * 2)]
+
+
+class Block(C.Structure):
+    _fields_ = [("first_output", C.c_uint64), ("nr_outputs", C.c_size_t), ("stride", C.c_size_t),
+                ("pcm", C.POINTER(C.c_int16)), ("iq", C.POINTER(C.c_int16))]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples_in", C.c_uint64), ("outputs", C.c_uint64), ("launches", C.c_uint64),
+                ("kernel_ms", C.c_double), ("nr_channels", C.c_uint32), ("nr_taps", C.c_uint32),
+                ("outputs_per_tile", C.c_uint32), ("lds_bytes", C.c_uint32), ("grid_last", C.c_uint32),
+                ("tail_samples", C.c_uint32), ("rot_table_entries", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmultifm_hip.so (raises if it was not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `make -C tsl-sdr_amd` (hipcc, gfx950). "
+                          "There is no CPU fallback for the multifm engine.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i16p = C.c_void_p, C.POINTER(C.c_int16)
+    lib.mfm_engine_input_bytes.restype = C.c_size_t
+    lib.mfm_engine_input_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.mfm_engine_create.argtypes = [C.POINTER(vp), C.POINTER(EngineConfig)]
+    lib.mfm_engine_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_engine_destroy.restype = None
+    lib.mfm_engine_add_channel.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_int]
+    lib.mfm_engine_add_channel_q14.argtypes = [vp, i16p, i16p, C.c_size_t, C.c_int16, C.c_int16, C.c_int]
+    lib.mfm_engine_get_channel.argtypes = [vp, C.c_uint32, i16p, i16p, i16p]
+    lib.mfm_engine_commit.argtypes = [vp]
+    lib.mfm_engine_acquire_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.mfm_engine_submit.argtypes = [vp, C.c_size_t, vp]
+    lib.mfm_engine_push.argtypes = [vp, i16p, C.c_size_t]
+    lib.mfm_engine_fetch.argtypes = [vp, C.POINTER(Block)]
+    lib.mfm_engine_release.argtypes = [vp]
+    lib.mfm_engine_last_output_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                                  C.POINTER(C.c_size_t), C.POINTER(vp)]
+    lib.mfm_engine_sync.argtypes = [vp]
+    lib.mfm_engine_reset.argtypes = [vp]
+    lib.mfm_engine_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.mfm_engine_stream.argtypes = [vp]
+    lib.mfm_engine_stream.restype = vp
+    lib.mfm_strerror.argtypes = [C.c_int]
+    lib.mfm_strerror.restype = C.c_char_p
+    lib.mfm_last_error.restype = C.c_char_p
+    lib.mfm_hosttwin_discriminate.argtypes = [C.c_int32, C.c_int32]
+    lib.mfm_hosttwin_discriminate.restype = C.c_int32
+    lib.mfm_hosttwin_discriminate_batch.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, i16p]
+    lib.mfm_hosttwin_discriminate_batch.restype = None
+    lib.mfm_hosttwin_r14.argtypes = [C.c_int32]
+    lib.mfm_hosttwin_r14.restype = C.c_int16
+    lib.mfm_hosttwin_pcm_range.argtypes = [C.c_uint32, C.c_uint32, i16p]
+    lib.mfm_hosttwin_pcm_range.restype = None
+    lib.mfm_hosttwin_atan_table.argtypes = [C.POINTER(C.c_float)]
+    lib.mfm_hosttwin_atan_table.restype = None
+    lib.mfm_hosttwin_atan_table_ok.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _i16p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int16))
+
+
+class Engine:
+    """One multifm channel engine (struct mfm_engine) on one GPU."""
+
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, flags=0, ext_input=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = EngineConfig()
+        cfg.abi_version = MFM_ABI_VERSION
+        cfg.device = device
+        cfg.sample_rate_hz = sample_rate_hz
+        cfg.decimation = decimation
+        cfg.max_block_samples = max_block_samples
+        cfg.flags = flags
+        if ext_input is not None:
+            cfg.ext_input[0], cfg.ext_input[1] = ext_input
+        self.sample_rate_hz, self.decimation, self.max_block_samples = sample_rate_hz, decimation, max_block_samples
+        self.nr_taps = 0
+        self.nr_channels = 0
+        self._chk(self.lib.mfm_engine_create(C.byref(self.h), C.byref(cfg)), "mfm_engine_create")
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise MfmError(rc, what, self.lib.mfm_last_error().decode() or self.lib.mfm_strerror(rc).decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_engine_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- channel set -------------------------------------------------------------------
+    def add_channel(self, offset_hz, lpf_taps, gain=1.0, want_iq=False):
+        taps = np.ascontiguousarray(lpf_taps, dtype=np.float64)
+        idx = self._chk(self.lib.mfm_engine_add_channel(self.h, int(offset_hz),
+                                                        taps.ctypes.data_as(C.POINTER(C.c_double)), taps.size,
+                                                        float(gain), int(want_iq)), "mfm_engine_add_channel")
+        self.nr_taps = taps.size
+        self.nr_channels = idx + 1
+        return idx
+
+    def add_channel_q14(self, coeff_re, coeff_im, incr, want_iq=False):
+        cre = np.ascontiguousarray(coeff_re, dtype=np.int16)
+        cim = np.ascontiguousarray(coeff_im, dtype=np.int16)
+        idx = self._chk(self.lib.mfm_engine_add_channel_q14(self.h, _i16p(cre), _i16p(cim), cre.size,
+                                                            int(incr[0]), int(incr[1]), int(want_iq)),
+                        "mfm_engine_add_channel_q14")
+        self.nr_taps = cre.size
+        self.nr_channels = idx + 1
+        return idx
+
+    def get_channel(self, chan):
+        cre = np.zeros(self.nr_taps, dtype=np.int16)
+        cim = np.zeros(self.nr_taps, dtype=np.int16)
+        incr = np.zeros(2, dtype=np.int16)
+        self._chk(self.lib.mfm_engine_get_channel(self.h, chan, _i16p(cre), _i16p(cim), _i16p(incr)),
+                  "mfm_engine_get_channel")
+        return cre, cim, incr
+
+    def commit(self):
+        self._chk(self.lib.mfm_engine_commit(self.h), "mfm_engine_commit")
+
+    # -- data path ---------------------------------------------------------------------
+    def acquire_input(self):
+        ptr, cap = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.mfm_engine_acquire_input(self.h, C.byref(ptr), C.byref(cap)), "mfm_engine_acquire_input")
+        return ptr.value, cap.value
+
+    def submit(self, nr_samples, producer_stream=None):
+        self._chk(self.lib.mfm_engine_submit(self.h, nr_samples, C.c_void_p(producer_stream or 0)),
+                  "mfm_engine_submit")
+
+    def push(self, iq):
+        """iq: int16 array of interleaved I,Q (2*n elements)."""
+        a = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)
+        return self.lib.mfm_engine_push(self.h, _i16p(a), a.size // 2)
+
+    def fetch(self):
+        """Oldest finished block as (first_output, pcm[C][n] copy, iq[C][n][2] copy or None); None when drained."""
+        blk = Block()
+        rc = self.lib.mfm_engine_fetch(self.h, C.byref(blk))
+        if rc == MFM_E_DONE:
+            return None
+        self._chk(rc, "mfm_engine_fetch")
+        n, stride, nch = blk.nr_outputs, blk.stride, self.nr_channels
+        pcm = np.ctypeslib.as_array(blk.pcm, shape=(nch, stride))[:, :n].copy()
+        iq = None
+        if blk.iq:
+            iq = np.ctypeslib.as_array(blk.iq, shape=(nch, stride, 2))[:, :n, :].copy()
+        first = blk.first_output
+        self._chk(self.lib.mfm_engine_release(self.h), "mfm_engine_release")
+        return first, pcm, iq
+
+    def run(self, iq, block_samples):
+        """Push a whole stream in blocks, draining as needed.  Returns (pcm[C][N], iq[C][N][2] | None)."""
+        a = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+        pcm_parts, iq_parts = [], []
+
+        def drain():
+            while True:
+                got = self.fetch()
+                if got is None:
+                    return
+                pcm_parts.append(got[1])
+                if got[2] is not None:
+                    iq_parts.append(got[2])
+
+        pos = 0
+        while pos < a.shape[0]:
+            n = min(block_samples, a.shape[0] - pos)
+            rc = self.push(a[pos:pos + n])
+            if rc == MFM_E_BUSY:
+                drain()
+                continue
+            self._chk(rc, "mfm_engine_push")
+            pos += n
+        drain()
+        nch = self.nr_channels
+        pcm = np.concatenate(pcm_parts, axis=1) if pcm_parts else np.zeros((nch, 0), np.int16)
+        iqo = np.concatenate(iq_parts, axis=1) if iq_parts else None
+        return pcm, iqo
+
+    def last_output_device(self):
+        p, st, n, q = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_void_p()
+        self._chk(self.lib.mfm_engine_last_output_device(self.h, C.byref(p), C.byref(st), C.byref(n), C.byref(q)),
+                  "mfm_engine_last_output_device")
+        return p.value, st.value, n.value, q.value
+
+    def sync(self):
+        self._chk(self.lib.mfm_engine_sync(self.h), "mfm_engine_sync")
+
+    def reset(self):
+        self._chk(self.lib.mfm_engine_reset(self.h), "mfm_engine_reset")
+
+    def stats(self):
+        st = Stats()
+        self._chk(self.lib.mfm_engine_get_stats(self.h, C.byref(st)), "mfm_engine_get_stats")
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    @property
+    def stream(self):
+        return self.lib.mfm_engine_stream(self.h)

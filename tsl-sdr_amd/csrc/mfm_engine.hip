@@ -1,0 +1,1016 @@
+/*
+ * mfm_engine.hip - host side of the MI355X multifm channel engine behind include/multifm_hip.h.
+ *
+ * Owns: the channel set (Q14 taps, rotator tables), two device input staging buffers holding
+ * [history tail | new block] contiguously, a small ring of output slots (device + pinned host
+ * mirror), the per-channel carry state (rotator index, last filtered sample) and three HIP
+ * streams (copy-in, compute, copy-out) so H2D, the fused kernel and D2H of consecutive blocks
+ * overlap.  What the reference keeps per channel thread in struct direct_fir / struct
+ * multifm_fm_demod (filter/direct_fir.h:9-74, multifm/fm_demod.c:14-18) lives here per engine.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/multifm_hip.h"
+#include "mfm_kernel.h"
+#include "mfm_numerics.h"
+#include "mfm_taps.h"
+
+extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, int dbg_iq, uint32_t lds_bytes,
+                                                hipStream_t stream);
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t err_ = (expr);                                                                            \
+        if (err_ != hipSuccess) {                                                                            \
+            return fail(MFM_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err_), __FILE__,     \
+                        __LINE__);                                                                           \
+        }                                                                                                    \
+    } while (0)
+
+/* FNV-1a of the 257 float bit patterns of the fast_atan2f table */
+constexpr uint64_t MFM_ATAN_TABLE_FNV1A = 0x674d1aab1787b44bull;
+
+constexpr int kOutSlots = 4;      /* output ring depth (2 in device-only mode) */
+constexpr int kTimingPairs = 256; /* event pairs kept before the oldest is folded into the total */
+constexpr uint32_t kMaxOutputsPerTile = 128;
+constexpr uint64_t kMaxRotEntries = 1ull << 26; /* per distinct increment: 512 MiB of table */
+
+struct Channel {
+    std::vector<int16_t> cre, cim;
+    int16_t incr_re = 0, incr_im = 0;
+    bool want_iq = false;
+    /* rotator table placement */
+    uint64_t rot_base = 0;
+    uint32_t mu = 0, lam = 1;
+};
+
+inline void rot_step(int16_t &rr, int16_t &ri, int16_t ir, int16_t ii)
+{
+    /* filter/direct_fir.c:166-167 -> filter/complex.h:51-62 */
+    const int32_t a = rr, b = ri;
+    const int16_t nr = (int16_t)mfm_r14_wide(a * ir - b * ii);
+    const int16_t ni = (int16_t)mfm_r14_wide(a * ii + b * ir);
+    rr = nr;
+    ri = ni;
+}
+
+/* Brent's cycle finder on the rotator recurrence started at (16384, 0) (direct_fir.c:78-79). */
+bool rot_cycle(int16_t ir, int16_t ii, uint64_t limit, uint32_t *mu_out, uint32_t *lam_out)
+{
+    int16_t tr = 16384, ti = 0, hr = 16384, hi = 0;
+    uint64_t power = 1, lam = 1;
+    rot_step(hr, hi, ir, ii);
+    while (!(tr == hr && ti == hi)) {
+        if (power == lam) {
+            tr = hr;
+            ti = hi;
+            power *= 2;
+            lam = 0;
+        }
+        rot_step(hr, hi, ir, ii);
+        lam++;
+        if (lam > limit) {
+            return false;
+        }
+    }
+    tr = 16384, ti = 0, hr = 16384, hi = 0;
+    for (uint64_t i = 0; i < lam; i++) {
+        rot_step(hr, hi, ir, ii);
+    }
+    uint64_t mu = 0;
+    while (!(tr == hr && ti == hi)) {
+        rot_step(tr, ti, ir, ii);
+        rot_step(hr, hi, ir, ii);
+        mu++;
+        if (mu > limit) {
+            return false;
+        }
+    }
+    *mu_out = (uint32_t)mu;
+    *lam_out = (uint32_t)lam;
+    return true;
+}
+
+struct OutSlot {
+    int16_t *d_pcm = nullptr;
+    uint32_t *d_iq = nullptr;
+    int16_t *h_pcm = nullptr;
+    uint32_t *h_iq = nullptr;
+    hipEvent_t ready = nullptr; /* D2H (or, device-only, the kernel) finished */
+    uint64_t first_output = 0;
+    uint32_t nr_outputs = 0;
+    enum { FREE, INFLIGHT, FETCHED } state = FREE;
+};
+
+} /* namespace */
+
+struct mfm_engine {
+    mfm_engine_config cfg{};
+    std::vector<Channel> chans;
+    uint32_t nr_taps = 0;
+    bool committed = false;
+    bool any_iq = false;
+
+    /* geometry */
+    int opl = 2;
+    uint32_t rs2 = 0, lds_bytes = 0, lut_off = 0, nchunks = 0, ngroups = 0, gpw = 0, nslices = 0;
+    uint32_t cap_in = 0;     /* samples per input buffer */
+    uint32_t out_stride = 0; /* outputs per channel one submit can produce (even) */
+
+    /* device tables */
+    uint32_t *d_coef = nullptr, *d_tapoff = nullptr;
+    mfm_chan_info *d_info = nullptr;
+    uint2 *d_rot = nullptr;
+    float2 *d_lut = nullptr;
+    mfm_chan_state *d_state[2] = { nullptr, nullptr };
+    uint64_t rot_entries = 0;
+
+    /* input staging */
+    uint32_t *d_in[2] = { nullptr, nullptr };
+    bool own_in = false;
+    uint32_t *h_in[2] = { nullptr, nullptr }; /* pinned, for push() */
+    hipEvent_t in_free[2] = { nullptr, nullptr };
+    hipEvent_t in_ready = nullptr;
+    int cur_in = 0;
+    uint32_t tail = 0; /* samples of history at the front of d_in[cur_in] */
+
+    /* outputs */
+    OutSlot slots[kOutSlots];
+    int nslots = kOutSlots;
+    uint64_t submit_seq = 0; /* submits that produced outputs */
+    uint64_t fetch_seq = 0;
+    int last_slot = -1;
+
+    hipStream_t s_in = nullptr, s_compute = nullptr, s_out = nullptr;
+    hipEvent_t kernel_done = nullptr;
+
+    /* stream bookkeeping */
+    int parity = 0;
+    uint64_t samples_in = 0, outputs = 0, launches = 0;
+    uint32_t grid_last = 0;
+
+    /* timing */
+    hipEvent_t t0[kTimingPairs], t1[kTimingPairs];
+    uint64_t t_head = 0, t_tail = 0;
+    double kernel_ms = 0.0;
+};
+
+namespace {
+
+int fold_timing(mfm_engine *e, bool all)
+{
+    while (e->t_tail < e->t_head && (all || e->t_head - e->t_tail >= (uint64_t)kTimingPairs)) {
+        const int i = (int)(e->t_tail % kTimingPairs);
+        HIP_TRY(hipEventSynchronize(e->t1[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->t0[i], e->t1[i]));
+        e->kernel_ms += ms;
+        e->t_tail++;
+    }
+    return MFM_OK;
+}
+
+void free_device(mfm_engine *e)
+{
+    if (!e->committed) {
+        return;
+    }
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(e->d_coef);
+    (void)hipFree(e->d_tapoff);
+    (void)hipFree(e->d_info);
+    (void)hipFree(e->d_rot);
+    (void)hipFree(e->d_lut);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(e->d_state[i]);
+        if (e->own_in) {
+            (void)hipFree(e->d_in[i]);
+        }
+        if (e->h_in[i]) {
+            (void)hipHostFree(e->h_in[i]);
+        }
+        if (e->in_free[i]) {
+            (void)hipEventDestroy(e->in_free[i]);
+        }
+    }
+    for (int i = 0; i < kOutSlots; i++) {
+        OutSlot &s = e->slots[i];
+        (void)hipFree(s.d_pcm);
+        (void)hipFree(s.d_iq);
+        if (s.h_pcm) {
+            (void)hipHostFree(s.h_pcm);
+        }
+        if (s.h_iq) {
+            (void)hipHostFree(s.h_iq);
+        }
+        if (s.ready) {
+            (void)hipEventDestroy(s.ready);
+        }
+    }
+    if (e->cfg.flags & MFM_F_TIMING) {
+        for (int i = 0; i < kTimingPairs; i++) {
+            (void)hipEventDestroy(e->t0[i]);
+            (void)hipEventDestroy(e->t1[i]);
+        }
+    }
+    if (e->in_ready) {
+        (void)hipEventDestroy(e->in_ready);
+    }
+    if (e->kernel_done) {
+        (void)hipEventDestroy(e->kernel_done);
+    }
+    if (e->s_in) {
+        (void)hipStreamDestroy(e->s_in);
+    }
+    if (e->s_compute) {
+        (void)hipStreamDestroy(e->s_compute);
+    }
+    if (e->s_out) {
+        (void)hipStreamDestroy(e->s_out);
+    }
+    e->committed = false;
+}
+
+uint32_t input_capacity(uint32_t max_block, uint32_t nr_taps)
+{
+    /* history tail (< nr_taps samples) + block, rounded to 64 samples */
+    return (max_block + nr_taps + 63u) & ~63u;
+}
+
+int write_state_fresh(mfm_engine *e)
+{
+    std::vector<mfm_chan_state> st(e->ngroups * MFM_CG);
+    for (auto &s : st) {
+        s.carry_q = 0; /* fm_demod.c: last sample starts at 0 (TZAALLOC, :29) */
+        s.kb = 0;
+    }
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMemcpy(e->d_state[i], st.data(), st.size() * sizeof(mfm_chan_state), hipMemcpyHostToDevice));
+    }
+    e->parity = 0;
+    return MFM_OK;
+}
+
+} /* namespace */
+
+/* ------------------------------------------------------------------------------------- */
+
+extern "C" {
+
+const char *mfm_strerror(int err)
+{
+    switch (err) {
+    case MFM_OK: return "ok";
+    case MFM_E_INVAL: return "invalid argument";
+    case MFM_E_NOMEM: return "out of memory";
+    case MFM_E_BUSY: return "busy";
+    case MFM_E_DEVICE: return "HIP device error";
+    case MFM_E_STATE: return "invalid state";
+    case MFM_E_DONE: return "done";
+    default: return "unknown error";
+    }
+}
+
+const char *mfm_last_error(void)
+{
+    return g_last_error;
+}
+
+size_t mfm_engine_input_bytes(uint32_t max_block_samples, uint32_t nr_taps)
+{
+    return (size_t)input_capacity(max_block_samples, nr_taps) * sizeof(uint32_t);
+}
+
+int mfm_engine_create(struct mfm_engine **pe, const struct mfm_engine_config *cfg)
+{
+    if (!pe || !cfg) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    *pe = nullptr;
+    if (cfg->abi_version != MFM_ABI_VERSION) {
+        return fail(MFM_E_INVAL, "ABI version %u, library is %u", cfg->abi_version, MFM_ABI_VERSION);
+    }
+    if (0 == cfg->decimation || 0 == cfg->sample_rate_hz || 0 == cfg->max_block_samples) {
+        return fail(MFM_E_INVAL, "decimation, sample rate and max block must be non-zero");
+    }
+    if (cfg->max_block_samples > (1u << 30)) {
+        return fail(MFM_E_INVAL, "max_block_samples %u too large", cfg->max_block_samples);
+    }
+    if ((cfg->ext_input[0] == nullptr) != (cfg->ext_input[1] == nullptr)) {
+        return fail(MFM_E_INVAL, "ext_input needs both buffers or neither");
+    }
+    mfm_engine *e = new (std::nothrow) mfm_engine();
+    if (!e) {
+        return fail(MFM_E_NOMEM, "engine allocation failed");
+    }
+    e->cfg = *cfg;
+    *pe = e;
+    return MFM_OK;
+}
+
+void mfm_engine_destroy(struct mfm_engine **pe)
+{
+    if (!pe || !*pe) {
+        return;
+    }
+    free_device(*pe);
+    delete *pe;
+    *pe = nullptr;
+}
+
+int mfm_engine_add_channel_q14(struct mfm_engine *e, const int16_t *coeff_re, const int16_t *coeff_im,
+                               size_t nr_taps, int16_t rot_incr_re, int16_t rot_incr_im, int want_iq)
+{
+    if (!e || !coeff_re || !coeff_im || 0 == nr_taps) {
+        return fail(MFM_E_INVAL, "NULL or empty taps");
+    }
+    if (e->committed) {
+        return fail(MFM_E_STATE, "channel set is frozen after commit");
+    }
+    if (!e->chans.empty() && nr_taps != e->nr_taps) {
+        return fail(MFM_E_INVAL, "all channels share one tap count (%u), got %zu", e->nr_taps, nr_taps);
+    }
+    if (nr_taps < e->cfg.decimation) {
+        /* the reference dereferences a NULL sb_active in this configuration (direct_fir.c:394-398) */
+        return fail(MFM_E_INVAL, "taps (%zu) < decimation (%u) is not a valid multifm configuration", nr_taps,
+                    e->cfg.decimation);
+    }
+    if (nr_taps > 65535) {
+        return fail(MFM_E_INVAL, "too many taps");
+    }
+    for (size_t i = 0; i < nr_taps; i++) {
+        if (coeff_im[i] == INT16_MIN) {
+            /* -ci is not an int16: the packed (cr,-ci) operand cannot hold it */
+            return fail(MFM_E_INVAL, "imaginary tap %zu is -32768 (a tap of magnitude 2.0); not supported", i);
+        }
+    }
+    Channel c;
+    c.cre.assign(coeff_re, coeff_re + nr_taps);
+    c.cim.assign(coeff_im, coeff_im + nr_taps);
+    c.incr_re = rot_incr_re;
+    c.incr_im = rot_incr_im;
+    c.want_iq = want_iq != 0;
+    e->nr_taps = (uint32_t)nr_taps;
+    e->chans.push_back(std::move(c));
+    return (int)e->chans.size() - 1;
+}
+
+int mfm_engine_add_channel(struct mfm_engine *e, int32_t offset_hz, const double *lpf_taps, size_t nr_taps,
+                           double channel_gain, int want_iq)
+{
+    if (!e || !lpf_taps || 0 == nr_taps) {
+        return fail(MFM_E_INVAL, "NULL or empty taps");
+    }
+    std::vector<int16_t> cre(nr_taps), cim(nr_taps);
+    int16_t ir = 0, ii = 0;
+    mfm_taps_rotate_q14(lpf_taps, nr_taps, offset_hz, e->cfg.sample_rate_hz, channel_gain, cre.data(), cim.data());
+    mfm_taps_rot_increment(offset_hz, e->cfg.sample_rate_hz, e->cfg.decimation, &ir, &ii);
+    return mfm_engine_add_channel_q14(e, cre.data(), cim.data(), nr_taps, ir, ii, want_iq);
+}
+
+int mfm_engine_get_channel(struct mfm_engine *e, uint32_t chan, int16_t *coeff_re, int16_t *coeff_im,
+                           int16_t rot_incr[2])
+{
+    if (!e || chan >= e->chans.size()) {
+        return fail(MFM_E_INVAL, "no such channel");
+    }
+    const Channel &c = e->chans[chan];
+    if (coeff_re) {
+        memcpy(coeff_re, c.cre.data(), c.cre.size() * sizeof(int16_t));
+    }
+    if (coeff_im) {
+        memcpy(coeff_im, c.cim.data(), c.cim.size() * sizeof(int16_t));
+    }
+    if (rot_incr) {
+        rot_incr[0] = c.incr_re;
+        rot_incr[1] = c.incr_im;
+    }
+    return MFM_OK;
+}
+
+int mfm_engine_commit(struct mfm_engine *e)
+{
+    if (!e) {
+        return fail(MFM_E_INVAL, "NULL engine");
+    }
+    if (e->committed) {
+        return fail(MFM_E_STATE, "already committed");
+    }
+    if (e->chans.empty()) {
+        return fail(MFM_E_INVAL, "no channels");
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        return fail(MFM_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    }
+    if (e->cfg.device < 0 || e->cfg.device >= ndev) {
+        return fail(MFM_E_DEVICE, "device %d out of range (%d devices)", e->cfg.device, ndev);
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+
+    const uint32_t T = e->nr_taps, D = e->cfg.decimation, C = (uint32_t)e->chans.size();
+    const bool dev_only = (e->cfg.flags & MFM_F_DEVICE_ONLY) != 0;
+
+    /* ---- geometry: outputs per lane, LDS tile ---- */
+    const uint32_t qrows = (T + D - 1) / D;
+    auto tile_dwords = [&](int opl, uint32_t *rs2) {
+        const uint32_t rows = 64u * opl - 1u + qrows;
+        *rs2 = rows | 1u; /* odd stride: transposing stores hit 32 different banks */
+        return (uint64_t)D * *rs2;
+    };
+    uint32_t rs2 = 0;
+    int opl = 2;
+    const char *force = getenv("MFM_OPL");
+    uint64_t dw = tile_dwords(2, &rs2);
+    if ((force && atoi(force) == 1) || (dw + 512) * 4 > 53 * 1024) {
+        opl = 1;
+        dw = tile_dwords(1, &rs2);
+    }
+    if ((dw + 512) * 4 > 160 * 1024) {
+        return fail(MFM_E_INVAL, "decimation %u needs a %llu-byte LDS tile (> 160 KiB)", D,
+                    (unsigned long long)(dw + 512) * 4);
+    }
+    e->opl = opl;
+    e->rs2 = rs2;
+    e->lut_off = (uint32_t)((dw + 3) & ~3ull);
+    e->lds_bytes = (e->lut_off + 512) * 4;
+    e->nchunks = (T + MFM_TG - 1) / MFM_TG;
+    e->ngroups = (C + MFM_CG - 1) / MFM_CG;
+    e->gpw = MFM_NW;
+    if (const char *g = getenv("MFM_GPW")) {
+        e->gpw = std::max(1, atoi(g));
+    }
+    e->gpw = std::min(e->gpw, e->ngroups);
+    e->nslices = (e->ngroups + e->gpw - 1) / e->gpw;
+    e->cap_in = input_capacity(e->cfg.max_block_samples, T);
+    e->out_stride = ((e->cap_in - T) / D + 1 + 1) & ~1u;
+    e->any_iq = false;
+    for (const Channel &c : e->chans) {
+        e->any_iq |= c.want_iq;
+    }
+
+    /* ---- tap table: [group][chunk][tap in chunk][channel in group]{(cr,-ci),(ci,cr)} ---- */
+    const size_t coef_dwords = (size_t)e->ngroups * e->nchunks * MFM_TG * MFM_CG * 2;
+    std::vector<uint32_t> coef(coef_dwords, 0u);
+    for (uint32_t c = 0; c < C; c++) {
+        const Channel &ch = e->chans[c];
+        const uint32_t g = c / MFM_CG, cc = c % MFM_CG;
+        for (uint32_t i = 0; i < T; i++) {
+            const uint32_t chunk = i / MFM_TG, k = i % MFM_TG;
+            const size_t at = ((((size_t)g * e->nchunks + chunk) * MFM_TG + k) * MFM_CG + cc) * 2;
+            const int32_t cr = ch.cre[i], ci = ch.cim[i];
+            coef[at + 0] = mfm_pack16(cr, -ci);
+            coef[at + 1] = mfm_pack16(ci, cr);
+        }
+    }
+    std::vector<uint32_t> tapoff((size_t)e->nchunks * MFM_TG, 0u);
+    for (uint32_t i = 0; i < T; i++) {
+        tapoff[i] = ((i % D) * rs2 + i / D) * 4u;
+    }
+
+    /* ---- rotator tables (one per distinct increment) ---- */
+    std::map<std::pair<int16_t, int16_t>, std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> seen;
+    std::vector<uint2> rot;
+    for (Channel &ch : e->chans) {
+        const auto key = std::make_pair(ch.incr_re, ch.incr_im);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            uint32_t mu = 0, lam = 1;
+            int16_t ir = ch.incr_re, ii = ch.incr_im;
+            if (0 == ir && 0 == ii) {
+                /* direct_fir.c:406 skips derotation for a zero increment; a constant (16384,0)
+                 * rotator is the identity through both Q14 roundings */
+                ir = 16384;
+                ii = 0;
+            }
+            if (!rot_cycle(ir, ii, kMaxRotEntries, &mu, &lam)) {
+                return fail(MFM_E_INVAL, "rotator (%d,%d) has no cycle within %llu steps", ir, ii,
+                            (unsigned long long)kMaxRotEntries);
+            }
+            const uint64_t n = (uint64_t)mu + lam + kMaxOutputsPerTile;
+            const uint64_t base = rot.size() + 1; /* one dummy entry in front: index -1 is readable */
+            rot.resize(rot.size() + 1 + n);
+            rot[base - 1] = make_uint2(0, 0);
+            int16_t rr = 16384, ri = 0;
+            for (uint64_t k = 0; k < n; k++) {
+                if (ri == INT16_MIN) {
+                    return fail(MFM_E_INVAL, "rotator state reached -32768");
+                }
+                rot[base + k] = make_uint2(mfm_pack16(rr, -(int32_t)ri), mfm_pack16(ri, rr));
+                rot_step(rr, ri, ir, ii);
+            }
+            it = seen.emplace(key, std::make_pair(base, std::make_pair(mu, lam))).first;
+        }
+        ch.rot_base = it->second.first;
+        ch.mu = it->second.second.first;
+        ch.lam = it->second.second.second;
+    }
+    e->rot_entries = rot.size();
+
+    std::vector<mfm_chan_info> info((size_t)e->ngroups * MFM_CG);
+    memset(info.data(), 0, info.size() * sizeof(mfm_chan_info));
+    for (uint32_t c = 0; c < C; c++) {
+        info[c].rot_base = e->chans[c].rot_base;
+        info[c].mu = e->chans[c].mu;
+        info[c].lam = e->chans[c].lam;
+        info[c].lam_magic = (uint32_t)std::min<uint64_t>(0xffffffffull, (1ull << 32) / e->chans[c].lam);
+    }
+
+    /* ---- atan LUT: fast_atan2f.c:14-81, entries atan(i/255) at 7 significant digits ---- */
+    float tbl[257];
+    mfm_hosttwin_atan_table(tbl);
+    if (!mfm_hosttwin_atan_table_ok()) {
+        return fail(MFM_E_INVAL, "atan table self-check failed (host libm rounds atan() differently)");
+    }
+    std::vector<float2> lut(256);
+    for (int i = 0; i < 256; i++) {
+        lut[i] = make_float2(tbl[i], tbl[i + 1] - tbl[i]);
+    }
+
+    /* ---- device allocations ---- */
+    e->committed = true; /* from here free_device() releases whatever was allocated */
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->in_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->kernel_done, hipEventDisableTiming));
+
+    HIP_TRY(hipMalloc(&e->d_coef, coef.size() * 4));
+    HIP_TRY(hipMemcpy(e->d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&e->d_tapoff, tapoff.size() * 4));
+    HIP_TRY(hipMemcpy(e->d_tapoff, tapoff.data(), tapoff.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&e->d_info, info.size() * sizeof(mfm_chan_info)));
+    HIP_TRY(hipMemcpy(e->d_info, info.data(), info.size() * sizeof(mfm_chan_info), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&e->d_rot, rot.size() * sizeof(uint2)));
+    HIP_TRY(hipMemcpy(e->d_rot, rot.data(), rot.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&e->d_lut, lut.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(e->d_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMalloc(&e->d_state[i], info.size() * sizeof(mfm_chan_state)));
+    }
+    {
+        int rc = write_state_fresh(e);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+    }
+
+    const size_t in_bytes = (size_t)e->cap_in * 4;
+    e->own_in = e->cfg.ext_input[0] == nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (e->own_in) {
+            HIP_TRY(hipMalloc(&e->d_in[i], in_bytes));
+        } else {
+            e->d_in[i] = static_cast<uint32_t *>(e->cfg.ext_input[i]);
+        }
+        HIP_TRY(hipEventCreateWithFlags(&e->in_free[i], hipEventDisableTiming));
+    }
+
+    e->nslots = dev_only ? 2 : kOutSlots;
+    for (int i = 0; i < e->nslots; i++) {
+        OutSlot &s = e->slots[i];
+        const size_t pcm_bytes = (size_t)C * e->out_stride * sizeof(int16_t);
+        HIP_TRY(hipMalloc(&s.d_pcm, pcm_bytes));
+        if (e->any_iq) {
+            HIP_TRY(hipMalloc(&s.d_iq, pcm_bytes * 2));
+        }
+        if (!dev_only) {
+            HIP_TRY(hipHostMalloc(&s.h_pcm, pcm_bytes, hipHostMallocDefault));
+            if (e->any_iq) {
+                HIP_TRY(hipHostMalloc(&s.h_iq, pcm_bytes * 2, hipHostMallocDefault));
+            }
+        }
+        HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+    }
+    if (e->cfg.flags & MFM_F_TIMING) {
+        for (int i = 0; i < kTimingPairs; i++) {
+            HIP_TRY(hipEventCreate(&e->t0[i]));
+            HIP_TRY(hipEventCreate(&e->t1[i]));
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return MFM_OK;
+}
+
+int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacity_samples)
+{
+    if (!e || !d_dst) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    /* the kernel that last read this buffer (two submits ago) must be done with it */
+    HIP_TRY(hipEventSynchronize(e->in_free[e->cur_in]));
+    *d_dst = e->d_in[e->cur_in] + e->tail;
+    if (capacity_samples) {
+        *capacity_samples = e->cap_in - e->tail;
+    }
+    return MFM_OK;
+}
+
+int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream)
+{
+    if (!e) {
+        return fail(MFM_E_INVAL, "NULL engine");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (0 == nr_samples) {
+        /* receiver_sample_buf_deliver() treats an empty buffer as a bug (receiver.c:84) */
+        return fail(MFM_E_INVAL, "empty block");
+    }
+    if (nr_samples > e->cap_in - e->tail || nr_samples > e->cfg.max_block_samples) {
+        return fail(MFM_E_INVAL, "block of %zu samples exceeds max_block_samples %u", nr_samples,
+                    e->cfg.max_block_samples);
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+
+    const uint32_t T = e->nr_taps, D = e->cfg.decimation, C = (uint32_t)e->chans.size();
+    const bool dev_only = (e->cfg.flags & MFM_F_DEVICE_ONLY) != 0;
+    const int cur = e->cur_in;
+    const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
+    const uint32_t n_new = n_avail >= T ? (n_avail - T) / D + 1 : 0;
+
+    OutSlot *slot = nullptr;
+    int slot_idx = -1;
+    if (n_new) {
+        slot_idx = (int)(e->submit_seq % e->nslots);
+        slot = &e->slots[slot_idx];
+        if (!dev_only && slot->state != OutSlot::FREE) {
+            return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
+        }
+    }
+
+    if (producer_stream) {
+        HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
+        HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
+    }
+
+    if (n_new) {
+        const uint32_t ot = 64u * e->opl;
+        mfm_launch L{};
+        L.x = e->d_in[cur];
+        L.n_avail = n_avail;
+        L.n_new = n_new;
+        L.decim = D;
+        L.nchunks = e->nchunks;
+        L.nstage = (ot - 1) * D + T;
+        L.rs2 = e->rs2;
+        L.lut_off = e->lut_off;
+        L.ngroups = e->ngroups;
+        L.gpw = e->gpw;
+        L.nslices = e->nslices;
+        L.ntiles = (n_new + ot - 2) / (ot - 1);
+        L.nchan = C;
+        L.out_stride = e->out_stride;
+        L.coef = e->d_coef;
+        L.tapoff = e->d_tapoff;
+        L.info = e->d_info;
+        L.rot = e->d_rot;
+        L.st_in = e->d_state[e->parity];
+        L.st_out = e->d_state[e->parity ^ 1];
+        L.lut = e->d_lut;
+        L.pcm = slot->d_pcm;
+        L.iq_dbg = e->any_iq ? slot->d_iq : nullptr;
+
+        if (!dev_only) {
+            /* the previous D2H out of this slot must have drained before the kernel rewrites it */
+            HIP_TRY(hipStreamWaitEvent(e->s_compute, slot->ready, 0));
+        }
+        const bool timing = (e->cfg.flags & MFM_F_TIMING) != 0;
+        int ti = 0;
+        if (timing) {
+            int rc = fold_timing(e, false);
+            if (rc != MFM_OK) {
+                return rc;
+            }
+            ti = (int)(e->t_head % kTimingPairs);
+            HIP_TRY(hipEventRecord(e->t0[ti], e->s_compute));
+        }
+        HIP_TRY(mfm_launch_channel_kernel(&L, e->opl, e->any_iq ? 1 : 0, e->lds_bytes, e->s_compute));
+        if (timing) {
+            HIP_TRY(hipEventRecord(e->t1[ti], e->s_compute));
+            e->t_head++;
+        }
+        e->parity ^= 1;
+        e->launches++;
+        e->grid_last = ((L.ntiles + 7) / 8) * 8 * L.nslices;
+    }
+
+    /* carry the unconsumed tail to the front of the other staging buffer */
+    const uint32_t consumed = n_new * D;
+    const uint32_t new_tail = n_avail - consumed;
+    if (new_tail) {
+        HIP_TRY(hipMemcpyAsync(e->d_in[cur ^ 1], e->d_in[cur] + consumed, (size_t)new_tail * 4,
+                               hipMemcpyDeviceToDevice, e->s_compute));
+    }
+    HIP_TRY(hipEventRecord(e->in_free[cur], e->s_compute));
+
+    if (n_new) {
+        slot->first_output = e->outputs;
+        slot->nr_outputs = n_new;
+        if (dev_only) {
+            HIP_TRY(hipEventRecord(slot->ready, e->s_compute));
+        } else {
+            HIP_TRY(hipEventRecord(e->kernel_done, e->s_compute));
+            HIP_TRY(hipStreamWaitEvent(e->s_out, e->kernel_done, 0));
+            const size_t row = (size_t)e->out_stride * sizeof(int16_t);
+            HIP_TRY(hipMemcpy2DAsync(slot->h_pcm, row, slot->d_pcm, row, (size_t)n_new * sizeof(int16_t), C,
+                                     hipMemcpyDeviceToHost, e->s_out));
+            if (e->any_iq) {
+                HIP_TRY(hipMemcpy2DAsync(slot->h_iq, row * 2, slot->d_iq, row * 2, (size_t)n_new * 4, C,
+                                         hipMemcpyDeviceToHost, e->s_out));
+            }
+            HIP_TRY(hipEventRecord(slot->ready, e->s_out));
+            slot->state = OutSlot::INFLIGHT;
+        }
+        e->last_slot = slot_idx;
+        e->submit_seq++;
+        e->outputs += n_new;
+    }
+
+    e->tail = new_tail;
+    e->cur_in = cur ^ 1;
+    e->samples_in += nr_samples;
+    return MFM_OK;
+}
+
+int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
+{
+    if (!e || !iq) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (0 == nr_samples || nr_samples > e->cfg.max_block_samples) {
+        return fail(MFM_E_INVAL, "block of %zu samples (max %u)", nr_samples, e->cfg.max_block_samples);
+    }
+    /* refuse before staging anything if the output ring is full, so a caller can drain and retry */
+    if (!(e->cfg.flags & MFM_F_DEVICE_ONLY)) {
+        const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
+        if (n_avail >= e->nr_taps && e->slots[e->submit_seq % e->nslots].state != OutSlot::FREE) {
+            return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
+        }
+    }
+    void *dst = nullptr;
+    size_t cap = 0;
+    int rc = mfm_engine_acquire_input(e, &dst, &cap);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    const int cur = e->cur_in;
+    if (!e->h_in[cur]) {
+        HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cfg.max_block_samples * 4, hipHostMallocDefault));
+    }
+    /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
+    memcpy(e->h_in[cur], iq, nr_samples * 4);
+    HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
+    return mfm_engine_submit(e, nr_samples, e->s_in);
+}
+
+int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk)
+{
+    if (!e || !blk) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!e->committed || (e->cfg.flags & MFM_F_DEVICE_ONLY)) {
+        return fail(MFM_E_STATE, "fetch needs a committed engine without MFM_F_DEVICE_ONLY");
+    }
+    if (e->fetch_seq >= e->submit_seq) {
+        return MFM_E_DONE;
+    }
+    OutSlot &s = e->slots[e->fetch_seq % e->nslots];
+    if (s.state == OutSlot::FETCHED) {
+        return fail(MFM_E_STATE, "release the previous block first");
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipEventSynchronize(s.ready));
+    s.state = OutSlot::FETCHED;
+    blk->first_output = s.first_output;
+    blk->nr_outputs = s.nr_outputs;
+    blk->stride = e->out_stride;
+    blk->pcm = s.h_pcm;
+    blk->iq = reinterpret_cast<const int16_t *>(s.h_iq);
+    return MFM_OK;
+}
+
+int mfm_engine_release(struct mfm_engine *e)
+{
+    if (!e) {
+        return fail(MFM_E_INVAL, "NULL engine");
+    }
+    if (!e->committed || e->fetch_seq >= e->submit_seq) {
+        return fail(MFM_E_STATE, "nothing fetched");
+    }
+    OutSlot &s = e->slots[e->fetch_seq % e->nslots];
+    if (s.state != OutSlot::FETCHED) {
+        return fail(MFM_E_STATE, "nothing fetched");
+    }
+    s.state = OutSlot::FREE;
+    e->fetch_seq++;
+    return MFM_OK;
+}
+
+int mfm_engine_last_output_device(struct mfm_engine *e, void **d_pcm, size_t *stride, size_t *nr_outputs,
+                                  void **d_iq)
+{
+    if (!e || !e->committed || e->last_slot < 0) {
+        return fail(MFM_E_STATE, "no output yet");
+    }
+    const OutSlot &s = e->slots[e->last_slot];
+    if (d_pcm) {
+        *d_pcm = s.d_pcm;
+    }
+    if (stride) {
+        *stride = e->out_stride;
+    }
+    if (nr_outputs) {
+        *nr_outputs = s.nr_outputs;
+    }
+    if (d_iq) {
+        *d_iq = s.d_iq;
+    }
+    return MFM_OK;
+}
+
+int mfm_engine_sync(struct mfm_engine *e)
+{
+    if (!e || !e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->s_in));
+    HIP_TRY(hipStreamSynchronize(e->s_compute));
+    HIP_TRY(hipStreamSynchronize(e->s_out));
+    return MFM_OK;
+}
+
+int mfm_engine_reset(struct mfm_engine *e)
+{
+    if (!e || !e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    int rc = mfm_engine_sync(e);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    rc = write_state_fresh(e);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    for (int i = 0; i < e->nslots; i++) {
+        e->slots[i].state = OutSlot::FREE;
+    }
+    e->fetch_seq = e->submit_seq = 0;
+    e->last_slot = -1;
+    e->tail = 0;
+    e->cur_in = 0;
+    e->outputs = 0;
+    e->samples_in = 0;
+    return MFM_OK;
+}
+
+int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
+{
+    if (!e || !st) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    memset(st, 0, sizeof(*st));
+    if (e->committed && (e->cfg.flags & MFM_F_TIMING)) {
+        HIP_TRY(hipSetDevice(e->cfg.device));
+        int rc = fold_timing(e, true);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+    }
+    st->samples_in = e->samples_in;
+    st->outputs = e->outputs;
+    st->launches = e->launches;
+    st->kernel_ms = e->kernel_ms;
+    st->nr_channels = (uint32_t)e->chans.size();
+    st->nr_taps = e->nr_taps;
+    st->outputs_per_tile = 64u * e->opl;
+    st->lds_bytes = e->lds_bytes;
+    st->grid_last = e->grid_last;
+    st->tail_samples = e->tail;
+    st->rot_table_entries = e->rot_entries;
+    return MFM_OK;
+}
+
+void *mfm_engine_stream(struct mfm_engine *e)
+{
+    return (e && e->committed) ? e->s_compute : nullptr;
+}
+
+/* ---- host twins (see include/multifm_hip.h) ---- */
+
+static float g_atan_tbl[257];
+static float2 g_atan_lut[256];
+static bool g_atan_ok = false;
+
+static void atan_tbl_build(void)
+{
+    /* multifm/fast_atan2f.c:14-81: the reference's literals are atan(i/255) printed with seven
+     * significant digits; entry 256 repeats entry 255 (the index+1 read at :131). */
+    for (int i = 0; i < 257; i++) {
+        char txt[32];
+        const int k = i < 255 ? i : 255;
+        snprintf(txt, sizeof(txt), "%.6e", atan((double)k / 255.0));
+        g_atan_tbl[i] = strtof(txt, nullptr);
+    }
+    for (int i = 0; i < 256; i++) {
+        g_atan_lut[i] = make_float2(g_atan_tbl[i], g_atan_tbl[i + 1] - g_atan_tbl[i]);
+    }
+    /* FNV-1a over the 257 bit patterns; the constant was checked against values read back through
+     * the reference's own fast_atan2f() (tests/test_oracle_atan2.py). A libm that rounds atan
+     * differently at the 7th digit would trip this instead of silently changing PCM. */
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 257; i++) {
+        uint32_t b;
+        memcpy(&b, &g_atan_tbl[i], 4);
+        for (int k = 0; k < 4; k++) {
+            h ^= (b >> (8 * k)) & 0xffu;
+            h *= 1099511628211ull;
+        }
+    }
+    g_atan_ok = (h == MFM_ATAN_TABLE_FNV1A);
+}
+
+static void atan_tbl_once(void)
+{
+    static std::once_flag once;
+    std::call_once(once, atan_tbl_build);
+}
+
+int mfm_hosttwin_atan_table_ok(void)
+{
+    atan_tbl_once();
+    return g_atan_ok ? 1 : 0;
+}
+
+void mfm_hosttwin_atan_table(float tbl[257])
+{
+    atan_tbl_once();
+    memcpy(tbl, g_atan_tbl, sizeof(g_atan_tbl));
+}
+
+int32_t mfm_hosttwin_discriminate(int32_t s_re, int32_t s_im)
+{
+    atan_tbl_once();
+    return mfm_discriminate(s_re, s_im, g_atan_lut);
+}
+
+void mfm_hosttwin_discriminate_batch(const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *out)
+{
+    atan_tbl_once();
+    for (size_t i = 0; i < n; i++) {
+        out[i] = (int16_t)mfm_discriminate(s_re[i], s_im[i], g_atan_lut);
+    }
+}
+
+int16_t mfm_hosttwin_r14(int32_t a)
+{
+    return (int16_t)mfm_r14_wide(a);
+}
+
+void mfm_hosttwin_pcm_range(uint32_t first_bits, uint32_t count, int16_t *out)
+{
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t b = first_bits + i;
+        float m;
+        memcpy(&m, &b, 4);
+        out[i] = (int16_t)mfm_mag_to_pcm(m);
+    }
+}
+
+} /* extern "C" */

@@ -1,0 +1,58 @@
+/*
+ * mfm_kernel.h - launch-time description of one pass of the fused multifm channel kernel.
+ * Shared by the kernel (mfm_kernel.hip) and the engine (mfm_engine.hip).  Internal: the public
+ * boundary is include/multifm_hip.h.
+ */
+#pragma once
+
+#include <stdint.h>
+
+#define MFM_WAVE 64
+/* channels per register group (accumulator tile = OPL x CG complex sums per lane) */
+#define MFM_CG 8
+/* taps per coefficient chunk: one chunk = TG*CG*2 dwords = two s_load_dwordx16 */
+#define MFM_TG 2
+/* waves per workgroup */
+#define MFM_NW 8
+#define MFM_NT (MFM_NW * MFM_WAVE)
+
+/* per-channel rotator table descriptor (filter/direct_fir.c:151-172 recurrence, tabulated) */
+struct mfm_chan_info {
+    uint64_t rot_base; /* index of R[0] in the rotator table (entries of uint2) */
+    uint32_t mu;       /* pre-period of the rotator sequence */
+    uint32_t lam;      /* period */
+    uint32_t lam_magic; /* floor(2^32 / lam) */
+    uint32_t pad[3];
+}; /* 8 dwords: the kernel reads it as a dword array */
+
+/* per-channel state carried between launches (ping-pong) */
+struct mfm_chan_state {
+    uint32_t carry_q; /* packed (re,im) of the last filtered sample: fm_demod.c:16-17 */
+    uint32_t kb;      /* folded rotator index of the next output */
+};
+
+struct mfm_launch {
+    const uint32_t *x;   /* packed int16 IQ; x[0] is the first unconsumed stream sample */
+    uint32_t n_avail;    /* samples readable at x */
+    uint32_t n_new;      /* outputs this pass produces (per channel) */
+    uint32_t decim;      /* D */
+    uint32_t nchunks;    /* ceil(T / MFM_TG) */
+    uint32_t nstage;     /* samples one tile stages: (OT-1)*D + T */
+    uint32_t rs2;        /* LDS row stride in dwords */
+    uint32_t lut_off;    /* dword offset of the atan LUT inside LDS */
+    uint32_t ngroups;    /* channel groups of MFM_CG (channels padded with zero taps) */
+    uint32_t gpw;        /* channel groups per workgroup slice */
+    uint32_t nslices;    /* ceil(ngroups / gpw) */
+    uint32_t ntiles;
+    uint32_t nchan;      /* real channels */
+    uint32_t out_stride; /* int16 elements between channels in pcm (and dwords in iq_dbg) */
+    const uint32_t *coef;   /* [ngroups][nchunks][TG][CG][2] */
+    const uint32_t *tapoff; /* [nchunks*TG] LDS byte offset of tap i */
+    const struct mfm_chan_info *info;
+    const uint2 *rot;       /* {(rr | -ri<<16), (ri | rr<<16)} */
+    const struct mfm_chan_state *st_in;
+    struct mfm_chan_state *st_out;
+    const float2 *lut;      /* [256] {T[i], T[i+1]-T[i]} */
+    int16_t *pcm;
+    uint32_t *iq_dbg;       /* NULL unless a channel asked for the filtered-IQ stream */
+};
