@@ -58,15 +58,23 @@ def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
     t0 = time.perf_counter()
     ora.run_channels(iq, cre, cim, incr, decim, threads=threads)
     t_cal = time.perf_counter() - t0
-    n = int(min(1 << 25, max(n_cal, n_cal * target_s / max(t_cal, 1e-3))))
-    reps = -(-n // n_cal)
-    big = np.tile(iq, (reps, 1))[:n]
+    n = int(min(1 << 24, max(n_cal, n_cal * target_s / max(t_cal, 1e-3))))
+    big = np.tile(iq, (-(-n // n_cal), 1))[:n]
     t0 = time.perf_counter()
     ora.run_channels(big, cre, cim, incr, decim, threads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
-            "sample": f"{n} IQ samples x {nch} channels, oracle/liboracle.so (-O2 -march=x86-64-v3), "
-                      f"{threads} threads thread-per-channel, {dt:.1f} s"}
+    t_one = time.perf_counter() - t0
+    del t_one  # first pass only warms the pages and the thread pool
+    passes = 0
+    t0 = time.perf_counter()
+    while True:
+        ora.run_channels(big, cre, cim, incr, decim, threads=threads)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_s:
+            break
+    return {"value": passes * n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
+            "sample": f"{passes} passes over {n} IQ samples x {nch} channels, oracle/liboracle.so "
+                      f"(-O2 -march=x86-64-v3), {threads} threads thread-per-channel, {dt:.1f} s"}
 
 
 def main():

@@ -126,11 +126,13 @@ int mfm_engine_commit(struct mfm_engine *e);
 /*
  * Zero-copy ingest.  acquire_input() returns device memory where the caller (an H2D copy, an RCCL
  * broadcast, a generator kernel) must write the next block; submit() then processes nr_samples of
- * it.  If producer_stream is non-NULL it is a hipStream_t the data was produced on: the engine's
- * compute stream waits for it (no host sync).  Blocks are processed in submit order.
+ * it.  With wait_producer != 0, producer_stream is the hipStream_t the data was produced on (NULL is
+ * the legacy default stream, which is what torch's default stream is): the engine's compute stream
+ * waits for the work queued there so far (no host sync).  With wait_producer == 0 the caller
+ * guarantees the data is already in place.  Blocks are processed in submit order.
  */
 int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacity_samples);
-int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream);
+int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer);
 
 /* Host ingest: copies nr_samples interleaved int16 IQ pairs (any count <= max_block_samples) and
  * submits them.  Returns as soon as the copy has been staged; never blocks longer than a memcpy. */

@@ -186,7 +186,6 @@ def test_device_resident_submit_path(pkg, ora):
         assert cap >= blk
         hip = torch.cuda.current_stream().cuda_stream
         # device-to-device placement of the block on torch's stream, then submit ordered after it
-        dst = torch.empty(0, dtype=torch.int16, device="cuda")
         import ctypes as C
         rt = C.CDLL("libamdhip64.so")
         rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -198,7 +197,6 @@ def test_device_resident_submit_path(pkg, ora):
         rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         assert rt.hipMemcpy(host.ctypes.data, dptr, host.nbytes, 2) == 0
         outs.append(host[:, :nout].copy())
-        del dst
     eng.close()
     assert np.array_equal(np.concatenate(outs, axis=1), ref)
 

@@ -75,7 +75,7 @@ def load_library():
     lib.mfm_engine_get_channel.argtypes = [vp, C.c_uint32, i16p, i16p, i16p]
     lib.mfm_engine_commit.argtypes = [vp]
     lib.mfm_engine_acquire_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
-    lib.mfm_engine_submit.argtypes = [vp, C.c_size_t, vp]
+    lib.mfm_engine_submit.argtypes = [vp, C.c_size_t, vp, C.c_int]
     lib.mfm_engine_push.argtypes = [vp, i16p, C.c_size_t]
     lib.mfm_engine_fetch.argtypes = [vp, C.POINTER(Block)]
     lib.mfm_engine_release.argtypes = [vp]
@@ -181,9 +181,13 @@ class Engine:
         self._chk(self.lib.mfm_engine_acquire_input(self.h, C.byref(ptr), C.byref(cap)), "mfm_engine_acquire_input")
         return ptr.value, cap.value
 
-    def submit(self, nr_samples, producer_stream=None):
-        self._chk(self.lib.mfm_engine_submit(self.h, nr_samples, C.c_void_p(producer_stream or 0)),
-                  "mfm_engine_submit")
+    def submit(self, nr_samples, producer_stream=None, wait_producer=None):
+        """producer_stream: raw hipStream_t (0 = legacy default stream).  By default the engine waits for
+        it whenever one is given."""
+        if wait_producer is None:
+            wait_producer = producer_stream is not None
+        self._chk(self.lib.mfm_engine_submit(self.h, nr_samples, C.c_void_p(producer_stream or 0),
+                                             int(bool(wait_producer))), "mfm_engine_submit")
 
     def push(self, iq):
         """iq: int16 array of interleaved I,Q (2*n elements)."""

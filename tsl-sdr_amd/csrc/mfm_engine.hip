@@ -636,7 +636,7 @@ int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacit
     return MFM_OK;
 }
 
-int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream)
+int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer)
 {
     if (!e) {
         return fail(MFM_E_INVAL, "NULL engine");
@@ -670,7 +670,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         }
     }
 
-    if (producer_stream) {
+    if (wait_producer) {
         HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
         HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
     }
@@ -795,7 +795,7 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
     /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
     memcpy(e->h_in[cur], iq, nr_samples * 4);
     HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
-    return mfm_engine_submit(e, nr_samples, e->s_in);
+    return mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 
 int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk)
