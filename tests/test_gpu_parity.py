@@ -9,13 +9,30 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_iq=False, flags=0):
+KERNELS = ["auto", "dot2"]  # "auto" = int8-MFMA kernel where it applies, "dot2" = forced v_dot2 kernel
+
+
+def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_iq=False, flags=0, kernel="auto"):
     eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
     gains = gains if gains is not None else [1.0] * len(offs)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
-    eng.commit()
+    if kernel == "dot2":
+        os.environ["MFM_FORCE_DOT2"] = "1"
+    try:
+        eng.commit()
+    finally:
+        os.environ.pop("MFM_FORCE_DOT2", None)
+    variant = eng.stats()["kernel_variant"]
+    if kernel == "dot2":
+        assert variant == 0
+    elif decim % 8 == 0 and len(taps) <= 128 and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
+        assert variant == 1, "the matrix-core kernel should have been selected"
     return eng
+
+
+def _all_taps(eng, nch):
+    return np.stack([np.stack(eng.get_channel(c)[:2]) for c in range(nch)])
 
 
 def _oracle_tables(eng, nch):
@@ -25,8 +42,8 @@ def _oracle_tables(eng, nch):
     return cre, cim, incr
 
 
-def _check(pkg, ora, fs, decim, taps, offs, iq, block, gains=None, want_iq=True, threads=8):
-    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=max(block, 1), want_iq=want_iq)
+def _check(pkg, ora, fs, decim, taps, offs, iq, block, gains=None, want_iq=True, threads=8, kernel="auto"):
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=max(block, 1), want_iq=want_iq, kernel=kernel)
     cre, cim, incr = _oracle_tables(eng, len(offs))
     pcm, q = eng.run(iq, block)
     ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=threads, want_iq=want_iq)
@@ -53,30 +70,33 @@ def test_golden_path_vector(pkg, ora, golden_dir):
     assert np.array_equal(pcm, g["pcm"]) and np.array_equal(q, g["filt_iq"])
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", ["multifm_1ch", "multifm_1ch_2400k", "pocsag_rtlsdr"])
-def test_reference_shaped_configs(pkg, ora, name):
+def test_reference_shaped_configs(pkg, ora, name, kernel):
     """BASELINE configs[0] and [3]: etc/multifm_1ch.json values (fs 1.0 MS/s, D 40) and its 2.4 MS/s / D 96
     variant, etc/pocsag_rtlsdr.json (fs 1.2 MS/s, D 25, dBGain 4.0 on channel 0), file_if-sized 4096-sample
     buffers (multifm/file_if.c:18)."""
     fs, decim, taps, offs, gains = pkg.synth.plan(name)
     iq = pkg.synth.synth_iq(4096 * 60, fs, offs, seed=21)
-    _check(pkg, ora, fs, decim, taps, offs, iq, 4096, gains=gains)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 4096, gains=gains, kernel=kernel)
 
 
-def test_cfg2_64_channels(pkg, ora):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cfg2_64_channels(pkg, ora, kernel):
     """BASELINE configs[1]: 64 channels, 25 kHz LPF (128 taps), D=96, 2.4 MS/s, 1 GPU."""
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch")
     iq = pkg.synth.synth_iq((1 << 20) + 4321, fs, offs[::7], seed=22)
-    pcm = _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 18, want_iq=False)
+    pcm = _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 18, want_iq=False, kernel=kernel)
     assert pcm.shape == (64, ora.expected_outputs(len(iq), 128, decim))
 
 
-def test_cfg3_shard_of_1024_channels(pkg, ora):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cfg3_shard_of_1024_channels(pkg, ora, kernel):
     """BASELINE configs[2]: one GPU's 128-channel shard of the 1024-channel plan."""
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg3_1024ch")
     shard = offs[3 * 128:4 * 128]
     iq = pkg.synth.synth_iq(1 << 18, fs, shard[::16], seed=23)
-    _check(pkg, ora, fs, decim, taps, shard, iq, 1 << 17, want_iq=False)
+    _check(pkg, ora, fs, decim, taps, shard, iq, 1 << 17, want_iq=False, kernel=kernel)
 
 
 def test_cfg5_airspy_rate(pkg, ora):
@@ -86,7 +106,8 @@ def test_cfg5_airspy_rate(pkg, ora):
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17)
 
 
-@pytest.mark.parametrize("decim,ntaps", [(1, 16), (2, 9), (7, 33), (25, 128), (40, 128), (96, 96), (97, 128), (128, 128)])
+@pytest.mark.parametrize("decim,ntaps", [(1, 16), (2, 9), (7, 33), (8, 8), (8, 17), (16, 64), (24, 100), (25, 128),
+                                         (40, 128), (96, 96), (97, 128), (104, 128), (128, 128), (200, 256)])
 def test_odd_geometries(pkg, ora, decim, ntaps):
     """decimationFactor 1 (etc/multifm_file.json), taps == decimation, odd tap counts, D not dividing anything."""
     fs = 1000000
@@ -97,7 +118,8 @@ def test_odd_geometries(pkg, ora, decim, ntaps):
     _check(pkg, ora, fs, decim, taps, offs, iq, 8192)
 
 
-def test_full_scale_random_input_wraps_like_int32(pkg, ora):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_full_scale_random_input_wraps_like_int32(pkg, ora, kernel):
     """Uniform full-scale int16 noise with a wide, high-gain filter overflows the accumulator and hits every
     atan2 octant, including exact ties."""
     fs, decim = 2400000, 96
@@ -108,7 +130,24 @@ def test_full_scale_random_input_wraps_like_int32(pkg, ora):
     iq[5000:6000] = 32767
     iq[7000:8000] = -32768
     iq[9000:9500] = 0  # all-zero stretch: atan2(0, 0) path
-    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, kernel=kernel)
+
+
+def test_taps_too_large_for_byte_split_fall_back_to_dot2(pkg, ora):
+    """A tap above 32639 cannot be split into two signed bytes: the engine must pick the v_dot2 kernel and
+    still be exact."""
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 400000.0, fs)
+    offs = [0, 37500]
+    gains = [6.275, 1.0]  # peak tap 5212 * 6.275 = 32705: an int16, but not two signed bytes
+    iq = pkg.synth.random_iq(96 * 600 + 128, seed=33, full_scale=True)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 16)
+    assert np.abs(_all_taps(eng, 2)).max() > 32639 and eng.stats()["kernel_variant"] == 0
+    cre, cim, incr = _oracle_tables(eng, 2)
+    pcm, _ = eng.run(iq, 1 << 16)
+    eng.close()
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    assert np.array_equal(pcm, ref)
 
 
 def test_ragged_blocks_and_blocks_shorter_than_the_filter(pkg, ora):
@@ -148,7 +187,8 @@ def test_ragged_blocks_and_blocks_shorter_than_the_filter(pkg, ora):
     assert st["tail_samples"] == n - ref.shape[1] * decim
 
 
-def test_long_stream_crosses_rotator_preperiod(pkg, ora):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_long_stream_crosses_rotator_preperiod(pkg, ora, kernel):
     """A stream long enough that the tabulated rotator leaves its pre-period and wraps its cycle several
     times (offset 101 kHz: pre-period 53 105 outputs, period 25; offset 777 Hz: 71 743 / 740)."""
     fs, decim = 2400000, 96
@@ -156,7 +196,7 @@ def test_long_stream_crosses_rotator_preperiod(pkg, ora):
     offs = [101000, 777, 3125, 37500]
     n = 96 * 160000 + 128
     iq = pkg.synth.synth_iq(n, fs, offs[:2], seed=51, noise=2000)
-    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 20, want_iq=True)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 20, want_iq=True, kernel=kernel)
 
 
 def test_reset_restarts_the_stream(pkg, ora):
@@ -201,14 +241,15 @@ def test_device_resident_submit_path(pkg, ora):
     assert np.array_equal(np.concatenate(outs, axis=1), ref)
 
 
-def test_full_size_block_properties(pkg, ora):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_full_size_block_properties(pkg, ora, kernel):
     """BASELINE full size (64 channels, 2^24-sample blocks): bit-exact against the threaded oracle, and
     the size-independent property that re-blocking the same stream leaves the PCM unchanged."""
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch")
     n = (1 << 24) + 12345
     iq = pkg.synth.synth_iq(n, fs, offs[::9], seed=81)
-    big = _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 24, want_iq=False)
-    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 20)
+    big = _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 24, want_iq=False, kernel=kernel)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 20, kernel=kernel)
     small, _ = eng.run(iq, (1 << 20) - 77)
     eng.close()
     assert np.array_equal(big, small)

@@ -28,6 +28,8 @@
 
 extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, int dbg_iq, uint32_t lds_bytes,
                                                 hipStream_t stream);
+extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, uint32_t lds_bytes,
+                                                     uint32_t grid, hipStream_t stream);
 
 namespace {
 
@@ -141,6 +143,13 @@ struct mfm_engine {
     uint32_t cap_in = 0;     /* samples per input buffer */
     uint32_t out_stride = 0; /* outputs per channel one submit can produce (even) */
 
+    /* matrix-core path (mfm_kernel_mfma.hip) */
+    bool use_mfma = false;
+    uint32_t m_ks = 0, m_ot = 0, m_rs = 0, m_plane_bytes = 0, m_lut_off = 0, m_krow_off = 0, m_nrb = 0,
+             m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
+    uint32_t *d_afrag = nullptr;
+    int32_t *d_krow = nullptr;
+
     /* device tables */
     uint32_t *d_coef = nullptr, *d_tapoff = nullptr;
     mfm_chan_info *d_info = nullptr;
@@ -203,6 +212,8 @@ void free_device(mfm_engine *e)
     (void)hipDeviceSynchronize();
     (void)hipFree(e->d_coef);
     (void)hipFree(e->d_tapoff);
+    (void)hipFree(e->d_afrag);
+    (void)hipFree(e->d_krow);
     (void)hipFree(e->d_info);
     (void)hipFree(e->d_rot);
     (void)hipFree(e->d_lut);
@@ -494,6 +505,100 @@ int mfm_engine_commit(struct mfm_engine *e)
         tapoff[i] = ((i % D) * rs2 + i / D) * 4u;
     }
 
+    /* ---- matrix-core path: usable when rows of 2*D plane bytes are 16-byte multiples, the taps fit
+     *      in registers and every tap splits into two signed bytes ---- */
+    std::vector<uint32_t> afrag;
+    std::vector<int32_t> krow;
+    e->use_mfma = (D % 8 == 0) && T <= 16u * MFM_MFMA_KS_MAX && !getenv("MFM_FORCE_DOT2");
+    for (const Channel &ch : e->chans) {
+        for (uint32_t i = 0; i < T && e->use_mfma; i++) {
+            if (ch.cre[i] > 32639 || ch.cim[i] > 32639 || ch.cim[i] < -32639) {
+                e->use_mfma = false; /* 256*Wh + Wl with both in int8 needs W <= 32639 */
+            }
+        }
+    }
+    if (e->use_mfma) {
+        uint32_t ks = 1;
+        while (16u * ks < T) {
+            ks *= 2;
+        }
+        const uint32_t row_bytes = 2u * D;
+        const uint32_t rs_m = ((row_bytes / 16u) & 1u) ? row_bytes : row_bytes + 16u;
+        uint32_t ot = 0, plane = 0, lds = 0;
+        const uint32_t want[] = { 128u, 96u, 64u, 32u };
+        uint32_t forced_ot = 0;
+        if (const char *f = getenv("MFM_OT")) {
+            forced_ot = (uint32_t)atoi(f);
+        }
+        for (uint32_t cand : want) {
+            if (forced_ot && cand != forced_ot) {
+                continue;
+            }
+            const uint32_t nst = (((cand - 1u) * D + 16u * ks) + 3u) & ~3u;
+            const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
+            const uint32_t pb = rows * rs_m;
+            const uint32_t need = 2u * pb + 2048u + MFM_MFMA_NW * 32u * 4u;
+            if (need <= 53u * 1024u || (cand == 32u && need <= 160u * 1024u) || forced_ot) {
+                ot = cand;
+                plane = pb;
+                lds = need;
+                break;
+            }
+        }
+        if (0 == ot) {
+            e->use_mfma = false;
+        } else {
+            e->m_ks = ks;
+            e->m_ot = ot;
+            e->m_rs = rs_m;
+            e->m_plane_bytes = plane;
+            e->m_lut_off = 2u * plane;
+            e->m_krow_off = 2u * plane + 2048u;
+            e->m_lds_bytes = lds;
+            e->m_nrb = (2u * C + 31u) / 32u;
+            e->m_nslices = (e->m_nrb + MFM_MFMA_NW - 1u) / MFM_MFMA_NW;
+            e->m_wg_per_cu = std::max(1u, std::min(3u, (160u * 1024u) / lds));
+            if (const char *w = getenv("MFM_WG_PER_CU")) {
+                e->m_wg_per_cu = std::max(1, atoi(w));
+            }
+
+            /* W[2c] = (cr0,-ci0,cr1,-ci1..), W[2c+1] = (ci0,cr0,ci1,cr1..) (filter/complex.h:40-46) */
+            const uint32_t K = 32u * ks;
+            auto w_at = [&](uint32_t row, uint32_t k) -> int32_t {
+                const uint32_t c = row / 2u, i = k / 2u;
+                if (c >= C || i >= T) {
+                    return 0;
+                }
+                const int32_t cr = e->chans[c].cre[i], ci = e->chans[c].cim[i];
+                if (row & 1u) {
+                    return (k & 1u) ? cr : ci;
+                }
+                return (k & 1u) ? -ci : cr;
+            };
+            afrag.assign((size_t)e->m_nrb * ks * 2 * 64 * 4, 0u);
+            krow.assign((size_t)e->m_nrb * 32, 0);
+            uint8_t *ab = reinterpret_cast<uint8_t *>(afrag.data());
+            for (uint32_t rb = 0; rb < e->m_nrb; rb++) {
+                for (uint32_t i = 0; i < 32; i++) {
+                    const uint32_t row = rb * 32u + i;
+                    uint32_t sum = 0;
+                    for (uint32_t k = 0; k < K; k++) {
+                        const int32_t w = w_at(row, k);
+                        sum += (uint32_t)w;
+                        const int32_t wl = (int8_t)(w & 0xff);
+                        const int32_t wh = (w - wl) >> 8;
+                        const uint32_t kst = k / 32u, gg = (k % 32u) / 16u, j = k % 16u;
+                        const uint32_t ln = gg * 32u + i;
+                        const size_t base = ((((size_t)rb * ks + kst) * 2u) * 64u + ln) * 16u + j;
+                        ab[base] = (uint8_t)(int8_t)wh;              /* plane 0: high bytes */
+                        ab[base + 64u * 16u] = (uint8_t)(int8_t)wl;  /* plane 1: low bytes */
+                    }
+                    krow[(size_t)rb * 32 + i] = (int32_t)(128u * sum);
+                }
+            }
+        }
+    }
+
     /* ---- rotator tables (one per distinct increment) ---- */
     std::map<std::pair<int16_t, int16_t>, std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> seen;
     std::vector<uint2> rot;
@@ -513,6 +618,9 @@ int mfm_engine_commit(struct mfm_engine *e)
                 return fail(MFM_E_INVAL, "rotator (%d,%d) has no cycle within %llu steps", ir, ii,
                             (unsigned long long)kMaxRotEntries);
             }
+            /* unroll short cycles to at least one tile's worth of entries: a multiple of a period is
+             * a period, and the kernels then fold an index with one conditional subtraction */
+            lam = lam * ((kMaxOutputsPerTile + lam - 1) / lam);
             const uint64_t n = (uint64_t)mu + lam + kMaxOutputsPerTile;
             const uint64_t base = rot.size() + 1; /* one dummy entry in front: index -1 is readable */
             rot.resize(rot.size() + 1 + n);
@@ -532,6 +640,9 @@ int mfm_engine_commit(struct mfm_engine *e)
         ch.lam = it->second.second.second;
     }
     e->rot_entries = rot.size();
+    if (rot.size() >= (1ull << 31)) {
+        return fail(MFM_E_INVAL, "rotator tables need %zu entries (limit 2^31)", rot.size());
+    }
 
     std::vector<mfm_chan_info> info((size_t)e->ngroups * MFM_CG);
     memset(info.data(), 0, info.size() * sizeof(mfm_chan_info));
@@ -565,6 +676,17 @@ int mfm_engine_commit(struct mfm_engine *e)
     HIP_TRY(hipMemcpy(e->d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&e->d_tapoff, tapoff.size() * 4));
     HIP_TRY(hipMemcpy(e->d_tapoff, tapoff.data(), tapoff.size() * 4, hipMemcpyHostToDevice));
+    if (e->use_mfma) {
+        HIP_TRY(hipMalloc(&e->d_afrag, afrag.size() * 4));
+        HIP_TRY(hipMemcpy(e->d_afrag, afrag.data(), afrag.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&e->d_krow, krow.size() * 4));
+        HIP_TRY(hipMemcpy(e->d_krow, krow.data(), krow.size() * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < 2; i++) {
+            if (e->cfg.ext_input[i] && (reinterpret_cast<uintptr_t>(e->cfg.ext_input[i]) & 15u)) {
+                return fail(MFM_E_INVAL, "ext_input buffers must be 16-byte aligned");
+            }
+        }
+    }
     HIP_TRY(hipMalloc(&e->d_info, info.size() * sizeof(mfm_chan_info)));
     HIP_TRY(hipMemcpy(e->d_info, info.data(), info.size() * sizeof(mfm_chan_info), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&e->d_rot, rot.size() * sizeof(uint2)));
@@ -716,14 +838,48 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             ti = (int)(e->t_head % kTimingPairs);
             HIP_TRY(hipEventRecord(e->t0[ti], e->s_compute));
         }
-        HIP_TRY(mfm_launch_channel_kernel(&L, e->opl, e->any_iq ? 1 : 0, e->lds_bytes, e->s_compute));
+        if (e->use_mfma) {
+            mfm_launch_mfma M{};
+            M.x = e->d_in[cur];
+            M.n_avail = n_avail;
+            M.n_new = n_new;
+            M.decim = D;
+            M.ks = e->m_ks;
+            M.ot = e->m_ot;
+            M.nstage = (((e->m_ot - 1u) * D + 16u * e->m_ks) + 3u) & ~3u;
+            M.rs = e->m_rs;
+            M.plane_bytes = e->m_plane_bytes;
+            M.lut_off = e->m_lut_off;
+            M.krow_off = e->m_krow_off;
+            M.nslices = e->m_nslices;
+            M.nrb = e->m_nrb;
+            M.ntiles = (n_new + e->m_ot - 2u) / (e->m_ot - 1u);
+            M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
+            M.nchan = C;
+            M.out_stride = e->out_stride;
+            M.afrag = e->d_afrag;
+            M.krow = e->d_krow;
+            M.info = e->d_info;
+            M.rot = e->d_rot;
+            M.st_in = L.st_in;
+            M.st_out = L.st_out;
+            M.lut = e->d_lut;
+            M.pcm = slot->d_pcm;
+            M.iq_dbg = L.iq_dbg;
+            const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_per_cu);
+            HIP_TRY(mfm_launch_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, e->m_lds_bytes, grid, e->s_compute));
+            L.ntiles = grid; /* for grid_last below */
+            L.nslices = 1;
+        } else {
+            HIP_TRY(mfm_launch_channel_kernel(&L, e->opl, e->any_iq ? 1 : 0, e->lds_bytes, e->s_compute));
+        }
         if (timing) {
             HIP_TRY(hipEventRecord(e->t1[ti], e->s_compute));
             e->t_head++;
         }
         e->parity ^= 1;
         e->launches++;
-        e->grid_last = ((L.ntiles + 7) / 8) * 8 * L.nslices;
+        e->grid_last = e->use_mfma ? L.ntiles : ((L.ntiles + 7) / 8) * 8 * L.nslices;
     }
 
     /* carry the unconsumed tail to the front of the other staging buffer */
@@ -919,8 +1075,9 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->kernel_ms = e->kernel_ms;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
-    st->outputs_per_tile = 64u * e->opl;
-    st->lds_bytes = e->lds_bytes;
+    st->outputs_per_tile = e->use_mfma ? e->m_ot : 64u * e->opl;
+    st->lds_bytes = e->use_mfma ? e->m_lds_bytes : e->lds_bytes;
+    st->kernel_variant = e->use_mfma ? 1u : 0u;
     st->grid_last = e->grid_last;
     st->tail_samples = e->tail;
     st->rot_table_entries = e->rot_entries;
