@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmultifm_hip.so")
+LIB_PATH = os.environ.get("MFM_LIB") or os.path.join(_HERE, "libmultifm_hip.so")
 
 MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_DONE = 0, -1, -2, -3, -4, -5, -6
 MFM_ABI_VERSION = 1

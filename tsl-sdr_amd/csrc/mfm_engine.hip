@@ -31,6 +31,14 @@ extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, in
 extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, uint32_t lds_bytes,
                                                      uint32_t grid, hipStream_t stream);
 
+#if defined(MFM_TRACE)
+static unsigned long long *g_trace_dev = nullptr;
+extern "C" int mfm_trace_read(unsigned long long *dst)
+{
+    return (g_trace_dev && hipMemcpy(dst, g_trace_dev, 64 * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess) ? 0 : -1;
+}
+#endif
+
 namespace {
 
 thread_local char g_last_error[512] = "";
@@ -481,6 +489,10 @@ int mfm_engine_commit(struct mfm_engine *e)
     e->nslices = (e->ngroups + e->gpw - 1) / e->gpw;
     e->cap_in = input_capacity(e->cfg.max_block_samples, T);
     e->out_stride = ((e->cap_in - T) / D + 1 + 1) & ~1u;
+    if ((uint64_t)C * e->out_stride >= (1ull << 31)) {
+        return fail(MFM_E_INVAL, "channels x outputs per block = %llu exceeds 2^31 (use smaller blocks)",
+                    (unsigned long long)C * e->out_stride);
+    }
     e->any_iq = false;
     for (const Channel &c : e->chans) {
         e->any_iq |= c.want_iq;
@@ -509,7 +521,7 @@ int mfm_engine_commit(struct mfm_engine *e)
      *      in registers and every tap splits into two signed bytes ---- */
     std::vector<uint32_t> afrag;
     std::vector<int32_t> krow;
-    e->use_mfma = (D % 8 == 0) && T <= 16u * MFM_MFMA_KS_MAX && !getenv("MFM_FORCE_DOT2");
+    e->use_mfma = (D % 8 == 0) && T <= 32u * MFM_MFMA_KQ_MAX && !getenv("MFM_FORCE_DOT2");
     for (const Channel &ch : e->chans) {
         for (uint32_t i = 0; i < T && e->use_mfma; i++) {
             if (ch.cre[i] > 32639 || ch.cim[i] > 32639 || ch.cim[i] < -32639) {
@@ -518,14 +530,14 @@ int mfm_engine_commit(struct mfm_engine *e)
         }
     }
     if (e->use_mfma) {
-        uint32_t ks = 1;
-        while (16u * ks < T) {
-            ks *= 2;
+        uint32_t kq = 1;
+        while (32u * kq < T) {
+            kq *= 2;
         }
         const uint32_t row_bytes = 2u * D;
         const uint32_t rs_m = ((row_bytes / 16u) & 1u) ? row_bytes : row_bytes + 16u;
         uint32_t ot = 0, plane = 0, lds = 0;
-        const uint32_t want[] = { 128u, 96u, 64u, 32u };
+        const uint32_t want[] = { 2u * 31u }; /* new outputs per tile: two 31-output iterations */
         uint32_t forced_ot = 0;
         if (const char *f = getenv("MFM_OT")) {
             forced_ot = (uint32_t)atoi(f);
@@ -534,11 +546,11 @@ int mfm_engine_commit(struct mfm_engine *e)
             if (forced_ot && cand != forced_ot) {
                 continue;
             }
-            const uint32_t nst = (((cand - 1u) * D + 16u * ks) + 3u) & ~3u;
+            const uint32_t nst = ((cand * D + 32u * kq) + 3u) & ~3u;
             const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
             const uint32_t pb = rows * rs_m;
-            const uint32_t need = 2u * pb + 2048u + MFM_MFMA_NW * 32u * 4u;
-            if (need <= 53u * 1024u || (cand == 32u && need <= 160u * 1024u) || forced_ot) {
+            const uint32_t need = 4u * pb + 2048u; /* two staging buffers x two byte planes + atan LUT */
+            if (need <= 80u * 1024u && nst / 4u <= 4u * MFM_MFMA_NW * 64u) {
                 ot = cand;
                 plane = pb;
                 lds = need;
@@ -548,22 +560,21 @@ int mfm_engine_commit(struct mfm_engine *e)
         if (0 == ot) {
             e->use_mfma = false;
         } else {
-            e->m_ks = ks;
+            e->m_ks = kq;
             e->m_ot = ot;
             e->m_rs = rs_m;
             e->m_plane_bytes = plane;
-            e->m_lut_off = 2u * plane;
-            e->m_krow_off = 2u * plane + 2048u;
+            e->m_lut_off = 4u * plane;
             e->m_lds_bytes = lds;
-            e->m_nrb = (2u * C + 31u) / 32u;
+            e->m_nrb = (2u * C + 15u) / 16u;
             e->m_nslices = (e->m_nrb + MFM_MFMA_NW - 1u) / MFM_MFMA_NW;
-            e->m_wg_per_cu = std::max(1u, std::min(3u, (160u * 1024u) / lds));
+            e->m_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
             if (const char *w = getenv("MFM_WG_PER_CU")) {
                 e->m_wg_per_cu = std::max(1, atoi(w));
             }
 
             /* W[2c] = (cr0,-ci0,cr1,-ci1..), W[2c+1] = (ci0,cr0,ci1,cr1..) (filter/complex.h:40-46) */
-            const uint32_t K = 32u * ks;
+            const uint32_t K = 64u * kq;
             auto w_at = [&](uint32_t row, uint32_t k) -> int32_t {
                 const uint32_t c = row / 2u, i = k / 2u;
                 if (c >= C || i >= T) {
@@ -575,25 +586,29 @@ int mfm_engine_commit(struct mfm_engine *e)
                 }
                 return (k & 1u) ? -ci : cr;
             };
-            afrag.assign((size_t)e->m_nrb * ks * 2 * 64 * 4, 0u);
-            krow.assign((size_t)e->m_nrb * 32, 0);
+            /* v_mfma_i32_16x16x64_i8 A operand: lane (kg = lane >> 4, i = lane & 15) holds row i,
+             * elements 64*kq + 16*kg + j, j = 0..15 */
+            afrag.assign((size_t)e->m_nrb * kq * 2 * 64 * 4, 0u);
+            krow.assign((size_t)e->m_nrb * 16, 0);
             uint8_t *ab = reinterpret_cast<uint8_t *>(afrag.data());
             for (uint32_t rb = 0; rb < e->m_nrb; rb++) {
-                for (uint32_t i = 0; i < 32; i++) {
-                    const uint32_t row = rb * 32u + i;
+                for (uint32_t i = 0; i < 16; i++) {
+                    const uint32_t row = rb * 16u + i;
                     uint32_t sum = 0;
                     for (uint32_t k = 0; k < K; k++) {
                         const int32_t w = w_at(row, k);
                         sum += (uint32_t)w;
                         const int32_t wl = (int8_t)(w & 0xff);
                         const int32_t wh = (w - wl) >> 8;
-                        const uint32_t kst = k / 32u, gg = (k % 32u) / 16u, j = k % 16u;
-                        const uint32_t ln = gg * 32u + i;
-                        const size_t base = ((((size_t)rb * ks + kst) * 2u) * 64u + ln) * 16u + j;
+                        const uint32_t kst = k / 64u, gg = (k % 64u) / 16u, j = k % 16u;
+                        const uint32_t ln = gg * 16u + i;
+                        const size_t base = ((((size_t)rb * kq + kst) * 2u) * 64u + ln) * 16u + j;
                         ab[base] = (uint8_t)(int8_t)wh;              /* plane 0: high bytes */
                         ab[base + 64u * 16u] = (uint8_t)(int8_t)wl;  /* plane 1: low bytes */
                     }
-                    krow[(size_t)rb * 32 + i] = (int32_t)(128u * sum);
+                    /* El = (e & 255) - 128 puts 128 * sum(W) into every product sum; 8192 is the rounding
+                     * bias of the first round_q30_q15 (filter/complex.h:30-34), added here once */
+                    krow[(size_t)rb * 16 + i] = (int32_t)(128u * sum + 8192u);
                 }
             }
         }
@@ -640,8 +655,8 @@ int mfm_engine_commit(struct mfm_engine *e)
         ch.lam = it->second.second.second;
     }
     e->rot_entries = rot.size();
-    if (rot.size() >= (1ull << 31)) {
-        return fail(MFM_E_INVAL, "rotator tables need %zu entries (limit 2^31)", rot.size());
+    if (rot.size() >= (1ull << 29)) {
+        return fail(MFM_E_INVAL, "rotator tables need %zu entries (limit 2^29: byte offsets are 32-bit)", rot.size());
     }
 
     std::vector<mfm_chan_info> info((size_t)e->ngroups * MFM_CG);
@@ -844,16 +859,16 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.n_avail = n_avail;
             M.n_new = n_new;
             M.decim = D;
-            M.ks = e->m_ks;
+            M.x_last4 = (e->cap_in - 4u) & ~3u;
+            M.kq = e->m_ks;
             M.ot = e->m_ot;
-            M.nstage = (((e->m_ot - 1u) * D + 16u * e->m_ks) + 3u) & ~3u;
+            M.nstage = ((e->m_ot * D + 32u * e->m_ks) + 3u) & ~3u;
             M.rs = e->m_rs;
             M.plane_bytes = e->m_plane_bytes;
             M.lut_off = e->m_lut_off;
-            M.krow_off = e->m_krow_off;
             M.nslices = e->m_nslices;
             M.nrb = e->m_nrb;
-            M.ntiles = (n_new + e->m_ot - 2u) / (e->m_ot - 1u);
+            M.ntiles = (n_new + e->m_ot - 1u) / e->m_ot;
             M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
             M.nchan = C;
             M.out_stride = e->out_stride;
@@ -866,6 +881,17 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.lut = e->d_lut;
             M.pcm = slot->d_pcm;
             M.iq_dbg = L.iq_dbg;
+#if defined(MFM_TRACE)
+            {
+                static unsigned long long *d_trace = nullptr;
+                if (!d_trace) {
+                    HIP_TRY(hipMalloc(&d_trace, 64 * 128 * 8));
+                }
+                HIP_TRY(hipMemsetAsync(d_trace, 0, 64 * 128 * 8, e->s_compute));
+                M.trace = d_trace;
+                g_trace_dev = d_trace;
+            }
+#endif
             const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_per_cu);
             HIP_TRY(mfm_launch_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, e->m_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */

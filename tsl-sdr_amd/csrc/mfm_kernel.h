@@ -59,29 +59,28 @@ struct mfm_launch {
 
 /* ---------------------------------------------------------------------------------------------
  * FIR-as-GEMM variant (mfm_kernel_mfma.hip): exact int16 arithmetic through four int8 MFMA
- * products.  Used when decimation % 8 == 0, taps <= 16 * MFM_MFMA_KS_MAX and every tap fits
+ * products.  Used when decimation % 8 == 0, taps <= 32 * MFM_MFMA_KQ_MAX and every tap fits
  * +-32639; otherwise the v_dot2 kernel above runs.
  * ------------------------------------------------------------------------------------------- */
-#define MFM_MFMA_NW 4            /* waves per workgroup; each owns 32 GEMM rows = 16 channels */
-#define MFM_MFMA_KS_MAX 8        /* k-steps of 32 int16 elements (= 16 complex taps) held in registers */
-#define MFM_MFMA_NT 32           /* outputs per MFMA tile (N) */
+#define MFM_MFMA_NW 8            /* waves per workgroup; each owns 16 GEMM rows = 8 channels */
+#define MFM_MFMA_KQ_MAX 4        /* k-steps of 64 int16 elements (= 32 complex taps) held in registers */
 
 struct mfm_launch_mfma {
     const uint32_t *x;
     uint32_t n_avail, n_new, decim;
-    uint32_t ks;          /* k-steps: padded taps = 16 * ks */
-    uint32_t ot;          /* outputs per workgroup tile incl. the recomputed first one (multiple of 32) */
-    uint32_t nstage;      /* samples staged per tile: (ot-1)*D + 16*ks, rounded up to 4 */
+    uint32_t x_last4;     /* last sample index at which a 16-byte load stays inside the input buffer (multiple of 4) */
+    uint32_t kq;          /* k-steps of 64 elements: padded taps = 32 * kq */
+    uint32_t ot;          /* NEW outputs per workgroup tile: 31 per N-tile of 32 columns */
+    uint32_t nstage;      /* samples staged per tile: ot*D + 32*kq, rounded up to 4 */
     uint32_t rs;          /* LDS row stride in bytes (row = 2*D plane bytes), rs/16 odd */
     uint32_t plane_bytes; /* bytes of one byte-plane in LDS (16-byte multiple) */
     uint32_t lut_off;     /* byte offset of the atan LUT in LDS */
-    uint32_t krow_off;    /* byte offset of the per-row constants (NW x 32 int32) in LDS */
     uint32_t nslices;     /* ceil(row blocks / MFM_MFMA_NW) */
-    uint32_t nrb;         /* row blocks of 32 rows (= 16 channels) */
+    uint32_t nrb;         /* row blocks of 16 rows (= 8 channels) */
     uint32_t ntiles, nitems;
     uint32_t nchan, out_stride;
-    const uint32_t *afrag;   /* [nrb][ks][plane hi,lo][lane][4 dwords] */
-    const int32_t *krow;     /* [nrb][32]: 128 * sum_k W[row][k] */
+    const uint32_t *afrag;   /* [nrb][kq][plane hi,lo][lane][4 dwords] */
+    const int32_t *krow;     /* [nrb][16]: 128 * sum_k W[row][k] + 8192 */
     const struct mfm_chan_info *info;
     const uint2 *rot;
     const struct mfm_chan_state *st_in;
@@ -89,4 +88,5 @@ struct mfm_launch_mfma {
     const float2 *lut;
     int16_t *pcm;
     uint32_t *iq_dbg;
+    unsigned long long *trace; /* NULL unless the library was built with -DMFM_TRACE */
 };

@@ -78,18 +78,31 @@ __global__ __launch_bounds__(MFM_NT) void mfm_channel_kernel(const mfm_launch L)
         const int64_t s0 = (int64_t)tile * (OT - 1) * D - (int64_t)D;
         uint32_t row = tid / D, r = tid % D;
         const uint32_t drow = MFM_NT / D, dr = MFM_NT % D;
-        for (uint32_t idx = tid; idx < L.nstage; idx += MFM_NT) {
-            const int64_t g = s0 + idx;
-            uint32_t v = 0;
-            if (g >= 0 && g < (int64_t)L.n_avail) {
-                v = L.x[g];
+        /* a batch of global loads is issued before any is consumed; one pass per load would cost one
+         * HBM round trip each */
+        constexpr int SB = 8;
+        for (uint32_t idx0 = tid; idx0 < L.nstage; idx0 += SB * MFM_NT) {
+            uint32_t v[SB];
+#pragma unroll
+            for (int b = 0; b < SB; b++) {
+                const uint32_t idx = idx0 + b * MFM_NT;
+                const int64_t g = s0 + idx;
+                v[b] = 0;
+                if (idx < L.nstage && g >= 0 && g < (int64_t)L.n_avail) {
+                    v[b] = L.x[g];
+                }
             }
-            lds[r * rs2 + row] = v;
-            r += dr;
-            row += drow;
-            if (r >= D) {
-                r -= D;
-                row += 1;
+#pragma unroll
+            for (int b = 0; b < SB; b++) {
+                if (idx0 + b * MFM_NT < L.nstage) {
+                    lds[r * rs2 + row] = v[b];
+                }
+                r += dr;
+                row += drow;
+                if (r >= D) {
+                    r -= D;
+                    row += 1;
+                }
             }
         }
         /* atan LUT: 256 x {T[i], T[i+1]-T[i]} = 512 dwords */

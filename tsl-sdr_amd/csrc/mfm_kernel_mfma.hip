@@ -16,17 +16,22 @@
  *
  *     sum W*e = 65536*sum Wh*Eh + 256*(sum Wh*El + sum Wl*Eh) + sum Wl*El + 128*sum W     (mod 2^32)
  *
- * i.e. four v_mfma_i32_32x32x32_i8 per 32 rows x 32 outputs x 32 elements, int32 accumulators that
- * wrap exactly like the reference's int32 sums (tools/ubench_mfma_i8.hip checks the wrap, the k-slot
- * pairing and the C/D layout on hardware).  The last term is a per-row constant added once.
+ * i.e. four v_mfma_i32_16x16x64_i8 per 16 rows x 16 outputs x 64 elements, with int32 accumulators
+ * that wrap exactly like the reference's int32 sums (tools/ubench_mfma_i8.hip checks wrap-around, the
+ * k-slot pairing and the C/D layout on hardware).  The last term is a per-row constant.
  *
- * Per workgroup: 4 waves x 32 rows (= 64 channels) share one LDS image of the input tile, stored as
- * two byte planes (Eh, El) in rows of 2*D bytes with an odd 16-byte row stride, so the B operand of
- * every lane is one conflict-free ds_read_b128.  The A operand (taps) is loaded once per wave and
- * stays in 64 VGPRs.  Everything after the accumulators - Q14 round, derotation by the tabulated
- * rotator, the fast_atan2f discriminator, PCM store - is the same exact arithmetic as the v_dot2
- * kernel (mfm_numerics.h), applied to the MFMA C/D layout (each lane holds re/im of 8 channels for
- * one output).
+ * Geometry.  A workgroup = 8 waves; wave w owns GEMM rows 16w..16w+15 = channels 8w..8w+7 of the
+ * workgroup's 64-channel slice, its taps (A operand) stay in registers for the whole launch.  All
+ * waves share one LDS image of the input tile, stored as two byte planes (Eh, El) in rows of 2*D
+ * bytes with an odd 16-byte row stride, so every lane's B operand is one ds_read_b128.  One loop
+ * iteration of a wave covers 32 output columns as two 16-column MFMA groups (interleaved so no
+ * accumulator is reused back to back); column 0 is the output before the first new one, recomputed,
+ * which makes the discriminator's one-sample history always "the lane to the left" (DPP row_shr).
+ * In the C/D layout a lane holds re/im of 2 channels for one column, so the epilogue - Q14 round,
+ * derotation by the tabulated rotator, fast_atan2f discriminator, PCM store (the same exact scalar
+ * arithmetic as the v_dot2 kernel, mfm_numerics.h) - handles four (channel, output) pairs per lane
+ * per iteration.  The small register footprint (<= 128 VGPRs) is what lets four waves share a SIMD
+ * so that one wave's matrix work overlaps another's VALU epilogue.
  */
 #include <hip/hip_runtime.h>
 
@@ -34,128 +39,132 @@
 #include "mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
-typedef int mfm_v16i __attribute__((ext_vector_type(16)));
 typedef short mfm_s2 __attribute__((ext_vector_type(2)));
+
+#define MFM_M_NT (MFM_MFMA_NW * 64)
+
+/* Optional phase trace for tools/trace_phases.py (build with -DMFM_TRACE): wave 0 of a few workgroups
+ * drops s_memtime stamps into L.trace.  Compiled out of the product library. */
+#if defined(MFM_TRACE)
+#define MFM_STAMP(id)                                                                                        \
+    do {                                                                                                     \
+        if (L.trace && blockIdx.x < 64 && tid == 0 && tr_n < 60) {                                          \
+            L.trace[blockIdx.x * 128 + 2 * tr_n] = (unsigned long long)(id);                                 \
+            L.trace[blockIdx.x * 128 + 2 * tr_n + 1] = __builtin_readcyclecounter();                         \
+            tr_n++;                                                                                          \
+        }                                                                                                    \
+    } while (0)
+#else
+#define MFM_STAMP(id)                                                                                        \
+    do {                                                                                                     \
+    } while (0)
+#endif
+#define MFM_M_NEW 31 /* new outputs per 32-column iteration */
+#define MFM_M_ITERS 2 /* iterations per tile: a tile is 62 new outputs */
+#define MFM_M_CH 4    /* 16-byte staging chunks a thread owns per tile (>= ceil(samples/4/512)) */
 
 static __device__ __forceinline__ int mfm_dot2m(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(mfm_s2, a), __builtin_bit_cast(mfm_s2, b), c, false);
 }
 
-template <int KS, bool DBG_IQ>
-__global__ __launch_bounds__(MFM_MFMA_NW * 64, 2) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
+/* (hh << 16) + (md << 8) + ll: the recombined sum, already carrying K + 8192 through ll */
+static __device__ __forceinline__ uint32_t mfm_combine(int hh, int md, int ll)
+{
+    return ((((uint32_t)hh << 8) + (uint32_t)md) << 8) + (uint32_t)ll;
+}
+
+/* bits 29:14 of two biased sums packed as (re | im << 16): round_q30_q15 + int16 truncation */
+static __device__ __forceinline__ uint32_t mfm_round_pack(uint32_t re_b, uint32_t im_b)
+{
+    return ((re_b >> 14) & 0xffffu) | ((im_b << 2) & 0xffff0000u);
+}
+
+/* decode a persistent-loop item into (tile, slice): XCD-aware, the slices of one tile run back to back
+ * on one XCD (see mfm_kernel.hip) */
+static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L, uint32_t item, uint32_t *tile,
+                                                       uint32_t *slice)
+{
+    const uint32_t xcd = item & 7u, seq = item >> 3;
+    *tile = (seq / L.nslices) * 8u + xcd;
+    *slice = seq % L.nslices;
+    return item < L.nitems && *tile < L.ntiles;
+}
+
+template <int KQ, bool DBG_IQ> /* KQ = k-steps of 64 elements (32 complex taps) */
+__global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t g = lane >> 5, n = lane & 31u;
+    const uint32_t kg = lane >> 4, n = lane & 15u;
+#if defined(MFM_TRACE)
+    uint32_t tr_n = 0;
+#endif
+    MFM_STAMP(1);
     const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
-
-    uint8_t *plane_h = smem, *plane_l = smem + L.plane_bytes;
+    const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
+    const uint32_t buf_bytes = 2u * L.plane_bytes; /* one staging buffer = H plane + L plane */
     const float2 *lut = reinterpret_cast<const float2 *>(smem + L.lut_off);
-    const int32_t *krow_s = reinterpret_cast<const int32_t *>(smem + L.krow_off);
 
-    /* per-lane LDS byte offset of the B fragment of k-step ks for output column n of N-tile 0 */
-    uint32_t boff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const uint32_t e = 32u * ks + 16u * g;
-        boff[ks] = (n + e / row_bytes) * rs + e % row_bytes;
+    /* atan LUT: 256 x {T[i], T[i+1]-T[i]}, once per workgroup (its LDS region is never restaged) */
+    {
+        uint32_t *lut_s = reinterpret_cast<uint32_t *>(smem + L.lut_off);
+        const uint32_t *lut_g = reinterpret_cast<const uint32_t *>(L.lut);
+        for (uint32_t i = tid; i < 512; i += MFM_M_NT) {
+            lut_s[i] = lut_g[i];
+        }
     }
 
-    mfm_v4i a_h[KS], a_l[KS];
-    uint32_t slice_loaded = 0xffffffffu;
-
-    for (uint32_t item = blockIdx.x; item < L.nitems; item += gridDim.x) {
-        /* XCD-aware decode (see mfm_kernel.hip): the slices of one tile run back to back on one XCD */
-        const uint32_t xcd = item & 7u, seq = item >> 3;
-        const uint32_t tile = (seq / L.nslices) * 8u + xcd;
-        const uint32_t slice = seq % L.nslices;
-        if (tile >= L.ntiles) {
-            continue;
-        }
-        const uint32_t rb = slice * MFM_MFMA_NW + wave; /* this wave's block of 32 rows */
-        const bool rb_valid = rb < L.nrb;
-
-        if (slice != slice_loaded) {
-            /* A operand: the wave's 32 rows x (32*KS) elements, both byte planes, in fragment order */
-            if (rb_valid) {
-                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rb * KS * 2 * 64 + lane;
+    /* per-lane LDS byte offset of the B fragment of k-step kq for column n of the first group */
+    uint32_t boff[KQ];
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    a_h[ks] = ap[(ks * 2 + 0) * 64];
-                    a_l[ks] = ap[(ks * 2 + 1) * 64];
-                }
-            }
-            slice_loaded = slice;
-        }
+    for (int kq = 0; kq < KQ; kq++) {
+        const uint32_t e = 64u * kq + 16u * kg;
+        boff[kq] = (n + e / row_bytes) * rs + e % row_bytes;
+    }
 
-        __syncthreads(); /* everyone is done reading the previous tile's LDS image */
-
-        /* ---- stage: 4 samples (16 B) per thread per pass -> 8 bytes into each plane ---- */
-        {
-            const int64_t s0 = ((int64_t)tile * (L.ot - 1) - 1) * (int64_t)D;
-            const uint32_t nchunk = L.nstage >> 2;
-            uint32_t p8 = tid * 8u;
-            uint32_t row = p8 / row_bytes, off = p8 % row_bytes;
-            const uint32_t drow = 2048u / row_bytes, doff = 2048u % row_bytes; /* 256 threads x 8 bytes */
-            for (uint32_t q = tid; q < nchunk; q += MFM_MFMA_NW * 64) {
-                const int64_t gs = s0 + (int64_t)q * 4;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (gs >= 0 && gs + 3 < (int64_t)L.n_avail) {
-                    v = *reinterpret_cast<const uint4 *>(L.x + gs);
-                } else if (gs + 3 >= 0 && gs < (int64_t)L.n_avail) {
-                    uint32_t t[4];
+    /* staging: this thread owns chunks q = tid + j * MFM_M_NT, j = 0 .. MFM_M_CH-1 of every tile; their
+     * place in the LDS image never changes */
+    uint32_t st_at[MFM_M_CH];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int64_t gk = gs + k;
-                        t[k] = (gk >= 0 && gk < (int64_t)L.n_avail) ? L.x[gk] : 0u;
-                    }
-                    v = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-                /* dword = [lo0 hi0 lo1 hi1]: gather high bytes / low bytes of four int16 into one dword */
-                uint2 hi, lo;
-                hi.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
-                hi.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
-                lo.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) ^ 0x80808080u;
-                lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) ^ 0x80808080u;
-                const uint32_t at = row * rs + off;
-                *reinterpret_cast<uint2 *>(plane_h + at) = hi;
-                *reinterpret_cast<uint2 *>(plane_l + at) = lo;
-                off += doff;
-                row += drow;
-                if (off >= row_bytes) {
-                    off -= row_bytes;
-                    row += 1;
-                }
-            }
-            uint32_t *lut_s = reinterpret_cast<uint32_t *>(smem + L.lut_off);
-            const uint32_t *lut_g = reinterpret_cast<const uint32_t *>(L.lut);
-            for (uint32_t i = tid; i < 512; i += MFM_MFMA_NW * 64) {
-                lut_s[i] = lut_g[i];
-            }
-            if (tid < MFM_MFMA_NW * 32) {
-                const uint32_t r = slice * MFM_MFMA_NW * 32 + tid;
-                reinterpret_cast<int32_t *>(smem + L.krow_off)[tid] = (r < L.nrb * 32u) ? L.krow[r] : 0;
-            }
-        }
-        __syncthreads();
+    for (int j = 0; j < MFM_M_CH; j++) {
+        const uint32_t p8 = (tid + (uint32_t)j * MFM_M_NT) * 8u;
+        st_at[j] = (p8 / row_bytes) * rs + p8 % row_bytes;
+    }
 
-        if (!rb_valid) {
-            continue;
+    auto stage_load = [&](uint32_t tile, int j) -> uint4 {
+        /* 4 samples of tile `tile`.  No bounds masking is needed, only a readable address: samples before
+         * the stream start feed nothing but column 0 of tile 0 (replaced by the carried sample), samples
+         * past n_avail feed only columns >= n_new (never stored) or zero-padded taps. */
+        const uint32_t q = tid + (uint32_t)j * MFM_M_NT;
+        int64_t gs = ((int64_t)tile * L.ot - 1) * (int64_t)D + (int64_t)q * 4;
+        gs = gs < 0 ? 0 : gs;
+        gs = gs > (int64_t)L.x_last4 ? (int64_t)L.x_last4 : gs;
+        return *reinterpret_cast<const uint4 *>(L.x + gs);
+    };
+    auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
+        if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
+            /* dword = [lo0 hi0 lo1 hi1]: gather high / low bytes of four int16 into one dword */
+            uint2 hi, lo;
+            hi.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+            hi.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+            lo.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) ^ 0x80808080u;
+            lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) ^ 0x80808080u;
+            uint8_t *base = smem + buf * buf_bytes + st_at[j];
+            *reinterpret_cast<uint2 *>(base) = hi;
+            *reinterpret_cast<uint2 *>(base + L.plane_bytes) = lo;
         }
-
-        /* ---- per tile, per channel pair: where this lane's first column sits in the rotator table ---- */
-        const int rel_first = (int)(tile * (L.ot - 1)) - 1; /* output index (this pass) of column 0 */
-        uint32_t q_prev[8]; /* previous N-tile's filtered samples, per channel pair */
-        uint32_t k_abs[8], k_wrap[8], k_lam[8];
+    };
+    /* where column 0 of tile `tile` sits in this lane's two channels' rotator tables */
+    auto rot_offsets = [&](uint32_t tile, uint32_t ch0, bool valid, uint32_t koff[2]) {
+        const int rel_first = (int)(tile * L.ot) - 1;
 #pragma unroll
-        for (int rp = 0; rp < 8; rp++) {
-            q_prev[rp] = 0;
-            const uint32_t chn = rb * 16u + (uint32_t)(rp & 1) + 4u * (uint32_t)(rp >> 1) + 2u * g;
-            const uint32_t chs = chn < L.nchan ? chn : 0u;
+        for (int c = 0; c < 2; c++) {
+            const uint32_t chn = ch0 + c;
+            const uint32_t chs = (valid && chn < L.nchan) ? chn : 0u;
             const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chs * 8;
             const uint4 inf = *reinterpret_cast<const uint4 *>(ip);
             const uint32_t lam_magic = ip[4];
@@ -168,97 +177,242 @@ __global__ __launch_bounds__(MFM_MFMA_NW * 64, 2) void mfm_channel_kernel_mfma(c
                 m = (m >= lam) ? m - lam : m;
                 k = (int)(mu + m);
             }
-            k_abs[rp] = inf.x + (uint32_t)k; /* table index fits 32 bits (engine checks) */
-            k_wrap[rp] = inf.x + mu + lam;
-            k_lam[rp] = lam;                 /* >= 128: one conditional subtraction folds a whole tile */
+            /* every table runs 128 entries past mu + lam, so a tile never wraps once its first column is
+             * folded; the byte offset fits 32 bits (engine checks) */
+            koff[c] = (inf.x + (uint32_t)k + n) * 8u;
+        }
+    };
+
+    mfm_v4i a_h[KQ], a_l[KQ];
+    mfm_v4i krow = { 0, 0, 0, 0 };
+    uint32_t slice_loaded = 0xffffffffu;
+
+    /* ---- first tile of this workgroup: staged synchronously into buffer 0 ---- */
+    uint32_t item = blockIdx.x, tile, slice;
+    bool have = mfm_decode_item(L, item, &tile, &slice);
+    if (have) {
+        uint4 v[MFM_M_CH];
+#pragma unroll
+        for (int j = 0; j < MFM_M_CH; j++) {
+            v[j] = stage_load(tile, j);
+        }
+#pragma unroll
+        for (int j = 0; j < MFM_M_CH; j++) {
+            stage_store(0, j, v[j]);
+        }
+    }
+    uint32_t k_off[2] = { 0, 0 };
+    if (have) {
+        rot_offsets(tile, (slice * MFM_MFMA_NW + wave) * 8u + 2u * kg, slice * MFM_MFMA_NW + wave < L.nrb, k_off);
+    }
+    __syncthreads();
+    MFM_STAMP(2);
+
+    uint32_t cur = 0;
+    while (have) {
+        /* the tile after this one (persistent loop, stride = grid) is staged while this one computes */
+        uint32_t tile_n, slice_n;
+        const uint32_t item_n = item + gridDim.x;
+        const bool have_n = mfm_decode_item(L, item_n, &tile_n, &slice_n);
+
+        const uint32_t rb = slice * MFM_MFMA_NW + wave; /* this wave's block of 16 rows = 8 channels */
+        const bool rb_valid = rb < L.nrb;
+        const uint32_t ch0 = rb * 8u + 2u * kg;        /* this lane's channels: ch0 (regs 0,1), ch0+1 (regs 2,3) */
+        const int rel_first = (int)(tile * L.ot) - 1;  /* output index (this pass) of column 0 */
+
+        if (slice != slice_loaded) {
+            if (rb_valid) {
+                /* A operand: 16 rows x (64*KQ) elements, both byte planes, already in fragment order */
+                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rb * KQ * 2 * 64 + lane;
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    a_h[kq] = ap[(kq * 2 + 0) * 64];
+                    a_l[kq] = ap[(kq * 2 + 1) * 64];
+                }
+                /* 128 * sum_k W[row][k] + 8192 for rows 4kg..4kg+3 */
+                krow = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rb * 16 + 4 * kg);
+                /* settle these loads now: they stay live across the whole tile loop, and without this the
+                 * compiler waits vmcnt(0) at their first use in every iteration - which would also drain
+                 * the next tile's prefetch loads in the middle of the matrix work */
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    asm volatile("" : "+v"(a_h[kq]), "+v"(a_l[kq]));
+                }
+                asm volatile("" : "+v"(krow));
+            }
+            slice_loaded = slice;
         }
 
-        const uint32_t ntiles_n = L.ot / MFM_MFMA_NT;
-        for (uint32_t tau = 0; tau < ntiles_n; tau++) {
-            /* rotator entries for this N-tile: addresses do not depend on data, so issue the loads
-             * before the matrix work and let them land underneath it */
-            uint2 rv[8];
+        uint32_t k_off_n[2] = { 0, 0 };
+        if (have_n) {
+            const uint32_t rb_n = slice_n * MFM_MFMA_NW + wave;
+            rot_offsets(tile_n, rb_n * 8u + 2u * kg, rb_n < L.nrb, k_off_n);
+        }
+
+        const uint8_t *plane_h = smem + cur * buf_bytes, *plane_l = plane_h + L.plane_bytes;
+
+        /* first tile of the pass: its column 0 is the previous pass's last filtered sample */
+        const bool use_carry = (tile == 0) && (n == 0);
+        uint32_t carry[2] = { 0, 0 };
+        if (tile == 0) {
 #pragma unroll
-            for (int rp = 0; rp < 8; rp++) {
-                uint32_t idx = k_abs[rp] + tau * MFM_MFMA_NT + n;
-                idx = (idx >= k_wrap[rp]) ? idx - k_lam[rp] : idx;
-                rv[rp] = L.rot[idx];
-            }
-
-            /* ---- GEMM: 32 rows x 32 outputs x (32*KS) elements, four byte-plane products ---- */
-            mfm_v16i acc_hh, acc_md, acc_ll;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                acc_hh[r] = 0;
-                acc_md[r] = 0;
-                /* + 128 * sum_k W[row][k]: the constant of the El offset */
-                acc_ll[r] = krow_s[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
-            }
-            const uint32_t tbase = tau * MFM_MFMA_NT * rs;
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                const mfm_v4i b_h = *reinterpret_cast<const mfm_v4i *>(plane_h + tbase + boff[ks]);
-                const mfm_v4i b_l = *reinterpret_cast<const mfm_v4i *>(plane_l + tbase + boff[ks]);
-                acc_hh = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_h[ks], b_h, acc_hh, 0, 0, 0);
-                acc_md = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_h[ks], b_l, acc_md, 0, 0, 0);
-                acc_ll = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_l[ks], b_l, acc_ll, 0, 0, 0);
-                acc_md = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_l[ks], b_h, acc_md, 0, 0, 0);
-            }
-
-            /* ---- epilogue: this lane holds (re, im) of 8 channels for output column n ---- */
-            const int rel = rel_first + (int)(tau * MFM_MFMA_NT + n);
-            const bool first_col = (tau == 0) && (n == 0); /* the recomputed previous output */
-#pragma unroll
-            for (int rp = 0; rp < 8; rp++) {
-                const int r = 2 * rp;
-                const uint32_t chn = rb * 16u + (uint32_t)(rp & 1) + 4u * (uint32_t)(rp >> 1) + 2u * g;
-                const bool ch_ok = chn < L.nchan;
-
-                const uint32_t a_re = ((uint32_t)acc_hh[r] << 16) + ((uint32_t)acc_md[r] << 8) + (uint32_t)acc_ll[r];
-                const uint32_t a_im =
-                    ((uint32_t)acc_hh[r + 1] << 16) + ((uint32_t)acc_md[r + 1] << 8) + (uint32_t)acc_ll[r + 1];
-
-                /* filter/direct_fir.c:406-413 */
-                const uint32_t f = mfm_pack16(mfm_r14_wide((int)a_re), mfm_r14_wide((int)a_im));
-                const int o_re = mfm_dot2m(f, rv[rp].x, 0);
-                const int o_im = mfm_dot2m(f, rv[rp].y, 0);
-                uint32_t q = mfm_pack16(mfm_r14_wide(o_re), mfm_r14_wide(o_im));
-                if (tile == 0 && tau == 0) {
-                    /* column 0 of the pass is the last filtered sample of the previous pass */
-                    const uint32_t carry = L.st_in[ch_ok ? chn : 0u].carry_q;
-                    q = (n == 0) ? carry : q;
-                }
-
-                /* previous output of the same channel: lane n-1, or the last column of the previous N-tile */
-                uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)q_prev[rp], 31);
-                const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)q_prev[rp], 63);
-                p = (n == 0) ? (g ? e1 : e0) : p;
-                q_prev[rp] = q;
-
-                /* multifm/fm_demod.c:55-72 */
-                const int q_re = mfm_lo16(q), q_im = mfm_hi16(q), p_re = mfm_lo16(p), p_im = mfm_hi16(p);
-                const int s_re = mfm_dot2m(q, p, 0);
-                const int s_im = (int)((uint32_t)(q_im * p_re) - (uint32_t)(q_re * p_im));
-                const int pcm = mfm_discriminate(s_re, s_im, lut);
-
-                if (ch_ok && !first_col && rel < (int)L.n_new) {
-                    L.pcm[(size_t)chn * L.out_stride + rel] = (int16_t)pcm;
-                    if (DBG_IQ) {
-                        L.iq_dbg[(size_t)chn * L.out_stride + rel] = q;
-                    }
-                    if (rel == (int)L.n_new - 1) {
-                        L.st_out[chn].carry_q = q;
-                    }
-                }
+            for (int c = 0; c < 2; c++) {
+                const uint32_t chn = ch0 + c;
+                carry[c] = L.st_in[(rb_valid && chn < L.nchan) ? chn : 0u].carry_q;
             }
         }
 
-        if (tile == 0 && n == 0) {
-            /* rotator index of the next pass's first output, one lane per channel */
 #pragma unroll
-            for (int rp = 0; rp < 8; rp++) {
-                const uint32_t chn = rb * 16u + (uint32_t)(rp & 1) + 4u * (uint32_t)(rp >> 1) + 2u * g;
+        for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
+            /* Vector-memory order matters (one in-order counter): first the rotator entries of this
+             * iteration's columns (L2 hits, needed right after the matrix work; their addresses do not
+             * depend on data), then this iteration's share of the next tile's input (HBM, needed only at
+             * the end of the iteration), so waiting for the former leaves the latter in flight. */
+            const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
+            uint2 rv[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                rv[0][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c]);
+                rv[1][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c] + 16u * 8u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            uint4 pre[MFM_M_CH / MFM_M_ITERS];
+            if (have_n) {
+#pragma unroll
+                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
+                    pre[u] = stage_load(tile_n, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            uint32_t q[2][2];
+            int pcm[2][2];
+            if (rb_valid) {
+
+                /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
+                mfm_v4i hh[2], md[2], ll[2];
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    hh[gq] = mfm_v4i{ 0, 0, 0, 0 };
+                    md[gq] = mfm_v4i{ 0, 0, 0, 0 };
+                    ll[gq] = krow;
+                }
+                const uint32_t ibase = it * MFM_M_NEW * rs;
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    mfm_v4i b_h[2], b_l[2];
+#pragma unroll
+                    for (int gq = 0; gq < 2; gq++) {
+                        const uint32_t at = ibase + boff[kq] + (uint32_t)gq * 16u * rs;
+                        b_h[gq] = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
+                        b_l[gq] = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
+                    }
+                    hh[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[0], hh[0], 0, 0, 0);
+                    hh[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[1], hh[1], 0, 0, 0);
+                    md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[0], md[0], 0, 0, 0);
+                    md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[1], md[1], 0, 0, 0);
+                    ll[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[0], ll[0], 0, 0, 0);
+                    ll[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[1], ll[1], 0, 0, 0);
+                    md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[0], md[0], 0, 0, 0);
+                    md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[1], md[1], 0, 0, 0);
+                }
+                /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) pads the MFMA -> VALU
+                 * read hazard inside a basic block but not across a branch it places here, and the first
+                 * reads then see the accumulator before the last v_mfma retired (caught by the parity
+                 * tests: tile 0 passed, later tiles did not).  16 wait states cover a 16x16x64 MFMA. */
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                MFM_STAMP(6);
+
+                /* ---- epilogue: lane (kg, n) holds channels ch0, ch0+1 for columns n (group 0) and 16+n
+                 *      (group 1); written in phases so the four independent chains interleave ---- */
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        /* a + 8192 (mod 2^32); r14(a) truncated to int16 is bits 29:14 (filter/complex.h:30-34) */
+                        const uint32_t a_re = mfm_combine(hh[gq][2 * c], md[gq][2 * c], ll[gq][2 * c]);
+                        const uint32_t a_im = mfm_combine(hh[gq][2 * c + 1], md[gq][2 * c + 1], ll[gq][2 * c + 1]);
+                        const uint32_t f = mfm_round_pack(a_re, a_im);
+                        /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
+                        const uint32_t o_re = (uint32_t)mfm_dot2m(f, rv[gq][c].x, 8192);
+                        const uint32_t o_im = (uint32_t)mfm_dot2m(f, rv[gq][c].y, 8192);
+                        q[gq][c] = mfm_round_pack(o_re, o_im);
+                    }
+                }
+                if (it == 0) {
+                    /* column 0 of the pass is the last filtered sample of the previous pass (a select, not
+                     * a branch: see the hazard note above) */
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        q[0][c] = use_carry ? carry[c] : q[0][c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    /* previous output of the same channel: the lane to the left; column 16's is column 15 */
+                    const uint32_t p0 =
+                        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[0][c], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    const int wrap = __builtin_amdgcn_update_dpp(0, (int)q[0][c], 0x121 /* row_ror:1 */, 0xf, 0xf, false);
+                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(wrap, (int)q[1][c], 0x111 /* row_shr:1 */,
+                                                                              0xf, 0xf, false);
+                    const uint32_t pp[2] = { p0, p1 };
+#pragma unroll
+                    for (int gq = 0; gq < 2; gq++) {
+                        /* multifm/fm_demod.c:55-64: s = q * conj(p), wrapping int32 */
+                        const int s_re = mfm_dot2m(q[gq][c], pp[gq], 0);
+                        int u, t;
+                        asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(u) : "v"(q[gq][c]), "v"(pp[gq]));
+                        asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[0,1,0,0]" : "=v"(t) : "v"(q[gq][c]), "v"(pp[gq]));
+                        const int s_im = (int)((uint32_t)u - (uint32_t)t); /* q_im*p_re - q_re*p_im */
+                        pcm[gq][c] = mfm_discriminate(s_re, s_im, lut);
+                    }
+                }
+            }
+
+            /* the prefetched samples go to the other staging buffer before this iteration's PCM stores are
+             * issued, so the wait for them does not also wait for those stores */
+            if (have_n) {
+#pragma unroll
+                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
+                    stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            if (rb_valid) {
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    const int rel = rel_first + (int)(it * MFM_M_NEW + 16u * gq + n);
+                    const bool store_ok = (gq != 0 || n != 0) && (rel < (int)L.n_new);
+                    if (store_ok) {
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            const uint32_t chn = ch0 + c;
+                            if (chn < L.nchan) {
+                                const uint32_t at = chn * L.out_stride + (uint32_t)rel; /* fits 32 bits (engine checks) */
+                                L.pcm[at] = (int16_t)pcm[gq][c];
+                                if (DBG_IQ) {
+                                    L.iq_dbg[at] = q[gq][c];
+                                }
+                                if (rel == (int)L.n_new - 1) {
+                                    L.st_out[chn].carry_q = q[gq][c];
+                                }
+                            }
+                        }
+                    }
+                }
+                MFM_STAMP(7);
+            }
+        }
+
+        if (rb_valid && tile == 0 && n == 0) {
+            /* rotator index of the next pass's first output, one lane per channel pair */
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t chn = ch0 + c;
                 if (chn < L.nchan) {
                     const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chn * 8;
                     const uint32_t mu = ip[2], lam = ip[3], lam_magic = ip[4];
@@ -273,6 +427,17 @@ __global__ __launch_bounds__(MFM_MFMA_NW * 64, 2) void mfm_channel_kernel_mfma(c
                 }
             }
         }
+
+        MFM_STAMP(4);
+        __syncthreads(); /* next tile's image is complete and nobody reads the current one any more */
+        MFM_STAMP(5);
+        cur ^= 1u;
+        item = item_n;
+        tile = tile_n;
+        slice = slice_n;
+        have = have_n;
+        k_off[0] = k_off_n[0];
+        k_off[1] = k_off_n[1];
     }
 }
 
@@ -282,9 +447,9 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
     if (L->ntiles == 0) {
         return hipSuccess;
     }
-#define MFM_LAUNCH_M(KS_, DBG_)                                                                              \
+#define MFM_LAUNCH_M(KQ_, DBG_)                                                                              \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KS_, DBG_>;                                                       \
+        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_>;                                                       \
         static uint32_t lds_set_ = 0;                                                                        \
         if (lds_bytes > lds_set_) {                                                                          \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
@@ -294,25 +459,24 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
             }                                                                                                \
             lds_set_ = lds_bytes;                                                                            \
         }                                                                                                    \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_MFMA_NW * 64), lds_bytes, stream, *L);                  \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
     } while (0)
-#define MFM_LAUNCH_KS(KS_)                                                                                   \
+#define MFM_LAUNCH_KQ(KQ_)                                                                                   \
     do {                                                                                                     \
         if (dbg_iq) {                                                                                        \
-            MFM_LAUNCH_M(KS_, true);                                                                         \
+            MFM_LAUNCH_M(KQ_, true);                                                                         \
         } else {                                                                                             \
-            MFM_LAUNCH_M(KS_, false);                                                                        \
+            MFM_LAUNCH_M(KQ_, false);                                                                        \
         }                                                                                                    \
     } while (0)
 
-    switch (L->ks) {
-    case 1: MFM_LAUNCH_KS(1); break;
-    case 2: MFM_LAUNCH_KS(2); break;
-    case 4: MFM_LAUNCH_KS(4); break;
-    case 8: MFM_LAUNCH_KS(8); break;
+    switch (L->kq) {
+    case 1: MFM_LAUNCH_KQ(1); break;
+    case 2: MFM_LAUNCH_KQ(2); break;
+    case 4: MFM_LAUNCH_KQ(4); break;
     default: return hipErrorInvalidValue;
     }
-#undef MFM_LAUNCH_KS
+#undef MFM_LAUNCH_KQ
 #undef MFM_LAUNCH_M
     return hipGetLastError();
 }

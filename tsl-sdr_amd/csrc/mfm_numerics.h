@@ -88,6 +88,27 @@ struct mfm_lut_ent {
 #define MFM_LUT_Y(e) (e).y
 #endif
 
+/* Correctly rounded mn / mx.  On the device this is the core of the compiler's own IEEE fdiv
+ * expansion (v_rcp_f32 + three Newton/residual steps) without the v_div_scale / v_div_fixup
+ * wrapping that only matters for subnormal, infinite or zero operands: here both operands are
+ * int32 values converted to float, mn <= mx, so the quotient is in [2^-31, 1] (or 0/0 -> NaN, which
+ * the caller discards). */
+MFM_HD float mfm_div_unit(float mn, float mx)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(mx);
+    const float e0 = __builtin_fmaf(-mx, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = mn * r1;
+    const float e1 = __builtin_fmaf(-mx, q0, mn);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-mx, q1, mn);
+    return __builtin_fmaf(e2, r1, q1);
+#else
+    return mn / mx;
+#endif
+}
+
 MFM_HD int32_t mfm_discriminate(int32_t s_re, int32_t s_im, MFM_LUT_T lut)
 {
 #if defined(__clang__)
@@ -95,31 +116,40 @@ MFM_HD int32_t mfm_discriminate(int32_t s_re, int32_t s_im, MFM_LUT_T lut)
 #endif
     const float y = (float)s_im, x = (float)s_re; /* fm_demod.c:68 */
     const float ya = __builtin_fabsf(y), xa = __builtin_fabsf(x);
-    const float mx = ya > xa ? ya : xa, mn = ya > xa ? xa : ya;
+    const bool tall = ya > xa;
+    const float mx = tall ? ya : xa, mn = tall ? xa : ya;
 
     /* fast_atan2f.c:114-117: z = min/max (equal magnitudes give x_abs/y_abs = 1) */
-    const float z = mn / mx;
+    const float z = mfm_div_unit(mn, mx);
 
-    float base = z; /* :121-122 */
-    if (!(z < MFM_TAN_MAP_RES_F)) {
-        float alpha = z * 255.0f;               /* :125 */
-        const int idx = ((int)alpha) & 0xff;    /* :126 */
-        alpha = alpha - (float)idx;             /* :127 */
-        const float t0 = MFM_LUT_X(lut[idx]), dt = MFM_LUT_Y(lut[idx]);
-        const float prod = dt * alpha;
-        base = t0 + prod;                       /* :130-131, unfused */
-    }
+    /* :121-132, both arms evaluated, no branch (idx is 0 when z is below the threshold or NaN) */
+    float alpha = z * 255.0f;               /* :125 */
+    const int idx = ((int)alpha) & 0xff;    /* :126 */
+    alpha = alpha - (float)idx;             /* :127 */
+    const float t0 = MFM_LUT_X(lut[idx]), dt = MFM_LUT_Y(lut[idx]);
+    const float prod = dt * alpha;
+    const float interp = t0 + prod;         /* :130-131, unfused */
+    const float base = (z < MFM_TAN_MAP_RES_F) ? z : interp;
 
     /* :134-163 folded: every branch is sign(y) * (K + u) with K in {0, pi, pi/2}, u = +-base */
-    const bool x_nonneg = x >= 0.0f, wide = xa > ya;
+    const bool x_nonneg = s_re >= 0, wide = xa > ya;
     const float k = wide ? (x_nonneg ? 0.0f : MFM_PI_F) : MFM_HALF_PI_F;
     const float u = (x_nonneg == wide) ? base : -base;
     const float mag = k + u;
 
     /* fm_demod.c:71-72 on |angle|, sign restored afterwards (division, rounding and the
      * truncating cast are all odd-symmetric) */
-    int32_t pcm = mfm_mag_to_pcm(mag);
-    pcm = (y >= 0.0f) ? pcm : -pcm;
+    const float lo = mag * MFM_Q14_OVER_PI_LO;
+    const float sc = __builtin_fmaf(mag, MFM_Q14_OVER_PI_HI, lo);
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* sign of y = sign of s_im; (0,0) made z NaN and NaN converts to 0 (v_cvt_i32_f32), which is
+     * fast_atan2f.c:111-112's answer */
+    const float signed_sc = __int_as_float((__float_as_int(sc) & 0x7fffffff) | (s_im & (int32_t)0x80000000));
+    return (int32_t)signed_sc;
+#else
+    int32_t pcm = (int32_t)sc;
+    pcm = (s_im >= 0) ? pcm : -pcm;
     /* fast_atan2f.c:111-112: (0,0) -> 0 (mx == 0 made z NaN above; it is discarded here) */
     return (mx > 0.0f) ? pcm : 0;
+#endif
 }
