@@ -2,7 +2,7 @@
 """bench.py - throughput of the multifm channel hot path on N MI355X GPUs.
 
 One "step" = one pass of the fused FIR + derotator + FM-discriminator kernel over one block of
-synthetic wideband int16 IQ (default 2^24 samples = 64 MiB) for every channel a GPU owns.
+synthetic wideband int16 IQ (default 2^26 samples = 256 MiB) for every channel a GPU owns.
 
   N = 1 : BASELINE.json configs[1] - 64 channels, 128-tap 25 kHz LPF, decimation 96, 2.4 MS/s-shaped IQ.
   N > 1 : the same 64 channels PER GPU (weak scaling; N = 8 with --channels-per-gpu 128 is configs[2]).
@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels-per-gpu", type=int, default=64)
-    ap.add_argument("--block-log2", type=int, default=24, help="log2 of wideband samples per step")
+    ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")

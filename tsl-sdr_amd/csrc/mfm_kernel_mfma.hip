@@ -265,18 +265,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
 #pragma unroll
         for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
-            /* Vector-memory order matters (one in-order counter): first the rotator entries of this
-             * iteration's columns (L2 hits, needed right after the matrix work; their addresses do not
-             * depend on data), then this iteration's share of the next tile's input (HBM, needed only at
-             * the end of the iteration), so waiting for the former leaves the latter in flight. */
-            const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
-            uint2 rv[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                rv[0][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c]);
-                rv[1][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c] + 16u * 8u);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            /* this iteration's share of the next tile's input: loads in flight across the matrix work */
             uint4 pre[MFM_M_CH / MFM_M_ITERS];
             if (have_n) {
 #pragma unroll
@@ -284,11 +273,19 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     pre[u] = stage_load(tile_n, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
 
             uint32_t q[2][2];
             int pcm[2][2];
             if (rb_valid) {
+                /* rotator entries of this iteration's columns (two groups x two channels): addresses do
+                 * not depend on data, so the loads are issued ahead of the matrix work */
+                const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
+                uint2 rv[2][2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    rv[0][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c]);
+                    rv[1][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c] + 16u * 8u);
+                }
 
                 /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
                 mfm_v4i hh[2], md[2], ll[2];
@@ -370,19 +367,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                         pcm[gq][c] = mfm_discriminate(s_re, s_im, lut);
                     }
                 }
-            }
-
-            /* the prefetched samples go to the other staging buffer before this iteration's PCM stores are
-             * issued, so the wait for them does not also wait for those stores */
-            if (have_n) {
-#pragma unroll
-                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
-                    stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-
-            if (rb_valid) {
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) {
                     const int rel = rel_first + (int)(it * MFM_M_NEW + 16u * gq + n);
@@ -405,6 +389,13 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     }
                 }
                 MFM_STAMP(7);
+            }
+
+            if (have_n) {
+#pragma unroll
+                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
+                    stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
+                }
             }
         }
 
