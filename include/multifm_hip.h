@@ -95,7 +95,7 @@ struct mfm_stats {
     uint32_t tail_samples;     /* unconsumed samples carried to the next block */
     uint64_t rot_table_entries;
     uint32_t kernel_variant;   /* 0 = v_dot2 kernel, 1 = int8-MFMA (FIR-as-GEMM) kernel */
-    uint32_t reserved;
+    uint32_t pending_blocks;   /* finished or in-flight blocks not yet fetched + released */
 };
 
 /* Size in bytes of one input staging buffer for this configuration and tap count. */

@@ -1,0 +1,203 @@
+"""The C host around the engine (tsl-sdr_amd/host): JSON configuration with the reference's key names,
+the sample_buf pool and refcount contract, and - on the GPU - the multifm-shaped driver end to end on
+file_if input (BASELINE configs[0])."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_SO = os.path.join(ROOT, "tsl-sdr_amd", "host", "libmfm_host.so")
+MULTIFM = os.path.join(ROOT, "tsl-sdr_amd", "host", "multifm_amd")
+REF_ETC = "/root/reference/etc"
+
+
+class Config(C.Structure):
+    _fields_ = [("node", C.c_void_p), ("owner", C.c_bool)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    if not os.path.exists(HOST_SO):
+        pytest.fail(f"{HOST_SO} missing: run make -C tsl-sdr_amd")
+    h = C.CDLL(HOST_SO)
+    h.config_new.argtypes = [C.POINTER(C.POINTER(Config))]
+    h.config_add.argtypes = [C.POINTER(Config), C.c_char_p]
+    h.config_add_string.argtypes = [C.POINTER(Config), C.c_char_p]
+    h.config_delete.argtypes = [C.POINTER(C.POINTER(Config))]
+    h.config_delete.restype = None
+    h.config_get.argtypes = [C.POINTER(Config), C.POINTER(Config), C.c_char_p]
+    h.config_get_integer.argtypes = [C.POINTER(Config), C.POINTER(C.c_int), C.c_char_p]
+    h.config_get_float.argtypes = [C.POINTER(Config), C.POINTER(C.c_double), C.c_char_p]
+    h.config_get_string.argtypes = [C.POINTER(Config), C.POINTER(C.c_char_p), C.c_char_p]
+    h.config_get_float_array.argtypes = [C.POINTER(Config), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t), C.c_char_p]
+    h.config_array_length.argtypes = [C.POINTER(Config), C.POINTER(C.c_size_t)]
+    h.config_array_at.argtypes = [C.POINTER(Config), C.POINTER(Config), C.c_size_t]
+    return h
+
+
+def _new(host):
+    p = C.POINTER(Config)()
+    assert host.config_new(C.byref(p)) == 0
+    return p
+
+
+def _int(host, cfg, key):
+    v = C.c_int()
+    rc = host.config_get_integer(cfg, C.byref(v), key.encode())
+    return rc, v.value
+
+
+def test_config_merge_and_types(host):
+    cfg = _new(host)
+    assert host.config_add_string(cfg, b'{"sampleRateHz": 1000000, "decimationFactor": 40, "x": {"y": [1, 2.5, -3e2]}}') == 0
+    # a second "file" adds and overrides top-level keys (multifm.c:105-111 stacks config files)
+    assert host.config_add_string(cfg, b'{"decimationFactor": 96, "lpfTaps": [0.25, 0.5, 0.25], "name": "a\\"b"}') == 0
+    assert _int(host, cfg, "sampleRateHz") == (0, 1000000)
+    assert _int(host, cfg, "decimationFactor") == (0, 96)
+    assert _int(host, cfg, "missing")[0] < 0
+    vals, n = C.POINTER(C.c_double)(), C.c_size_t()
+    assert host.config_get_float_array(cfg, C.byref(vals), C.byref(n), b"lpfTaps") == 0
+    assert [vals[i] for i in range(n.value)] == [0.25, 0.5, 0.25]
+    s = C.c_char_p()
+    assert host.config_get_string(cfg, C.byref(s), b"name") == 0 and s.value == b'a"b'
+    sub, arr, item = Config(), Config(), Config()
+    assert host.config_get(cfg, C.byref(sub), b"x") == 0
+    assert host.config_get(C.byref(sub), C.byref(arr), b"y") == 0
+    ln = C.c_size_t()
+    assert host.config_array_length(C.byref(arr), C.byref(ln)) == 0 and ln.value == 3
+    assert host.config_array_at(C.byref(arr), C.byref(item), 3) < 0
+    # a float is not an integer (the reference's config_get_integer rejects 2.5 as well)
+    assert host.config_add_string(cfg, b'{"f": 2.5}') == 0 and _int(host, cfg, "f")[0] < 0
+    assert host.config_add_string(cfg, b'{"broken": [1, 2') < 0
+    host.config_delete(C.byref(cfg))
+
+
+def test_own_etc_files_load(host):
+    cfg = _new(host)
+    assert host.config_add(cfg, os.path.join(ROOT, "etc", "multifm_1ch_file.json").encode()) == 0
+    assert host.config_add(cfg, os.path.join(ROOT, "etc", "lpf_25khz_1000k_128.json").encode()) == 0
+    vals, n = C.POINTER(C.c_double)(), C.c_size_t()
+    assert host.config_get_float_array(cfg, C.byref(vals), C.byref(n), b"lpfTaps") == 0 and n.value == 128
+    assert abs(sum(vals[i] for i in range(128)) - 1.0) < 1e-12
+    host.config_delete(C.byref(cfg))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ETC), reason="reference tree not present (only in the authoring container)")
+def test_reference_etc_files_load_unchanged(host):
+    """Every non-empty JSON the reference ships must load with its keys readable."""
+    seen = 0
+    for name in sorted(os.listdir(REF_ETC)):
+        path = os.path.join(REF_ETC, name)
+        if os.path.getsize(path) == 0:
+            continue  # etc/pocsag_narrow.json and etc/pocsag_1200khz_fs.json are empty files
+        want = json.load(open(path))
+        cfg = _new(host)
+        assert host.config_add(cfg, path.encode()) == 0, name
+        for key, val in want.items():
+            if isinstance(val, bool):
+                continue
+            if isinstance(val, int):
+                assert _int(host, cfg, key) == (0, val), (name, key)
+            elif isinstance(val, list) and val and isinstance(val[0], float):
+                vals, n = C.POINTER(C.c_double)(), C.c_size_t()
+                assert host.config_get_float_array(cfg, C.byref(vals), C.byref(n), key.encode()) == 0
+                assert [vals[i] for i in range(n.value)] == val, (name, key)
+            elif key == "channels":
+                arr, item = Config(), Config()
+                assert host.config_get(cfg, C.byref(arr), b"channels") == 0
+                for i, ch in enumerate(val):
+                    assert host.config_array_at(C.byref(arr), C.byref(item), i) == 0
+                    assert _int(host, C.byref(item), "chanCenterFreq") == (0, ch["chanCenterFreq"])
+                    s = C.c_char_p()
+                    assert host.config_get_string(C.byref(item), C.byref(s), b"outFifo") == 0
+                    assert s.value.decode() == ch["outFifo"]
+        host.config_delete(C.byref(cfg))
+        seen += 1
+    assert seen >= 8
+
+
+def test_frame_pool_and_refcount_contract(host):
+    """nrSampBufs frames; exhaustion fails instead of blocking (receiver.c:57-63 then drops and counts);
+    a buffer returns to the pool when the last holder decrefs it (sample_buf.c:31-43)."""
+    fa = C.c_void_p()
+    host.frame_alloc_new.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t]
+    host.frame_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    host.frame_free.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    host.frame_alloc_nr_free.argtypes = [C.c_void_p]
+    host.frame_alloc_nr_free.restype = C.c_size_t
+    host.frame_alloc_delete.argtypes = [C.POINTER(C.c_void_p)]
+    assert host.frame_alloc_new(C.byref(fa), 48 + 4096 * 4, 4) == 0
+    frames = []
+    for _ in range(4):
+        f = C.c_void_p()
+        assert host.frame_alloc(fa, C.byref(f)) == 0 and f.value % 64 == 0
+        frames.append(f)
+    extra = C.c_void_p()
+    assert host.frame_alloc(fa, C.byref(extra)) < 0 and not extra.value
+    assert host.frame_alloc_nr_free(fa) == 0
+    for f in frames:
+        assert host.frame_free(fa, C.byref(f)) == 0
+    assert host.frame_alloc_nr_free(fa) == 4
+    assert host.frame_alloc_delete(C.byref(fa)) == 0
+
+
+def _run_multifm(tmp_path, pkg, fmt, iq16, raw_bytes, fs, decim, center, chans, taps_file, gains_db=None):
+    cap = tmp_path / f"cap_{fmt}.bin"
+    cap.write_bytes(raw_bytes)
+    cfg = {"device": {"type": "file", "filename": str(cap), "fileFormat": fmt}, "sampleRateHz": fs,
+           "centerFreqHz": center, "nrSampBufs": 32, "decimationFactor": decim, "channels": []}
+    outs = []
+    for i, f in enumerate(chans):
+        o = tmp_path / f"ch{i}_{fmt}.pcm"
+        o.write_bytes(b"")  # the driver opens sinks O_WRONLY like the reference opens its FIFOs
+        ch = {"outFifo": str(o), "chanCenterFreq": int(center + f)}
+        if gains_db and gains_db[i] is not None:
+            ch["dBGain"] = gains_db[i]
+        if i == 0:
+            q = tmp_path / f"ch{i}_{fmt}.iq"
+            q.write_bytes(b"")
+            ch["signalDebugFile"] = str(q)
+        cfg["channels"].append(ch)
+        outs.append(o)
+    cj = tmp_path / f"cfg_{fmt}.json"
+    cj.write_text(json.dumps(cfg))
+    r = subprocess.run([MULTIFM, str(cj), taps_file], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [np.frombuffer(o.read_bytes(), dtype=np.int16) for o in outs], \
+        np.frombuffer((tmp_path / f"ch0_{fmt}.iq").read_bytes(), dtype=np.int16).reshape(-1, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["cs16", "cs8", "cu8"])
+def test_multifm_driver_on_file_input(tmp_path, pkg, ora, fmt):
+    """BASELINE configs[0]: etc/multifm_1ch.json values (fs 1.0 MS/s, D 40, channel at +112.5 kHz) plus a second
+    channel with dBGain, fed from a file through file_if's three sample formats; the FIFO byte streams must be
+    the oracle's PCM."""
+    fs, decim, center = 1000000, 40, 929500000
+    offs, gains_db = [112500, -200000], [None, 4.0]
+    taps_file = os.path.join(ROOT, "etc", "lpf_25khz_1000k_128.json")
+    taps = np.array(json.load(open(taps_file))["lpfTaps"])
+    n = 4096 * 37 + 1234  # last buffer is a partial one
+    if fmt == "cs16":
+        iq = pkg.synth.synth_iq(n, fs, offs, seed=91)
+        raw = iq.tobytes()
+    else:
+        rng = np.random.RandomState(92)
+        b = rng.randint(0, 256, size=(n, 2)).astype(np.uint8)
+        raw = b.tobytes()
+        s8 = b.view(np.int8).astype(np.int16)
+        # file_if.c:92-96 (cs8: plain widening) and :139-143 (cu8: bytes read as SIGNED, minus 127)
+        iq = s8 if fmt == "cs8" else (s8 - 127).astype(np.int16)
+    pcm, q = _run_multifm(tmp_path, pkg, fmt, iq, raw, fs, decim, center, offs, taps_file, gains_db)
+    gains = [1.0, 10.0 ** (4.0 / 10.0)]
+    cre = np.stack([ora.make_taps(taps, o, fs, g)[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, o, fs, g)[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(o, fs, decim) for o in offs])
+    ref, refq = ora.run_channels(iq, cre, cim, incr, decim, want_iq=True)
+    for c in range(2):
+        assert pcm[c].shape == ref[c].shape and np.array_equal(pcm[c], ref[c]), f"channel {c} PCM differs"
+    assert np.array_equal(q, refq[0])

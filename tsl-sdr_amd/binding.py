@@ -50,7 +50,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("nr_channels", C.c_uint32), ("nr_taps", C.c_uint32),
                 ("outputs_per_tile", C.c_uint32), ("lds_bytes", C.c_uint32), ("grid_last", C.c_uint32),
                 ("tail_samples", C.c_uint32), ("rot_table_entries", C.c_uint64),
-                ("kernel_variant", C.c_uint32), ("reserved", C.c_uint32)]
+                ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32)]
 
 
 _lib = None

@@ -190,6 +190,10 @@ struct mfm_engine {
     uint64_t samples_in = 0, outputs = 0, launches = 0;
     uint32_t grid_last = 0;
 
+    /* one producer thread (push/submit) and one consumer thread (fetch/release) may use the engine
+     * concurrently: this guards the bookkeeping they share; device waits happen outside it */
+    std::mutex mu;
+
     /* timing */
     hipEvent_t t0[kTimingPairs], t1[kTimingPairs];
     uint64_t t_head = 0, t_tail = 0;
@@ -790,6 +794,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
                     e->cfg.max_block_samples);
     }
     HIP_TRY(hipSetDevice(e->cfg.device));
+    std::lock_guard<std::mutex> guard(e->mu);
 
     const uint32_t T = e->nr_taps, D = e->cfg.decimation, C = (uint32_t)e->chans.size();
     const bool dev_only = (e->cfg.flags & MFM_F_DEVICE_ONLY) != 0;
@@ -959,6 +964,7 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
     }
     /* refuse before staging anything if the output ring is full, so a caller can drain and retry */
     if (!(e->cfg.flags & MFM_F_DEVICE_ONLY)) {
+        std::lock_guard<std::mutex> guard(e->mu);
         const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
         if (n_avail >= e->nr_taps && e->slots[e->submit_seq % e->nslots].state != OutSlot::FREE) {
             return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
@@ -988,15 +994,21 @@ int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk)
     if (!e->committed || (e->cfg.flags & MFM_F_DEVICE_ONLY)) {
         return fail(MFM_E_STATE, "fetch needs a committed engine without MFM_F_DEVICE_ONLY");
     }
-    if (e->fetch_seq >= e->submit_seq) {
-        return MFM_E_DONE;
+    OutSlot *sp = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(e->mu);
+        if (e->fetch_seq >= e->submit_seq) {
+            return MFM_E_DONE;
+        }
+        sp = &e->slots[e->fetch_seq % e->nslots];
+        if (sp->state == OutSlot::FETCHED) {
+            return fail(MFM_E_STATE, "release the previous block first");
+        }
     }
-    OutSlot &s = e->slots[e->fetch_seq % e->nslots];
-    if (s.state == OutSlot::FETCHED) {
-        return fail(MFM_E_STATE, "release the previous block first");
-    }
+    OutSlot &s = *sp;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipEventSynchronize(s.ready));
+    HIP_TRY(hipEventSynchronize(s.ready)); /* outside the lock: the producer keeps submitting meanwhile */
+    std::lock_guard<std::mutex> guard(e->mu);
     s.state = OutSlot::FETCHED;
     blk->first_output = s.first_output;
     blk->nr_outputs = s.nr_outputs;
@@ -1011,6 +1023,7 @@ int mfm_engine_release(struct mfm_engine *e)
     if (!e) {
         return fail(MFM_E_INVAL, "NULL engine");
     }
+    std::lock_guard<std::mutex> guard(e->mu);
     if (!e->committed || e->fetch_seq >= e->submit_seq) {
         return fail(MFM_E_STATE, "nothing fetched");
     }
@@ -1104,6 +1117,10 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->outputs_per_tile = e->use_mfma ? e->m_ot : 64u * e->opl;
     st->lds_bytes = e->use_mfma ? e->m_lds_bytes : e->lds_bytes;
     st->kernel_variant = e->use_mfma ? 1u : 0u;
+    {
+        std::lock_guard<std::mutex> guard(e->mu);
+        st->pending_blocks = (uint32_t)(e->submit_seq - e->fetch_seq);
+    }
     st->grid_last = e->grid_last;
     st->tail_samples = e->tail;
     st->rot_table_entries = e->rot_entries;

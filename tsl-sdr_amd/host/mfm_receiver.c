@@ -1,0 +1,524 @@
+/*
+ * mfm_receiver.c - receiver / demod_thread / sample_buf plumbing of multifm on the MI355X engine.
+ *
+ * Follows the behaviour of the reference's multifm/receiver.c, multifm/demod.c (set-up and FIFO output
+ * only; the per-buffer DSP loop demod.c:48-121 is the engine's kernel) and filter/sample_buf.c.
+ */
+#include "mfm_receiver.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdatomic.h>
+#include <unistd.h>
+
+#define MFM_MSG(sev, sys, msg, ...) MESSAGE("MULTIFM", sev, sys, msg, ##__VA_ARGS__)
+
+/* ---- intrusive list (the reference uses TSL's <tsl/list.h>) ---- */
+
+static void list_init(struct list_entry *e)
+{
+    e->prev = e->next = e;
+}
+
+static void list_append(struct list_entry *head, struct list_entry *e)
+{
+    e->prev = head->prev;
+    e->next = head;
+    head->prev->next = e;
+    head->prev = e;
+}
+
+static void list_del(struct list_entry *e)
+{
+    e->prev->next = e->next;
+    e->next->prev = e->prev;
+    e->prev = e->next = e;
+}
+
+#define list_for_each_type(pos, head, member)                                                                \
+    for (pos = BL_CONTAINER_OF((head)->next, __typeof__(*pos), member); &pos->member != (head);              \
+         pos = BL_CONTAINER_OF(pos->member.next, __typeof__(*pos), member))
+
+/* ---- sample buffers ---- */
+
+aresult_t sample_buf_decref(struct sample_buf *buf)
+{
+    TSL_ASSERT_ARG(NULL != buf);
+    /* filter/sample_buf.c:31-43: the holder that takes the count to zero releases the buffer */
+    if (1 == atomic_fetch_sub((_Atomic uint32_t *)&buf->refcount, 1)) {
+        TSL_BUG_ON(NULL == buf->release);
+        TSL_BUG_IF_FAILED(buf->release(buf));
+    }
+    return A_OK;
+}
+
+static aresult_t _sample_buf_release(struct sample_buf *buf)
+{
+    TSL_ASSERT_ARG(NULL != buf);
+    TSL_BUG_ON(atomic_load((_Atomic uint32_t *)&buf->refcount) != 0);
+    struct frame_alloc *fa = buf->priv;
+    return frame_free(fa, (void **)&buf);
+}
+
+/* ---- channels ---- */
+
+static struct mfm_engine *g_bound_engine; /* set by receiver_init() around its channel loop */
+
+void demod_thread_bind_engine(struct mfm_engine *engine)
+{
+    g_bound_engine = engine;
+}
+
+aresult_t demod_thread_new(struct demod_thread **pthr, unsigned core_id, int32_t offset_hz, uint32_t samp_hz,
+                           const char *out_fifo, int decimation_factor, const double *lpf_taps, size_t lpf_nr_taps,
+                           const char *fir_debug_output, double channel_gain)
+{
+    aresult_t ret = A_OK;
+    struct demod_thread *thr = NULL;
+
+    TSL_ASSERT_ARG(NULL != pthr);
+    TSL_ASSERT_ARG(NULL != out_fifo && '\0' != *out_fifo);
+    TSL_ASSERT_ARG(0 != decimation_factor);
+    TSL_ASSERT_ARG(NULL != lpf_taps);
+    TSL_ASSERT_ARG(0 != lpf_nr_taps);
+    (void)core_id;
+    (void)samp_hz; /* the engine was created with the receiver's sample rate and decimation */
+
+    *pthr = NULL;
+    if (NULL == g_bound_engine) {
+        MFM_MSG(SEV_FATAL, "NO-ENGINE", "demod_thread_new() outside receiver_init(): no engine is bound");
+        return A_E_INVAL;
+    }
+    if (FAILED(ret = TZAALLOC(thr, SYS_CACHE_LINE_LENGTH))) {
+        return ret;
+    }
+    thr->fifo_fd = -1;
+    thr->debug_signal_fd = -1;
+    list_init(&thr->dt_node);
+
+    const bool want_iq = NULL != fir_debug_output && '\0' != *fir_debug_output;
+    int chan = mfm_engine_add_channel(g_bound_engine, offset_hz, lpf_taps, lpf_nr_taps, channel_gain, want_iq);
+    if (chan < 0) {
+        MFM_MSG(SEV_FATAL, "BAD-CHANNEL", "Channel at offset %d Hz rejected: %s", offset_hz, mfm_last_error());
+        ret = A_E_INVAL;
+        goto done;
+    }
+    thr->chan_index = chan;
+
+    /* same order and flags as multifm/demod.c:322-331: debug file first, then the FIFO, both O_WRONLY
+     * (opening a FIFO blocks until a reader shows up) */
+    if (want_iq) {
+        if (0 > (thr->debug_signal_fd = open(fir_debug_output, O_WRONLY))) {
+            MFM_MSG(SEV_FATAL, "CANT-OPEN-SIGNAL-DEBUG", "Unable to open signal debug dump file '%s'", fir_debug_output);
+            ret = A_E_INVAL;
+            goto done;
+        }
+    }
+    if (0 > (thr->fifo_fd = open(out_fifo, O_WRONLY))) {
+        MFM_MSG(SEV_FATAL, "CANT-OPEN-FIFO", "Unable to open output fifo '%s'", out_fifo);
+        ret = A_E_INVAL;
+        goto done;
+    }
+    *pthr = thr;
+
+done:
+    if (FAILED(ret) && NULL != thr) {
+        if (-1 != thr->fifo_fd) {
+            close(thr->fifo_fd);
+        }
+        if (-1 != thr->debug_signal_fd) {
+            close(thr->debug_signal_fd);
+        }
+        TFREE(thr);
+    }
+    return ret;
+}
+
+aresult_t demod_thread_delete(struct demod_thread **pthr)
+{
+    TSL_ASSERT_ARG(NULL != pthr);
+    TSL_ASSERT_ARG(NULL != *pthr);
+    struct demod_thread *thr = *pthr;
+    if (-1 != thr->fifo_fd) {
+        close(thr->fifo_fd);
+        thr->fifo_fd = -1;
+    }
+    if (-1 != thr->debug_signal_fd) {
+        close(thr->debug_signal_fd);
+        thr->debug_signal_fd = -1;
+    }
+    TFREE(thr);
+    *pthr = NULL;
+    return A_OK;
+}
+
+/* write one channel's share of a finished block: the FIFO byte stream of demod.c:93, EPIPE policy :95-110 */
+static void _demod_thread_emit(struct demod_thread *dthr, const struct mfm_block *blk)
+{
+    const size_t n = blk->nr_outputs;
+    const int16_t *pcm = blk->pcm + (size_t)dthr->chan_index * blk->stride;
+
+    dthr->total_nr_demod_samples += n;
+    if (-1 != dthr->debug_signal_fd && NULL != blk->iq) {
+        const int16_t *iq = blk->iq + (size_t)dthr->chan_index * blk->stride * 2;
+        if (0 > write(dthr->debug_signal_fd, iq, n * 2 * sizeof(int16_t))) {
+            int errnum = errno;
+            MFM_MSG(SEV_WARNING, "CANT-WRITE-DEBUG-FILE", "Unable to write %zu bytes to post-demod debug file. "
+                    "Reason: %s (%d). Skipping.", n * 2 * sizeof(int16_t), strerror(errnum), errnum);
+        }
+    }
+
+    size_t done = 0;
+    while (done < n) {
+        ssize_t w = write(dthr->fifo_fd, pcm + done, (n - done) * sizeof(int16_t));
+        if (w < 0) {
+            int errnum = errno;
+            if (errnum == EINTR) {
+                continue;
+            }
+            if (errnum == EPIPE) {
+                if (0 == dthr->nr_dropped_samples) {
+                    MFM_MSG(SEV_WARNING, "FIFO-REMOTE-END-DISCONNECTED", "Remote end of FIFO disconnected. "
+                            "Until a process picks up the FIFO, we're dropping samples.");
+                }
+                dthr->nr_dropped_samples += n - done;
+                return;
+            }
+            PANIC("Failed to write %zu bytes to the output fifo. Reason: %s (%d)", (n - done) * sizeof(int16_t),
+                  strerror(errnum), errnum);
+        }
+        done += (size_t)w / sizeof(int16_t);
+    }
+    dthr->total_nr_pcm_samples += n;
+    if (0 != dthr->nr_dropped_samples) {
+        MFM_MSG(SEV_WARNING, "FIFO-RESUMED", "Remote FIFO end reconnected. Dropped %zu samples in the interim.",
+                dthr->nr_dropped_samples);
+        dthr->nr_dropped_samples = 0;
+    }
+}
+
+/* ---- receiver ---- */
+
+aresult_t receiver_sample_buf_alloc(struct receiver *rx, struct sample_buf **pbuf)
+{
+    aresult_t ret = A_OK;
+    struct sample_buf *sbuf = NULL;
+
+    TSL_ASSERT_ARG(NULL != rx);
+    TSL_ASSERT_ARG(NULL != pbuf);
+    *pbuf = NULL;
+
+    /* pool exhausted: drop and count, log once (multifm/receiver.c:57-63) */
+    if (FAILED(ret = frame_alloc(rx->samp_alloc, (void **)&sbuf))) {
+        if (0 == rx->nr_samp_buf_alloc_fails) {
+            MFM_MSG(SEV_INFO, "NO-SAMPLE-BUFFER", "There are no available sample buffers, dropping received samples.");
+        }
+        rx->nr_samp_buf_alloc_fails++;
+        return ret;
+    }
+    sbuf->release = _sample_buf_release;
+    sbuf->priv = rx->samp_alloc;
+    sbuf->refcount = 0;
+    sbuf->sample_type = COMPLEX_INT_16;
+    *pbuf = sbuf;
+    return A_OK;
+}
+
+aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *buf)
+{
+    TSL_ASSERT_ARG(NULL != rx);
+    TSL_ASSERT_ARG(NULL != buf);
+    TSL_BUG_ON(0 == buf->nr_samples); /* multifm/receiver.c:84 */
+
+    /* one consumer: the engine.  It copies the samples into its pinned staging slot inside push(), so the
+     * buffer goes back to the pool right away. */
+    atomic_store((_Atomic uint32_t *)&buf->refcount, 1);
+    for (;;) {
+        int rc = mfm_engine_push(rx->engine, (const int16_t *)buf->data_buf, buf->nr_samples);
+        if (MFM_OK == rc) {
+            break;
+        }
+        if (MFM_E_BUSY == rc) {
+            /* all output slots hold blocks the drain thread has not written out yet */
+            usleep(200);
+            continue;
+        }
+        PANIC("mfm_engine_push failed: %s", mfm_last_error());
+    }
+    rx->nr_bufs_delivered++;
+    return sample_buf_decref(buf);
+}
+
+static aresult_t _receiver_drain_once(struct receiver *rx, bool *got)
+{
+    struct mfm_block blk;
+    struct demod_thread *dthr = NULL;
+
+    *got = false;
+    int rc = mfm_engine_fetch(rx->engine, &blk);
+    if (MFM_E_DONE == rc) {
+        return A_OK;
+    }
+    if (MFM_OK != rc) {
+        MFM_MSG(SEV_FATAL, "ENGINE-FETCH", "mfm_engine_fetch failed: %s", mfm_last_error());
+        return A_E_DEVICE;
+    }
+    if (!rx->muted) {
+        list_for_each_type(dthr, &rx->demod_threads, dt_node) {
+            _demod_thread_emit(dthr, &blk);
+        }
+    }
+    rx->nr_blocks_drained++;
+    *got = true;
+    return MFM_OK == mfm_engine_release(rx->engine) ? A_OK : A_E_DEVICE;
+}
+
+static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
+{
+    struct receiver *rx = BL_CONTAINER_OF(wthr, struct receiver, drain_thr);
+    while (worker_thread_is_running(wthr)) {
+        bool got = false;
+        if (FAILED(_receiver_drain_once(rx, &got))) {
+            return A_E_DEVICE;
+        }
+        if (!got) {
+            usleep(500);
+        }
+    }
+    return A_OK;
+}
+
+aresult_t receiver_drain(struct receiver *rx)
+{
+    TSL_ASSERT_ARG(NULL != rx);
+    /* wait for the device, then until every finished block has been written out */
+    if (MFM_OK != mfm_engine_sync(rx->engine)) {
+        return A_E_DEVICE;
+    }
+    for (;;) {
+        struct mfm_stats st;
+        if (MFM_OK != mfm_engine_get_stats(rx->engine, &st)) {
+            return A_E_DEVICE;
+        }
+        if (0 == st.pending_blocks) {
+            return A_OK;
+        }
+        if (rx->drain_thr.started) {
+            usleep(500); /* the drain thread owns fetch/release */
+        } else {
+            bool got = false;
+            TSL_BUG_IF_FAILED(_receiver_drain_once(rx, &got));
+        }
+    }
+}
+
+void receiver_mark_input_done(struct receiver *rx)
+{
+    rx->input_done = true;
+}
+
+aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,
+                        receiver_cleanup_func_t cleanup_func, size_t samples_per_buf)
+{
+    aresult_t ret = A_OK;
+    double *lpf_taps = NULL;
+    size_t lpf_nr_taps = 0, arr_ctr = 0;
+    int decimation_factor = 0, nr_samp_bufs = 0, sample_rate = 0, center_freq = 0;
+    struct config channels = CONFIG_INIT_EMPTY, channel = CONFIG_INIT_EMPTY;
+
+    TSL_ASSERT_ARG(NULL != rx);
+    TSL_ASSERT_ARG(NULL != cfg);
+    TSL_ASSERT_ARG(NULL != rx_func);
+    TSL_ASSERT_ARG(NULL != cleanup_func);
+    TSL_ASSERT_ARG(0 != samples_per_buf);
+
+    rx->muted = true;
+    rx->samp_alloc = NULL;
+    rx->cleanup_func = cleanup_func;
+    rx->thread_func = rx_func;
+    rx->engine = NULL;
+    rx->nr_demod_threads = 0;
+    list_init(&rx->demod_threads);
+
+    /* keys and defaults of multifm/receiver.c:133-184 */
+    if (FAILED(config_get_integer(cfg, &nr_samp_bufs, "nrSampBufs"))) {
+        MFM_MSG(SEV_INFO, "DEFAULT-SAMP-BUFS", "Setting sample buffer count to 64");
+        nr_samp_bufs = 64;
+    }
+    if (FAILED(ret = config_get_integer(cfg, &sample_rate, "sampleRateHz"))) {
+        MFM_MSG(SEV_INFO, "NO-SAMPLE-RATE", "Need to specify a sample rate, in Hertz.");
+        goto done;
+    }
+    if (FAILED(ret = config_get_integer(cfg, &center_freq, "centerFreqHz"))) {
+        MFM_MSG(SEV_INFO, "NO-CENTER-FREQ", "You forgot to specify a center frequency, in Hz.");
+        goto done;
+    }
+    MFM_MSG(SEV_INFO, "SAMPLE-RATE", "Sample rate is set to %u Hz", sample_rate);
+    MFM_MSG(SEV_INFO, "CENTER-FREQ", "Center Frequency is %u Hz", center_freq);
+
+    TSL_BUG_IF_FAILED(frame_alloc_new(&rx->samp_alloc, sizeof(struct sample_buf) + samples_per_buf * sizeof(int16_t) * 2,
+                                      (size_t)nr_samp_bufs));
+
+    if (FAILED(config_get_integer(cfg, &decimation_factor, "decimationFactor"))) {
+        MFM_MSG(SEV_INFO, "NO-DECIMATION", "Not decimating the output signal: using full bandwidth.");
+        ret = A_E_INVAL;
+        goto done;
+    }
+    if (0 >= decimation_factor) {
+        MFM_MSG(SEV_ERROR, "BAD-DECIMATION-FACTOR", "Decimation factor of '%d' is not valid.", decimation_factor);
+        ret = A_E_INVAL;
+        goto done;
+    }
+    if (FAILED(ret = config_get_float_array(cfg, &lpf_taps, &lpf_nr_taps, "lpfTaps"))) {
+        MFM_MSG(SEV_ERROR, "BAD-FILTER-TAPS", "Need to provide a baseband filter with at least two filter taps as 'lpfTaps'.");
+        goto done;
+    }
+    if (1 >= lpf_nr_taps) {
+        MFM_MSG(SEV_ERROR, "INSUFF-FILTER-TAPS", "Not enough filter taps for the low-pass filter.");
+        ret = A_E_INVAL;
+        goto done;
+    }
+    if (FAILED(config_get(cfg, &channels, "channels"))) {
+        MFM_MSG(SEV_ERROR, "MISSING-CHANNELS", "Need to specify at least one channel to demodulate.");
+        ret = A_E_INVAL;
+        goto done;
+    }
+
+    /* one engine for the whole channel set; "gpuDevice" picks the HIP device (default 0) */
+    {
+        struct mfm_engine_config ec;
+        int gpu = 0;
+        memset(&ec, 0, sizeof(ec));
+        (void)config_get_integer(cfg, &gpu, "gpuDevice");
+        ec.abi_version = MFM_ABI_VERSION;
+        ec.device = gpu;
+        ec.sample_rate_hz = (uint32_t)sample_rate;
+        ec.decimation = (uint32_t)decimation_factor;
+        ec.max_block_samples = (uint32_t)samples_per_buf;
+        if (MFM_OK != mfm_engine_create(&rx->engine, &ec)) {
+            MFM_MSG(SEV_FATAL, "ENGINE-CREATE", "Unable to create the channel engine: %s", mfm_last_error());
+            ret = A_E_DEVICE;
+            goto done;
+        }
+    }
+
+    demod_thread_bind_engine(rx->engine);
+    CONFIG_ARRAY_FOR_EACH(channel, &channels, ret, arr_ctr) {
+        const char *fifo_name = NULL, *signal_debug = NULL;
+        int nb_center_freq = -1;
+        struct demod_thread *dmt = NULL;
+        double channel_gain = 1.0, channel_gain_db = 0.0;
+
+        if (FAILED(ret = config_get_string(&channel, &fifo_name, "outFifo"))) {
+            MFM_MSG(SEV_ERROR, "MISSING-FIFO-ID", "Missing output FIFO filename, aborting.");
+            break;
+        }
+        if (FAILED(ret = config_get_integer(&channel, &nb_center_freq, "chanCenterFreq"))) {
+            MFM_MSG(SEV_ERROR, "MISSING-CENTER-FREQ", "Missing output channel center frequency.");
+            break;
+        }
+        if (!FAILED(config_get_string(&channel, &signal_debug, "signalDebugFile"))) {
+            MFM_MSG(SEV_INFO, "WRITING-SIGNAL-DEBUG", "The channel at frequency %d will have raw I/Q written to '%s'",
+                    nb_center_freq, signal_debug);
+        }
+        /* the key is case sensitive ("dbGain" in etc/pocsag_rtlsdr.json:19 is silently ignored) and the
+         * conversion is 10^(dB/10) applied to amplitude taps (multifm/receiver.c:218-220) */
+        if (!FAILED(config_get_float(&channel, &channel_gain_db, "dBGain"))) {
+            channel_gain = pow(10.0, channel_gain_db / 10.0);
+        }
+        if (FAILED(ret = demod_thread_new(&dmt, (unsigned)-1, (int32_t)nb_center_freq - center_freq, (uint32_t)sample_rate,
+                                          fifo_name, decimation_factor, lpf_taps, lpf_nr_taps, signal_debug, channel_gain))) {
+            MFM_MSG(SEV_ERROR, "FAILED-DEMOD-THREAD", "Failed to create demodulator thread, aborting.");
+            break;
+        }
+        list_append(&rx->demod_threads, &dmt->dt_node);
+        rx->nr_demod_threads++;
+        MFM_MSG(SEV_INFO, "CHANNEL", "[%zu]: %4.5f MHz Gain: %f dB -> [%s]%s%s", rx->nr_demod_threads,
+                (double)nb_center_freq / 1e6, channel_gain_db, fifo_name, (NULL != signal_debug ? " DEBUG: " : ""),
+                (NULL != signal_debug ? signal_debug : ""));
+    }
+    demod_thread_bind_engine(NULL);
+    if (FAILED(ret)) {
+        MFM_MSG(SEV_ERROR, "CHANNEL-SETUP-FAILURE", "Error reading array of channels, aborting.");
+        goto done;
+    }
+    if (0 == rx->nr_demod_threads) {
+        MFM_MSG(SEV_ERROR, "MISSING-CHANNELS", "Need to specify at least one channel to demodulate.");
+        ret = A_E_INVAL;
+    }
+
+done:
+    if (NULL != lpf_taps) {
+        TFREE(lpf_taps);
+    }
+    return ret;
+}
+
+static aresult_t _receiver_worker_thread(struct worker_thread *wthr)
+{
+    struct receiver *rx = BL_CONTAINER_OF(wthr, struct receiver, wthr);
+    TSL_BUG_ON(NULL == rx->thread_func);
+    return rx->thread_func(rx);
+}
+
+aresult_t receiver_start(struct receiver *rx)
+{
+    aresult_t ret = A_OK;
+    TSL_ASSERT_ARG(NULL != rx);
+
+    /* the channel set is complete: build the tables and go to the device */
+    if (MFM_OK != mfm_engine_commit(rx->engine)) {
+        MFM_MSG(SEV_ERROR, "ENGINE-COMMIT", "Unable to start the channel engine: %s", mfm_last_error());
+        return A_E_DEVICE;
+    }
+    if (FAILED(ret = worker_thread_new(&rx->drain_thr, _receiver_drain_thread, WORKER_THREAD_CPU_MASK_ANY))) {
+        return ret;
+    }
+    if (FAILED(ret = worker_thread_new(&rx->wthr, _receiver_worker_thread, WORKER_THREAD_CPU_MASK_ANY))) {
+        MFM_MSG(SEV_ERROR, "THREAD-START-FAIL", "Failed to start worker thread, aborting.");
+    }
+    return ret;
+}
+
+aresult_t receiver_cleanup(struct receiver **prx)
+{
+    struct receiver *rx = NULL;
+
+    TSL_ASSERT_ARG(NULL != prx);
+    TSL_ASSERT_ARG(NULL != *prx);
+    rx = *prx;
+
+    /* stop the producer first, then let what it delivered reach the FIFOs */
+    TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->wthr));
+    TSL_BUG_IF_FAILED(worker_thread_delete(&rx->wthr));
+    if (NULL != rx->engine && rx->drain_thr.started) {
+        (void)receiver_drain(rx);
+        TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->drain_thr));
+        TSL_BUG_IF_FAILED(worker_thread_delete(&rx->drain_thr));
+    }
+    TSL_BUG_IF_FAILED(rx->cleanup_func(rx));
+
+    while (rx->demod_threads.next != &rx->demod_threads) {
+        struct demod_thread *cur = BL_CONTAINER_OF(rx->demod_threads.next, struct demod_thread, dt_node);
+        list_del(&cur->dt_node);
+        TSL_BUG_IF_FAILED(demod_thread_delete(&cur));
+    }
+    mfm_engine_destroy(&rx->engine);
+    TSL_BUG_IF_FAILED(frame_alloc_delete(&rx->samp_alloc));
+    *prx = NULL;
+    return A_OK;
+}
+
+aresult_t receiver_set_mute(struct receiver *rx, bool mute)
+{
+    TSL_ASSERT_ARG(NULL != rx);
+    rx->muted = mute;
+    return A_OK;
+}
+
+bool receiver_thread_running(struct receiver *rx)
+{
+    TSL_BUG_ON(NULL == rx);
+    return worker_thread_is_running(&rx->wthr);
+}

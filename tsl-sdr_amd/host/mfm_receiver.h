@@ -1,0 +1,113 @@
+/*
+ * mfm_receiver.h - multifm's receiver / demod_thread / sample_buf interface on top of the MI355X engine.
+ *
+ * Same names, arguments and error behaviour as the reference's
+ *     filter/sample_buf.h:59-104   struct sample_buf, sample_buf_decref()
+ *     multifm/receiver.h:18-124    struct receiver, receiver_init/start/cleanup/set_mute/thread_running,
+ *                                  receiver_sample_buf_alloc/deliver
+ *     multifm/demod.h:104-116      demod_thread_new / demod_thread_delete
+ * so a front end written against them (file_if, rtl_sdr_if, airspy_if, uhd_if) compiles and behaves the
+ * same: allocate a sample_buf from the receiver's pool, fill data_buf with interleaved int16 I,Q, set
+ * nr_samples, deliver.  What differs is behind the interface: a demod_thread is a channel REGISTRATION on
+ * the receiver's mfm_engine (no pthread per channel); deliver() hands the buffer to that one engine
+ * (refcount 1, released as soon as the samples are staged for H2D); one drain thread writes every
+ * channel's PCM to its FIFO.
+ */
+#pragma once
+
+#include "mfm_config.h"
+#include "mfm_tsl.h"
+
+#include "../../include/multifm_hip.h"
+
+/* ---- sample buffers (filter/sample_buf.h) ---- */
+
+enum sample_type {
+    UNKNOWN = 0,
+    REAL_UINT_16 = 1,
+    COMPLEX_UINT_16 = 2,
+    COMPLEX_INT_16 = 3,
+    REAL_UINT_32 = 4,
+    COMPLEX_UINT_32 = 5,
+};
+
+struct sample_buf;
+typedef aresult_t (*sample_buf_release_func_t)(struct sample_buf *buf);
+
+struct sample_buf {
+    uint32_t refcount CAL_ALIGN(16);   /* atomically decremented; buffer is released at 0 */
+    enum sample_type sample_type;
+    uint32_t nr_samples;               /* complex samples in data_buf */
+    uint32_t sample_buf_bytes;
+    uint64_t start_time_ns;
+    sample_buf_release_func_t release;
+    void *priv;
+    uint8_t data_buf[];                /* I,Q,I,Q... int16 */
+};
+
+aresult_t sample_buf_decref(struct sample_buf *buf);
+
+/* ---- channels (multifm/demod.h) ---- */
+
+struct list_entry {
+    struct list_entry *prev, *next;
+};
+
+struct demod_thread {
+    struct list_entry dt_node;
+    int chan_index;          /* channel number inside the receiver's engine */
+    int fifo_fd;             /* PCM sink (demod.c:331) */
+    int debug_signal_fd;     /* filtered-IQ sink or -1 (demod.c:322-328) */
+    size_t total_nr_demod_samples;
+    size_t total_nr_pcm_samples;
+    size_t nr_dropped_samples; /* EPIPE policy of demod.c:93-110 */
+};
+
+/*
+ * demod_thread_new() keeps the reference signature.  core_id is ignored (there is no thread to pin).
+ * The channel is registered on the engine made current with demod_thread_bind_engine(), which
+ * receiver_init() does around its channel loop.
+ */
+aresult_t demod_thread_new(struct demod_thread **pthr, unsigned core_id, int32_t offset_hz, uint32_t samp_hz,
+                           const char *out_fifo, int decimation_factor, const double *lpf_taps, size_t lpf_nr_taps,
+                           const char *fir_debug_output, double channel_gain);
+aresult_t demod_thread_delete(struct demod_thread **pthr);
+void demod_thread_bind_engine(struct mfm_engine *engine);
+
+/* ---- receiver (multifm/receiver.h) ---- */
+
+struct receiver;
+typedef aresult_t (*receiver_cleanup_func_t)(struct receiver *rx);
+typedef aresult_t (*receiver_rx_thread_func_t)(struct receiver *rx);
+
+struct receiver {
+    bool muted;
+    struct list_entry demod_threads;
+    size_t nr_demod_threads;
+    size_t nr_samp_buf_alloc_fails;
+    struct frame_alloc *samp_alloc;
+    struct worker_thread wthr;
+    receiver_cleanup_func_t cleanup_func;
+    receiver_rx_thread_func_t thread_func;
+
+    /* MI355X build */
+    struct mfm_engine *engine;
+    struct worker_thread drain_thr;
+    volatile bool input_done;     /* front end reached end of input */
+    size_t nr_bufs_delivered;
+    size_t nr_blocks_drained;
+};
+
+aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,
+                        receiver_cleanup_func_t cleanup_func, size_t samples_per_buf);
+aresult_t receiver_start(struct receiver *rx);
+aresult_t receiver_cleanup(struct receiver **prx);
+aresult_t receiver_sample_buf_alloc(struct receiver *rx, struct sample_buf **pbuf);
+aresult_t receiver_set_mute(struct receiver *rx, bool mute);
+aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *buf);
+bool receiver_thread_running(struct receiver *rx);
+
+/* additions of this build: a finite input (file) can tell the receiver it is finished, and a driver can
+ * wait until everything delivered so far has reached the FIFOs */
+void receiver_mark_input_done(struct receiver *rx);
+aresult_t receiver_drain(struct receiver *rx);
