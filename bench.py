@@ -11,8 +11,8 @@ synthetic wideband int16 IQ (default 2^26 samples = 256 MiB) for every channel a
           the kernel; each rank demodulates only its own contiguous channel range - no other collective.
 
 Metric (BASELINE.json): input IQ MSamp/s x channels demodulated, whole job.  The JSON line also carries
-the HBM roofline of the dominant kernel (algorithmic bytes / HIP-event kernel time), the integer-VALU
-roofline next to it, and - on rank 0 at N = 1 - the oracle's CPU path timed on the host cores.
+the HBM roofline of the dominant kernel (algorithmic bytes / HIP-event kernel time), the compute roofline of
+the kernel variant in use next to it, and - on rank 0 at N = 1 - the oracle's CPU path timed on the host cores.
 """
 import argparse
 import json
@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_DOT2_PEAK = 256 * 4 * 32 * 2.4e9  # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12
+VALU_DOT2_PEAK = 256 * 4 * 32 * 2.4e9  # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 (v_dot2 measured at half of it)
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8/fp8 MFMA, MI355X_MICROARCH.md (measured 4.1-4.4 POPS)
 
 
 def parse():
@@ -163,6 +164,16 @@ def main():
     bytes_per_launch = block * 4 + len(offs) * outs * 2        # 4 + 2*C_g/D bytes per input sample
     dot2_per_launch = 2.0 * len(offs) * T * outs               # two v_dot2 lane-ops per complex tap per output
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    mfma = st1["kernel_variant"] == 1
+    if mfma:
+        # exact int16 MACs done as four int8 products on the matrix cores: 2 ops x 4 x (4 real MACs per complex tap)
+        ops = 2.0 * 4.0 * 4.0 * len(offs) * T * outs
+        compute_roof = {"bound": "mfma_i8", "achieved": ops / (k_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS,
+                        "unit": "TOP/s", "frac": ops / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}
+    else:
+        compute_roof = {"bound": "v_dot2_i32_i16", "achieved": dot2_per_launch / (k_ms * 1e-3) / 1e12,
+                        "peak": VALU_DOT2_PEAK / 1e12, "unit": "T lane-ops/s",
+                        "frac": dot2_per_launch / (k_ms * 1e-3) / VALU_DOT2_PEAK}
     msamp = args.steps * block / dt / 1e6
 
     if rank == 0:
@@ -181,10 +192,9 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"channel shards x{world} + RCCL broadcast of IQ"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "mfm_channel_kernel", "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
-            "valu_roofline": {"bound": "v_dot2_i32_i16", "achieved": dot2_per_launch / (k_ms * 1e-3) / 1e12,
-                              "peak": VALU_DOT2_PEAK / 1e12, "unit": "T lane-ops/s",
-                              "frac": dot2_per_launch / (k_ms * 1e-3) / VALU_DOT2_PEAK},
+                         "kernel": "mfm_channel_kernel_mfma" if mfma else "mfm_channel_kernel", "kernel_ms": k_ms,
+                         "bytes_per_launch": bytes_per_launch},
+            "compute_roofline": compute_roof,
             "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],
                          "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"]},
         }
