@@ -94,8 +94,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the multifm engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 runs the RCCL path (process group, in-place broadcast into the engine buffer) even
+    # with one rank, so the N>1 plumbing can be exercised on a single-GPU box
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -129,7 +133,7 @@ def main():
 
     def step():
         ptr, cap = eng.acquire_input()
-        if world > 1:
+        if use_dist:
             which = 0 if ptr < bufs[0].data_ptr() + in_bytes and ptr >= bufs[0].data_ptr() else 1
             off = (ptr - bufs[which].data_ptr()) // 2
             view = bufs[which][off: off + 2 * block]
@@ -139,7 +143,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         eng.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,10 +157,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st1 = eng.stats()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if use_dist:
+        dt = pkg.dist.max_over_ranks(dt, device="cuda")
 
     launches = st1["launches"] - st0["launches"]
     k_ms = (st1["kernel_ms"] - st0["kernel_ms"]) / max(1, launches)
@@ -203,7 +205,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -60,6 +60,8 @@ typedef short mfm_s2 __attribute__((ext_vector_type(2)));
     } while (0)
 #endif
 #define MFM_M_NEW 31 /* new outputs per 32-column iteration */
+/* sched_barrier mask: ALU | VALU | SALU | MFMA | DS | DS-read | DS-write may cross, vector memory may not */
+#define MFM_SCHED_ALL_BUT_VMEM 0x38F
 #define MFM_M_ITERS 2 /* iterations per tile: a tile is 62 new outputs */
 #define MFM_M_CH 4    /* 16-byte staging chunks a thread owns per tile (>= ceil(samples/4/512)) */
 
@@ -138,12 +140,12 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     auto stage_load = [&](uint32_t tile, int j) -> uint4 {
         /* 4 samples of tile `tile`.  No bounds masking is needed, only a readable address: samples before
          * the stream start feed nothing but column 0 of tile 0 (replaced by the carried sample), samples
-         * past n_avail feed only columns >= n_new (never stored) or zero-padded taps. */
-        const uint32_t q = tid + (uint32_t)j * MFM_M_NT;
-        int64_t gs = ((int64_t)tile * L.ot - 1) * (int64_t)D + (int64_t)q * 4;
+         * past n_avail feed only columns >= n_new (never stored) or zero-padded taps.  Sample indices fit
+         * 31 bits (the engine caps a block at 2^30 samples). */
+        int gs = (int)(tile * L.ot * D) + (4 * (int)(tid + (uint32_t)j * MFM_M_NT) - (int)D);
         gs = gs < 0 ? 0 : gs;
-        gs = gs > (int64_t)L.x_last4 ? (int64_t)L.x_last4 : gs;
-        return *reinterpret_cast<const uint4 *>(L.x + gs);
+        gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
+        return *reinterpret_cast<const uint4 *>(L.x + (uint32_t)gs);
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
         if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
@@ -265,28 +267,31 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
 #pragma unroll
         for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
-            /* this iteration's share of the next tile's input: loads in flight across the matrix work */
-            uint4 pre[MFM_M_CH / MFM_M_ITERS];
-            if (have_n) {
+            /* Vector-memory order matters (vmcnt is one in-order counter): first the rotator entries of
+             * this iteration's columns (L2 hits, needed right after the matrix work; their addresses do not
+             * depend on data), then this iteration's share of the next tile's input (HBM, needed only at
+             * the end of the iteration) - waiting for the former then leaves the latter in flight.  The
+             * barrier pins VMEM order only; everything else may still be scheduled across it. */
+            const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
+            uint2 rv[2][2];
 #pragma unroll
-                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
-                    pre[u] = stage_load(tile_n, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
-                }
+            for (int c = 0; c < 2; c++) {
+                rv[0][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c]);
+                rv[1][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c] + 16u * 8u);
+            }
+            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
+            /* unconditional (a workgroup's last tile re-reads its own samples and discards them): a load
+             * under a run-time condition cannot be counted, and the wait for the rotator entries above
+             * would degrade to vmcnt(0) */
+            uint4 pre[MFM_M_CH / MFM_M_ITERS];
+#pragma unroll
+            for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
+                pre[u] = stage_load(have_n ? tile_n : tile, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
             }
 
             uint32_t q[2][2];
             int pcm[2][2];
             if (rb_valid) {
-                /* rotator entries of this iteration's columns (two groups x two channels): addresses do
-                 * not depend on data, so the loads are issued ahead of the matrix work */
-                const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
-                uint2 rv[2][2];
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    rv[0][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c]);
-                    rv[1][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c] + 16u * 8u);
-                }
-
                 /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
                 mfm_v4i hh[2], md[2], ll[2];
 #pragma unroll
@@ -367,6 +372,19 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                         pcm[gq][c] = mfm_discriminate(s_re, s_im, lut);
                     }
                 }
+            }
+
+            /* the prefetched samples go to the other staging buffer before this iteration's PCM stores are
+             * issued, so the wait for them does not also wait for those stores */
+            if (have_n) {
+#pragma unroll
+                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
+                    stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
+
+            if (rb_valid) {
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) {
                     const int rel = rel_first + (int)(it * MFM_M_NEW + 16u * gq + n);
@@ -389,13 +407,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     }
                 }
                 MFM_STAMP(7);
-            }
-
-            if (have_n) {
-#pragma unroll
-                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
-                    stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
-                }
             }
         }
 
