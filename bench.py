@@ -178,6 +178,13 @@ def main():
                         "frac": dot2_per_launch / (k_ms * 1e-3) / VALU_DOT2_PEAK}
     msamp = args.steps * block / dt / 1e6
 
+    # HBM bytes per launch from the committed PMC passes (profiles/): only quoted for the exact workload they
+    # were collected on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if mfma and world == 1 and args.block_log2 == 26 and cpg == 64 and args.config == "cfg2_64ch" and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+
     if rank == 0:
         line = {
             "metric": "input IQ MSamp/s x channels demodulated",
@@ -193,7 +200,7 @@ def main():
                        "input_msamp_per_s": msamp,
                        "parallelism": "1 GPU" if world == 1 else f"channel shards x{world} + RCCL broadcast of IQ"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "mfm_channel_kernel_mfma" if mfma else "mfm_channel_kernel", "kernel_ms": k_ms,
                          "bytes_per_launch": bytes_per_launch},
             "compute_roofline": compute_roof,
