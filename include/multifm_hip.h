@@ -165,6 +165,53 @@ const char *mfm_strerror(int err);
 const char *mfm_last_error(void); /* thread-local detail of the last failure */
 
 /*
+ * ---- PCM stage behind the FIFO -------------------------------------------
+ * The decoder / resampler processes read a channel's PCM FIFO and run it through a real-valued rational
+ * resampler and an optional DC blocker before the protocol decoders (decoder/decoder.c:580-673):
+ *
+ *   polyphase_fir_new(&fir, nr_coeffs, q14_coeffs, interpolate, decimate)   filter/polyphase_fir.c:47-105
+ *   polyphase_fir_push_sample_buf / polyphase_fir_process                    filter/polyphase_fir.c:162-233
+ *   dc_blocker_init(pole) / dc_blocker_apply                                 filter/dc_blocker.h:45-93
+ *
+ * mfm_resampler does that for ALL channels of an engine at once, on PCM that is still in HBM (the output
+ * of mfm_engine_submit) or handed in from the host.  Same arithmetic, bit for bit: int16 x int16 -> wrapping
+ * int32 dot product of one phase filter with consecutive samples, Q14 rounding, phase walk
+ * phase += D; consumed = phase / I; phase %= I, an output only while MORE than one phase length of
+ * unconsumed samples exists (polyphase_fir.c:184).
+ */
+struct mfm_resampler; /* opaque */
+
+struct mfm_resampler_config {
+    uint32_t abi_version;    /* MFM_ABI_VERSION */
+    int32_t device;
+    uint32_t nr_channels;
+    uint32_t interpolate;    /* I */
+    uint32_t decimate;       /* D */
+    uint32_t max_in_samples; /* most PCM samples per channel one process call may carry */
+    uint32_t invert;         /* decoder -i: negate the input samples (decoder.c:621-626) */
+    uint32_t dc_block;       /* decoder -b */
+    double dc_pole;          /* decoder -p, only with dc_block */
+};
+
+/* coeffs are the Q14 int16 taps (decoder.c:530-533 quantises lpfCoeffs with (int16_t)(c * 16384)) */
+int mfm_resampler_create(struct mfm_resampler **pr, const struct mfm_resampler_config *cfg, const int16_t *coeffs,
+                         size_t nr_coeffs);
+void mfm_resampler_destroy(struct mfm_resampler **pr);
+/* Upper bound of outputs per channel one process call can produce. */
+size_t mfm_resampler_max_out(const struct mfm_resampler *r);
+/*
+ * Consume nr_in PCM samples per channel from device memory laid out [channel][in_stride] (for instance the
+ * pointer/stride of mfm_engine_last_output_device) and produce *nr_out resampled samples per channel at
+ * *d_out, laid out [channel][*out_stride], valid until the next call.  Work is queued on `stream` (a
+ * hipStream_t, NULL = legacy default stream); no host synchronisation.
+ */
+int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, size_t in_stride, size_t nr_in,
+                                 void *stream, int16_t **d_out, size_t *out_stride, size_t *nr_out);
+/* Host convenience (tests, harnesses): same, host in / host out, synchronous; out is [channel][out_stride]. */
+int mfm_resampler_process_host(struct mfm_resampler *r, const int16_t *pcm, size_t in_stride, size_t nr_in,
+                               int16_t *out, size_t out_stride, size_t *nr_out);
+
+/*
  * Host twins of the kernel's scalar numerics (compiled from the same header the kernel uses).
  * They exist so the test-suite can check, on the CPU, that the device formulas reproduce the
  * reference's expressions bit for bit; they are not a compute path.

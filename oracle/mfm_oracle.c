@@ -505,3 +505,106 @@ size_t mfmo_twoslot_run(const int16_t *iq, size_t buf_samples, size_t nr_bufs, c
     free(bufs);
     return n_out;
 }
+
+/* ------------------------------------------------------------------------------------- */
+/* PCM stage: rational resampler + DC blocker                                            */
+/* ------------------------------------------------------------------------------------- */
+
+struct mfmo_resampler {
+    int16_t *phase; /* [interp][plen] */
+    size_t plen;
+    unsigned interp, decim;
+    size_t phase_id;  /* filter/polyphase_fir_priv.h: last_phase */
+    int16_t *pend;    /* unconsumed samples */
+    size_t pend_n, pend_cap;
+};
+
+struct mfmo_resampler *mfmo_resampler_new(const int16_t *coeffs, size_t nr_coeffs, unsigned interpolate,
+                                          unsigned decimate)
+{
+    if (!coeffs || !nr_coeffs || !interpolate || !decimate) {
+        return NULL;
+    }
+    struct mfmo_resampler *r = calloc(1, sizeof(*r));
+    /* filter/polyphase_fir.c:70-76 */
+    size_t plen = (nr_coeffs + interpolate - 1) / interpolate;
+    plen = (plen + 3) & ~(size_t)3;
+    r->plen = plen;
+    r->interp = interpolate;
+    r->decim = decimate;
+    r->phase = calloc((size_t)interpolate * plen, sizeof(int16_t));
+    for (size_t i = 0; i < nr_coeffs; i++) {
+        r->phase[(i % interpolate) * plen + (i / interpolate)] = coeffs[i]; /* :81-83 */
+    }
+    return r;
+}
+
+void mfmo_resampler_free(struct mfmo_resampler *r)
+{
+    if (r) {
+        free(r->phase);
+        free(r->pend);
+        free(r);
+    }
+}
+
+size_t mfmo_resampler_phase_len(const struct mfmo_resampler *r)
+{
+    return r->plen;
+}
+
+size_t mfmo_resampler_feed(struct mfmo_resampler *r, const int16_t *pcm, size_t nr_samples, int16_t *out,
+                           size_t max_out)
+{
+    size_t need = r->pend_n + nr_samples;
+    if (need > r->pend_cap) {
+        r->pend_cap = need + r->plen + 16;
+        r->pend = realloc(r->pend, r->pend_cap * sizeof(int16_t));
+    }
+    memcpy(r->pend + r->pend_n, pcm, nr_samples * sizeof(int16_t));
+    const size_t tot = need;
+    size_t pos = 0, n_out = 0;
+    /* filter/polyphase_fir.c:184: strictly more than one phase length of unconsumed samples */
+    while (tot - pos > r->plen && n_out < max_out) {
+        const int16_t *c = r->phase + r->phase_id * r->plen;
+        uint32_t acc = 0;
+        for (size_t k = 0; k < r->plen; k++) { /* filter/utils.c:94-103 */
+            acc += (uint32_t)((int32_t)r->pend[pos + k] * (int32_t)c[k]);
+        }
+        out[n_out++] = mfmo_r14((int32_t)acc); /* utils.c:112 */
+        r->phase_id += r->decim;               /* polyphase_fir.c:206-211 */
+        pos += r->phase_id / r->interp;
+        r->phase_id %= r->interp;
+        if (pos > tot) {
+            fprintf(stderr, "mfm_oracle: resampler stepped past the end (decimate/interpolate > phase length)\n");
+            abort();
+        }
+    }
+    memmove(r->pend, r->pend + pos, (tot - pos) * sizeof(int16_t));
+    r->pend_n = tot - pos;
+    return n_out;
+}
+
+void mfmo_dc_blocker_init(struct mfmo_dc_blocker *b, double pole)
+{
+    memset(b, 0, sizeof(*b));
+    b->p = (int16_t)((1.0 - pole) * (double)(1 << MFMO_Q_SHIFT)); /* filter/dc_blocker.h:56 */
+}
+
+void mfmo_dc_blocker_apply(struct mfmo_dc_blocker *b, int16_t *samples, size_t nr_samples)
+{
+    for (size_t i = 0; i < nr_samples; i++) { /* filter/dc_blocker.h:80-90, int32 wrap-around */
+        b->acc = (int32_t)((uint32_t)b->acc - (uint32_t)b->x_n_1);
+        b->x_n_1 = (int32_t)((uint32_t)(int32_t)samples[i] << MFMO_Q_SHIFT);
+        b->acc = (int32_t)((uint32_t)b->acc + (uint32_t)b->x_n_1 - (uint32_t)((int32_t)b->p * b->y_n_1));
+        b->y_n_1 = b->acc >> MFMO_Q_SHIFT;
+        samples[i] = (int16_t)b->y_n_1;
+    }
+}
+
+void mfmo_resampler_quantize_taps(const double *taps, size_t n, int16_t *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        out[i] = (int16_t)(taps[i] * (double)(1 << MFMO_Q_SHIFT)); /* decoder/decoder.c:530-533 */
+    }
+}

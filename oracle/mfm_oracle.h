@@ -120,6 +120,40 @@ size_t mfmo_twoslot_run(const int16_t *iq, size_t buf_samples, size_t nr_bufs, c
                         const int16_t *coeff_im, size_t nr_taps, unsigned decimation, int16_t incr_re,
                         int16_t incr_im, int16_t *pcm_out, int16_t *iq_out, size_t max_out);
 
+/* ---- PCM stage behind the FIFO: rational resampler + DC blocker ---------- */
+
+struct mfmo_resampler;
+
+/*
+ * filter/polyphase_fir.c:47-105: taps (Q14 int16, decoder/decoder.c:530-533) scattered into `interpolate`
+ * phase filters, tap i -> phase i % I, slot i / I, phase length rounded up to a multiple of 4 (zero filled).
+ */
+struct mfmo_resampler *mfmo_resampler_new(const int16_t *coeffs, size_t nr_coeffs, unsigned interpolate,
+                                          unsigned decimate);
+void mfmo_resampler_free(struct mfmo_resampler *r);
+size_t mfmo_resampler_phase_len(const struct mfmo_resampler *r);
+
+/*
+ * Feed real int16 PCM (any chunking), append up to max_out outputs.  Stream semantics of
+ * polyphase_fir_process (filter/polyphase_fir.c:162-233) + dot_product_sample_buffers_real
+ * (filter/utils.c:46-116): output m = r14(sum_k phase[p_m][k] * x[pos_m + k]), int32 wrap; then
+ * p += D, pos += p / I, p %= I (:206-211).  An output is produced only while MORE than phase_len
+ * unconsumed samples exist (the strict '>' at :184).  Returns outputs produced.
+ */
+size_t mfmo_resampler_feed(struct mfmo_resampler *r, const int16_t *pcm, size_t nr_samples, int16_t *out,
+                           size_t max_out);
+
+/* filter/dc_blocker.h:45-93: differentiator + leaky integrator, sequential, in place. */
+struct mfmo_dc_blocker {
+    int16_t p;
+    int32_t x_n_1, y_n_1, acc;
+};
+void mfmo_dc_blocker_init(struct mfmo_dc_blocker *b, double pole);
+void mfmo_dc_blocker_apply(struct mfmo_dc_blocker *b, int16_t *samples, size_t nr_samples);
+
+/* decoder/decoder.c:530-533: double taps -> Q14 int16 by truncation */
+void mfmo_resampler_quantize_taps(const double *taps, size_t n, int16_t *out);
+
 #ifdef __cplusplus
 }
 #endif

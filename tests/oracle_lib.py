@@ -59,6 +59,20 @@ def lib():
         o.mfmo_twoslot_run.argtypes = [_i16p, C.c_size_t, C.c_size_t, _i16p, _i16p, C.c_size_t, C.c_uint, C.c_int16,
                                        C.c_int16, _i16p, _i16p, C.c_size_t]
         o.mfmo_twoslot_run.restype = C.c_size_t
+        o.mfmo_resampler_new.argtypes = [_i16p, C.c_size_t, C.c_uint, C.c_uint]
+        o.mfmo_resampler_new.restype = C.c_void_p
+        o.mfmo_resampler_free.argtypes = [C.c_void_p]
+        o.mfmo_resampler_free.restype = None
+        o.mfmo_resampler_phase_len.argtypes = [C.c_void_p]
+        o.mfmo_resampler_phase_len.restype = C.c_size_t
+        o.mfmo_resampler_feed.argtypes = [C.c_void_p, _i16p, C.c_size_t, _i16p, C.c_size_t]
+        o.mfmo_resampler_feed.restype = C.c_size_t
+        o.mfmo_dc_blocker_init.argtypes = [C.c_void_p, C.c_double]
+        o.mfmo_dc_blocker_init.restype = None
+        o.mfmo_dc_blocker_apply.argtypes = [C.c_void_p, _i16p, C.c_size_t]
+        o.mfmo_dc_blocker_apply.restype = None
+        o.mfmo_resampler_quantize_taps.argtypes = [C.POINTER(C.c_double), C.c_size_t, _i16p]
+        o.mfmo_resampler_quantize_taps.restype = None
         _lib = o
     return _lib
 
@@ -164,3 +178,47 @@ def twoslot_run(iq, buf_samples, cre, cim, decimation, incr):
     n = lib().mfmo_twoslot_run(p16(iq), buf_samples, nb, p16(cre), p16(cim), cre.size, decimation, int(incr[0]),
                                int(incr[1]), p16(pcm), p16(q), cap)
     return pcm[:n], q[:n]
+
+
+class Resampler:
+    """Oracle rational resampler (one channel), optional DC blocker and input inversion, arbitrary chunking."""
+
+    def __init__(self, coeffs_q14, interpolate, decimate, dc_pole=None, invert=False):
+        self.co = np.ascontiguousarray(coeffs_q14, dtype=np.int16)
+        self.h = lib().mfmo_resampler_new(p16(self.co), self.co.size, interpolate, decimate)
+        assert self.h
+        self.interp, self.decim, self.invert = interpolate, decimate, invert
+        self.dc = None
+        if dc_pole is not None:
+            self.dc = (C.c_int32 * 4)()
+            lib().mfmo_dc_blocker_init(self.dc, float(dc_pole))
+
+    def phase_len(self):
+        return lib().mfmo_resampler_phase_len(self.h)
+
+    def feed(self, pcm):
+        x = np.ascontiguousarray(pcm, dtype=np.int16).copy()
+        if self.invert:
+            x = (-x.astype(np.int32)).astype(np.int16)  # decoder.c:624 on int16 storage
+        cap = x.size * self.interp // self.decim + 8
+        out = np.zeros(cap, np.int16)
+        n = lib().mfmo_resampler_feed(self.h, p16(x), x.size, p16(out), cap)
+        out = out[:n].copy()
+        if self.dc is not None and n:
+            lib().mfmo_dc_blocker_apply(self.dc, p16(out), n)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().mfmo_resampler_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def quantize_taps(taps):
+    t = np.ascontiguousarray(taps, dtype=np.float64)
+    out = np.zeros(t.size, np.int16)
+    lib().mfmo_resampler_quantize_taps(t.ctypes.data_as(C.POINTER(C.c_double)), t.size, p16(out))
+    return out

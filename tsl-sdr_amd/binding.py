@@ -25,6 +25,8 @@ ABI_SYMBOLS = [
     "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
     "mfm_engine_stream", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
+    "mfm_resampler_create", "mfm_resampler_destroy", "mfm_resampler_max_out", "mfm_resampler_process_device",
+    "mfm_resampler_process_host",
 ]
 
 
@@ -51,6 +53,12 @@ class Stats(C.Structure):
                 ("outputs_per_tile", C.c_uint32), ("lds_bytes", C.c_uint32), ("grid_last", C.c_uint32),
                 ("tail_samples", C.c_uint32), ("rot_table_entries", C.c_uint64),
                 ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32)]
+
+
+class ResamplerConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("nr_channels", C.c_uint32),
+                ("interpolate", C.c_uint32), ("decimate", C.c_uint32), ("max_in_samples", C.c_uint32),
+                ("invert", C.c_uint32), ("dc_block", C.c_uint32), ("dc_pole", C.c_double)]
 
 
 _lib = None
@@ -101,6 +109,14 @@ def load_library():
     lib.mfm_hosttwin_atan_table.argtypes = [C.POINTER(C.c_float)]
     lib.mfm_hosttwin_atan_table.restype = None
     lib.mfm_hosttwin_atan_table_ok.restype = C.c_int
+    lib.mfm_resampler_create.argtypes = [C.POINTER(vp), C.POINTER(ResamplerConfig), i16p, C.c_size_t]
+    lib.mfm_resampler_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_resampler_destroy.restype = None
+    lib.mfm_resampler_max_out.argtypes = [vp]
+    lib.mfm_resampler_max_out.restype = C.c_size_t
+    lib.mfm_resampler_process_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.POINTER(vp),
+                                                 C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.mfm_resampler_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t, i16p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = lib
     return lib
 
@@ -260,3 +276,52 @@ class Engine:
     @property
     def stream(self):
         return self.lib.mfm_engine_stream(self.h)
+
+
+class Resampler:
+    """mfm_resampler: rational resampler (+ optional DC blocker) for all channels of a PCM block."""
+
+    def __init__(self, nr_channels, coeffs_q14, interpolate, decimate, max_in_samples, device=0, invert=False,
+                 dc_pole=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = ResamplerConfig(MFM_ABI_VERSION, device, nr_channels, interpolate, decimate, max_in_samples,
+                              int(invert), int(dc_pole is not None), float(dc_pole or 0.0))
+        co = np.ascontiguousarray(coeffs_q14, dtype=np.int16)
+        rc = self.lib.mfm_resampler_create(C.byref(self.h), C.byref(cfg), _i16p(co), co.size)
+        if rc < 0:
+            raise MfmError(rc, "mfm_resampler_create", self.lib.mfm_strerror(rc).decode())
+        self.nr_channels = nr_channels
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_resampler_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def max_out(self):
+        return self.lib.mfm_resampler_max_out(self.h)
+
+    def process_host(self, pcm):
+        """pcm: int16 [C][n] -> int16 [C][m]"""
+        a = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.nr_channels, -1)
+        cap = self.max_out()
+        out = np.zeros((self.nr_channels, cap), np.int16)
+        n = C.c_size_t()
+        rc = self.lib.mfm_resampler_process_host(self.h, _i16p(a), a.shape[1], a.shape[1], _i16p(out), cap, C.byref(n))
+        if rc < 0:
+            raise MfmError(rc, "mfm_resampler_process_host", self.lib.mfm_strerror(rc).decode())
+        return out[:, :n.value].copy()
+
+    def process_device(self, d_pcm, in_stride, nr_in, stream=None):
+        p, st, n = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        rc = self.lib.mfm_resampler_process_device(self.h, C.c_void_p(d_pcm), in_stride, nr_in, C.c_void_p(stream or 0),
+                                                   C.byref(p), C.byref(st), C.byref(n))
+        if rc < 0:
+            raise MfmError(rc, "mfm_resampler_process_device", self.lib.mfm_strerror(rc).decode())
+        return p.value, st.value, n.value
