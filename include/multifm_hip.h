@@ -212,6 +212,75 @@ int mfm_resampler_process_host(struct mfm_resampler *r, const int16_t *pcm, size
                                int16_t *out, size_t out_stride, size_t *nr_out);
 
 /*
+ * ---- Pager stage: POCSAG slicer / sync / batch collection + BCH(31,21) -----
+ * Replaces, for ALL channels at once and on PCM that is still in HBM (38 400 Hz, i.e. the resampler's output):
+ *
+ *   pager_pocsag_on_pcm            pager/pager_pocsag.c:434-543   state machine SEARCH -> SYNCHRONIZED ->
+ *                                                                  BATCH_RECEIVE -> SEARCH_SYNCWORD
+ *   _pager_pocsag_baud_on_sample   pager/pager_pocsag.c:81-117    three eye detectors (75 / 32 / 16 samples/bit)
+ *   bch_code_decode                pager/bch_code.c:307-398       on the 16 words of every batch (:332-334)
+ *
+ * Output is an event list per channel (sync found, batch of 16 raw + corrected words with the BCH verdicts, sync
+ * kept / lost) - everything _pager_pocsag_process_batch (:319-432) needs to assemble pages.  That last step is
+ * a byte-serial walk over at most 16 words per batch and stays on the host (tsl-sdr_amd/host/mfm_pager_pocsag.c,
+ * same callback signatures as pager/pager_pocsag.h:29-46).
+ *
+ * Conventions kept: bit = (sample < 0); sync = popcount(word ^ 0x7cd215d8) <= 4; eye open when more than
+ * samples_per_bit/2 consecutive matches, sampling offset = matches/2; batch words filled LSB first; the word is
+ * masked with 0x7fffffff before BCH; a word that fails BCH ends the batch for the message layer (nr_ok).
+ */
+#define MFM_POCSAG_EV_SYNC_FOUND 1u
+#define MFM_POCSAG_EV_BATCH      2u
+#define MFM_POCSAG_EV_SYNC_LOST  3u
+#define MFM_POCSAG_EV_SYNC_KEPT  4u
+
+struct mfm_pocsag_event {
+    uint32_t type;          /* MFM_POCSAG_EV_* */
+    uint32_t baud;          /* 512 / 1200 / 2400 */
+    uint32_t channel;
+    uint32_t aux;           /* SYNC_FOUND: eye matches; SYNC_LOST / SYNC_KEPT: the 32 bits seen in the sync slot */
+    uint64_t sample;        /* index (per channel, since creation) of the PCM sample that completed the event */
+    uint32_t nr_ok;         /* BATCH: words accepted before the first BCH failure (16 = whole batch) */
+    uint32_t fail_mask;     /* BATCH: bit z set when word z is uncorrectable */
+    uint32_t raw[16];       /* BATCH: words as collected */
+    uint32_t corrected[16]; /* BATCH: (raw & 0x7fffffff) after BCH correction */
+};
+
+struct mfm_pocsag; /* opaque */
+
+struct mfm_pocsag_config {
+    uint32_t abi_version;    /* MFM_ABI_VERSION */
+    int32_t device;
+    uint32_t nr_channels;
+    uint32_t max_in_samples; /* most PCM samples per channel one process call may carry */
+    uint32_t max_events;     /* per channel and call; 0 = max_in_samples / 2048 + 16 (cannot overflow) */
+    uint32_t flags;          /* 0 */
+};
+
+int mfm_pocsag_create(struct mfm_pocsag **pp, const struct mfm_pocsag_config *cfg);
+void mfm_pocsag_destroy(struct mfm_pocsag **pp);
+/*
+ * Consume nr_in PCM samples per channel, laid out [channel][in_stride] in device memory (for instance the
+ * output of mfm_resampler_process_device).  Work is queued on `stream`; no host synchronisation.  The events of
+ * THIS call replace those of the previous one.
+ */
+int mfm_pocsag_process_device(struct mfm_pocsag *p, const int16_t *d_pcm, size_t in_stride, size_t nr_in,
+                              void *stream);
+/* Host convenience: same from host memory, synchronous. */
+int mfm_pocsag_process_host(struct mfm_pocsag *p, const int16_t *pcm, size_t in_stride, size_t nr_in);
+/*
+ * Wait for the last process call and copy its events: channels ascending, stream order within a channel.
+ * MFM_E_NOMEM when `max_events` is too small (nothing copied, *nr_events = needed), MFM_E_STATE when a channel
+ * overflowed its device-side event list (only possible with a caller-chosen max_events).
+ */
+int mfm_pocsag_fetch_events(struct mfm_pocsag *p, struct mfm_pocsag_event *out, size_t max_events,
+                            size_t *nr_events);
+
+/* bch_code_decode (pager/bch_code.c:307-398) on n words in place; rc[i] = its return value (0 or 1). */
+int mfm_bch3121_decode_device(uint32_t *d_words, uint8_t *d_rc, size_t n, int device, void *stream);
+int mfm_bch3121_decode_host(uint32_t *words, uint8_t *rc, size_t n, int device);
+
+/*
  * Host twins of the kernel's scalar numerics (compiled from the same header the kernel uses).
  * They exist so the test-suite can check, on the CPU, that the device formulas reproduce the
  * reference's expressions bit for bit; they are not a compute path.
@@ -223,6 +292,8 @@ int16_t mfm_hosttwin_r14(int32_t a);
 void mfm_hosttwin_pcm_range(uint32_t first_bits, uint32_t count, int16_t *out);
 void mfm_hosttwin_atan_table(float tbl[257]);
 int mfm_hosttwin_atan_table_ok(void); /* 1 if the generated table matches the pinned hash */
+/* the device's table-driven BCH(31,21) decode (syndrome bytes -> 1024-entry flip table), on the host */
+int mfm_hosttwin_bch3121_decode(uint32_t *word);
 
 #ifdef __cplusplus
 }

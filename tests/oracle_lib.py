@@ -73,6 +73,22 @@ def lib():
         o.mfmo_dc_blocker_apply.restype = None
         o.mfmo_resampler_quantize_taps.argtypes = [C.POINTER(C.c_double), C.c_size_t, _i16p]
         o.mfmo_resampler_quantize_taps.restype = None
+        u32p = C.POINTER(C.c_uint32)
+        o.mfmo_bch_tables.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        o.mfmo_bch_tables.restype = None
+        o.mfmo_bch3121_decode.argtypes = [u32p]
+        o.mfmo_bch3121_decode_batch.argtypes = [u32p, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint]
+        o.mfmo_bch3121_decode_batch.restype = None
+        o.mfmo_pocsag_new.restype = C.c_void_p
+        o.mfmo_pocsag_free.argtypes = [C.c_void_p]
+        o.mfmo_pocsag_free.restype = None
+        o.mfmo_pocsag_on_pcm.argtypes = [C.c_void_p, _i16p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        o.mfmo_pocsag_msgdec_new.restype = C.c_void_p
+        o.mfmo_pocsag_msgdec_free.argtypes = [C.c_void_p]
+        o.mfmo_pocsag_msgdec_free.restype = None
+        o.mfmo_pocsag_msgdec_batch.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
+                                               C.POINTER(C.c_size_t)]
         _lib = o
     return _lib
 
@@ -222,3 +238,99 @@ def quantize_taps(taps):
     out = np.zeros(t.size, np.int16)
     lib().mfmo_resampler_quantize_taps(t.ctypes.data_as(C.POINTER(C.c_double)), t.size, p16(out))
     return out
+
+
+# ---- BCH(31,21) and POCSAG (oracle/pocsag_oracle.c) --------------------------------------------------------
+
+# struct mfmo_pocsag_event / struct mfmo_pocsag_msg
+POCSAG_EVENT_DTYPE = np.dtype([("type", "<u4"), ("baud", "<u4"), ("sample", "<u8"), ("aux", "<u4"), ("nr_ok", "<u4"),
+                               ("fail_mask", "<u4"), ("pad", "<u4"), ("raw", "<u4", (16,)), ("corrected", "<u4", (16,))])
+POCSAG_MSG_DTYPE = np.dtype([("type", "<u4"), ("baud", "<u4"), ("capcode", "<u4"), ("function", "<u4"), ("len", "<u4"),
+                             ("pad", "<u4"), ("sample", "<u8"), ("text", "S512")])
+EV_SYNC_FOUND, EV_BATCH, EV_SYNC_LOST, EV_SYNC_KEPT = 1, 2, 3, 4
+
+
+def bch_tables():
+    a, i = (C.c_int * 32)(), (C.c_int * 32)()
+    lib().mfmo_bch_tables(a, i)
+    return list(a)[:31], list(i)
+
+
+def bch3121_decode(word):
+    v = C.c_uint32(int(word))
+    rc = lib().mfmo_bch3121_decode(C.byref(v))
+    return rc, v.value
+
+
+def bch3121_decode_batch(words, threads=1):
+    w = np.ascontiguousarray(words, dtype=np.uint32).copy()
+    rc = np.zeros(w.size, np.uint8)
+    lib().mfmo_bch3121_decode_batch(w.ctypes.data_as(C.POINTER(C.c_uint32)), rc.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    w.size, threads)
+    return w, rc
+
+
+def _msg_tuple(m):
+    n = int(m["len"])
+    raw = bytes(m["text"]).ljust(512, b"\0")[:min(n, 511)]  # numpy 'S' strips trailing NULs; put them back
+    return int(m["type"]), int(m["baud"]), int(m["capcode"]), int(m["function"]), raw, int(m["sample"])
+
+
+class Pocsag:
+    """Oracle POCSAG decoder for one channel: feed(pcm) -> (events, messages) of that call."""
+
+    def __init__(self):
+        self.h = lib().mfmo_pocsag_new()
+        assert self.h
+
+    def feed(self, pcm):
+        x = np.ascontiguousarray(pcm, dtype=np.int16)
+        cap = x.size // 512 + 16
+        ev = np.zeros(cap, POCSAG_EVENT_DTYPE)
+        ms = np.zeros(cap, POCSAG_MSG_DTYPE)
+        nev, nms = C.c_size_t(0), C.c_size_t(0)
+        if x.size:
+            lib().mfmo_pocsag_on_pcm(self.h, p16(x), x.size, ev.ctypes.data, cap, C.byref(nev), ms.ctypes.data, cap,
+                                     C.byref(nms))
+        assert nev.value <= cap and nms.value <= cap
+        return ev[:nev.value].copy(), [_msg_tuple(m) for m in ms[:nms.value]]
+
+    def close(self):
+        if self.h:
+            lib().mfmo_pocsag_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class PocsagMsgDec:
+    """Oracle message layer alone (_process_batch + deliver), driven by batches collected elsewhere."""
+
+    def __init__(self):
+        self.h = lib().mfmo_pocsag_msgdec_new()
+        assert self.h
+
+    def _call(self, words, flush, baud, sample):
+        ms = np.zeros(40, POCSAG_MSG_DTYPE)
+        n = C.c_size_t(0)
+        wp = None
+        if words is not None:
+            w = np.ascontiguousarray(words, dtype=np.uint32)
+            wp = w.ctypes.data_as(C.POINTER(C.c_uint32))
+        r = lib().mfmo_pocsag_msgdec_batch(self.h, wp, flush, baud, sample, ms.ctypes.data, 40, C.byref(n))
+        return r, [_msg_tuple(m) for m in ms[:n.value]]
+
+    def batch(self, words, baud, sample):
+        return self._call(words, 0, baud, sample)
+
+    def flush(self, baud, sample):
+        return self._call(None, 1, baud, sample)[1]
+
+    def close(self):
+        if self.h:
+            lib().mfmo_pocsag_msgdec_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

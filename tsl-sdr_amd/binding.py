@@ -27,7 +27,11 @@ ABI_SYMBOLS = [
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
     "mfm_resampler_create", "mfm_resampler_destroy", "mfm_resampler_max_out", "mfm_resampler_process_device",
     "mfm_resampler_process_host",
+    "mfm_pocsag_create", "mfm_pocsag_destroy", "mfm_pocsag_process_device", "mfm_pocsag_process_host",
+    "mfm_pocsag_fetch_events", "mfm_bch3121_decode_device", "mfm_bch3121_decode_host", "mfm_hosttwin_bch3121_decode",
 ]
+
+MFM_POCSAG_EV_SYNC_FOUND, MFM_POCSAG_EV_BATCH, MFM_POCSAG_EV_SYNC_LOST, MFM_POCSAG_EV_SYNC_KEPT = 1, 2, 3, 4
 
 
 class MfmError(RuntimeError):
@@ -53,6 +57,22 @@ class Stats(C.Structure):
                 ("outputs_per_tile", C.c_uint32), ("lds_bytes", C.c_uint32), ("grid_last", C.c_uint32),
                 ("tail_samples", C.c_uint32), ("rot_table_entries", C.c_uint64),
                 ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32)]
+
+
+class PocsagConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("nr_channels", C.c_uint32),
+                ("max_in_samples", C.c_uint32), ("max_events", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class PocsagEvent(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("baud", C.c_uint32), ("channel", C.c_uint32), ("aux", C.c_uint32),
+                ("sample", C.c_uint64), ("nr_ok", C.c_uint32), ("fail_mask", C.c_uint32),
+                ("raw", C.c_uint32 * 16), ("corrected", C.c_uint32 * 16)]
+
+
+# numpy view of struct mfm_pocsag_event (160 bytes)
+POCSAG_EVENT_DTYPE = np.dtype([("type", "<u4"), ("baud", "<u4"), ("channel", "<u4"), ("aux", "<u4"), ("sample", "<u8"),
+                               ("nr_ok", "<u4"), ("fail_mask", "<u4"), ("raw", "<u4", (16,)), ("corrected", "<u4", (16,))])
 
 
 class ResamplerConfig(C.Structure):
@@ -109,6 +129,16 @@ def load_library():
     lib.mfm_hosttwin_atan_table.argtypes = [C.POINTER(C.c_float)]
     lib.mfm_hosttwin_atan_table.restype = None
     lib.mfm_hosttwin_atan_table_ok.restype = C.c_int
+    u32p = C.POINTER(C.c_uint32)
+    lib.mfm_pocsag_create.argtypes = [C.POINTER(vp), C.POINTER(PocsagConfig)]
+    lib.mfm_pocsag_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_pocsag_destroy.restype = None
+    lib.mfm_pocsag_process_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+    lib.mfm_pocsag_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t]
+    lib.mfm_pocsag_fetch_events.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.mfm_bch3121_decode_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    lib.mfm_bch3121_decode_host.argtypes = [u32p, C.POINTER(C.c_uint8), C.c_size_t, C.c_int]
+    lib.mfm_hosttwin_bch3121_decode.argtypes = [u32p]
     lib.mfm_resampler_create.argtypes = [C.POINTER(vp), C.POINTER(ResamplerConfig), i16p, C.c_size_t]
     lib.mfm_resampler_destroy.argtypes = [C.POINTER(vp)]
     lib.mfm_resampler_destroy.restype = None
@@ -325,3 +355,69 @@ class Resampler:
         if rc < 0:
             raise MfmError(rc, "mfm_resampler_process_device", self.lib.mfm_strerror(rc).decode())
         return p.value, st.value, n.value
+
+
+class Pocsag:
+    """mfm_pocsag: POCSAG slicer / sync / batch collection + BCH(31,21) for all channels of a 38 400 Hz PCM block."""
+
+    def __init__(self, nr_channels, max_in_samples, device=0, max_events=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = PocsagConfig(MFM_ABI_VERSION, device, nr_channels, max_in_samples, max_events, 0)
+        rc = self.lib.mfm_pocsag_create(C.byref(self.h), C.byref(cfg))
+        if rc < 0:
+            raise MfmError(rc, "mfm_pocsag_create", self.lib.mfm_strerror(rc).decode())
+        self.nr_channels = nr_channels
+        self.max_events = max_events or (max_in_samples // 2048 + 16)
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_pocsag_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_host(self, pcm):
+        """pcm: int16 [C][n]; returns the events of this call as a structured array (POCSAG_EVENT_DTYPE)"""
+        a = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.nr_channels, -1)
+        rc = self.lib.mfm_pocsag_process_host(self.h, _i16p(a), a.shape[1], a.shape[1])
+        if rc < 0:
+            raise MfmError(rc, "mfm_pocsag_process_host", self.lib.mfm_strerror(rc).decode())
+        return self.fetch_events()
+
+    def process_device(self, d_pcm, in_stride, nr_in, stream=None):
+        rc = self.lib.mfm_pocsag_process_device(self.h, C.c_void_p(d_pcm), in_stride, nr_in, C.c_void_p(stream or 0))
+        if rc < 0:
+            raise MfmError(rc, "mfm_pocsag_process_device", self.lib.mfm_strerror(rc).decode())
+
+    def fetch_events(self):
+        cap = self.nr_channels * self.max_events
+        out = np.zeros(cap, POCSAG_EVENT_DTYPE)
+        n = C.c_size_t()
+        rc = self.lib.mfm_pocsag_fetch_events(self.h, out.ctypes.data, cap, C.byref(n))
+        if rc < 0:
+            raise MfmError(rc, "mfm_pocsag_fetch_events", self.lib.mfm_strerror(rc).decode())
+        return out[:n.value].copy()
+
+
+def bch3121_decode(words, device=0):
+    """bch_code_decode on the GPU: returns (corrected uint32 array, rc uint8 array)"""
+    lib = load_library()
+    w = np.ascontiguousarray(words, dtype=np.uint32).copy()
+    rc = np.zeros(w.size, np.uint8)
+    r = lib.mfm_bch3121_decode_host(w.ctypes.data_as(C.POINTER(C.c_uint32)), rc.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    w.size, device)
+    if r < 0:
+        raise MfmError(r, "mfm_bch3121_decode_host", lib.mfm_strerror(r).decode())
+    return w, rc
+
+
+def hosttwin_bch3121_decode(word):
+    lib = load_library()
+    v = C.c_uint32(int(word))
+    rc = lib.mfm_hosttwin_bch3121_decode(C.byref(v))
+    return rc, v.value

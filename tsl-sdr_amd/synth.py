@@ -92,3 +92,125 @@ def plan(name, nr_channels=None):
     gains_db = c.get("gains_db", [0.0] * len(offs))
     gains = np.array([10.0 ** (g / 10.0) for g in gains_db] + [1.0] * (len(offs) - len(gains_db)))
     return fs, decim, taps, offs, gains
+
+
+# ---- synthetic POCSAG ----------------------------------------------------------
+# Words are built in the bit order the reference holds them in (pager/pager_pocsag.c:477 fills batch words LSB
+# first): bit 0 = address/message flag, bits 1..20 = payload, bits 21..30 = BCH(31,21) parity (bit 30 - j is the
+# coefficient of x^j, pager/bch_code.c:325), bit 31 = even parity.  On the air that is a standard POCSAG codeword,
+# MSB first.
+
+POCSAG_SYNC = 0x7CD215D8   # pager/pager_pocsag_priv.h:40, sent MSB first
+POCSAG_IDLE = 0x6983915E   # pager/pager_pocsag_priv.h:46 (31 bits, as held after the mask)
+_BCH_G = 0x769             # x^10 + x^9 + x^8 + x^6 + x^5 + x^3 + 1
+
+
+def pocsag_codeword(payload21):
+    """payload21: bits 0..20 of the word -> full 32-bit word with BCH parity and the even-parity bit"""
+    w = int(payload21) & 0x1FFFFF
+    # data polynomial: bit b is the coefficient of x^(30 - b); reduce modulo g(x)
+    rem = 0
+    for b in range(21):
+        rem = (rem << 1) | ((w >> b) & 1)          # highest power first
+        if rem & (1 << 10):
+            rem ^= _BCH_G
+    for _ in range(10):                            # multiply by x^10
+        rem <<= 1
+        if rem & (1 << 10):
+            rem ^= _BCH_G
+    for j in range(10):                            # remainder coefficient of x^j -> bit 30 - j
+        if (rem >> j) & 1:
+            w |= 1 << (30 - j)
+    if bin(w).count("1") & 1:
+        w |= 1 << 31
+    return w
+
+
+def pocsag_address_word(addr18, function):
+    return pocsag_codeword(((int(addr18) & 0x3FFFF) << 1) | ((int(function) & 3) << 19))
+
+
+def pocsag_data_words(bits, pad=(0,)):
+    """bits: list of 0/1 payload bits in transmit order -> message codewords (20 bits each, padded with the
+    repeating `pad` pattern)"""
+    words = []
+    bits = list(bits)
+    while len(bits) % 20:
+        bits.append(pad[(len(bits)) % len(pad)])
+    for i in range(0, len(bits), 20):
+        chunk = bits[i:i + 20]
+        val = sum(int(chunk[k]) << k for k in range(20))
+        words.append(pocsag_codeword(1 | (val << 1)))
+    return words
+
+
+def pocsag_alpha_words(text):
+    bits = []
+    for ch in text.encode("ascii"):
+        bits += [(ch >> k) & 1 for k in range(7)]  # 7-bit characters, LSB first (pager_pocsag.c:378-399)
+    return pocsag_data_words(bits)
+
+
+def pocsag_numeric_words(digits):
+    table = "0123456789XU -[]"                      # pager_pocsag.c:299-316
+    bits = []
+    for ch in digits:
+        v = table.index(ch)
+        bits += [(v >> k) & 1 for k in range(4)]
+    return pocsag_data_words(bits, pad=(0, 0, 1, 1))   # fill with the "space" digit 0xC
+
+
+def pocsag_batches(messages):
+    """messages: list of (addr18, frame, function, data_words).  Each address word goes into its frame's first
+    slot (word 2 * frame) of the next batch that still has it free; the data words follow; the rest is idle."""
+    idle = POCSAG_IDLE | ((bin(POCSAG_IDLE).count("1") & 1) << 31)
+    stream = []                                     # flat list of words, 16 per batch
+    for addr18, frame, function, data in messages:
+        while len(stream) % 16 != 2 * frame:
+            stream.append(idle)
+        stream.append(pocsag_address_word(addr18, function))
+        stream += list(data)
+    stream.append(idle)
+    while len(stream) % 16:
+        stream.append(idle)
+    return [stream[i:i + 16] for i in range(0, len(stream), 16)]
+
+
+def pocsag_bits(batches, preamble_bits=576):
+    bits = [(i + 1) & 1 for i in range(preamble_bits)]          # 1010...
+    for batch in batches:
+        bits += [(POCSAG_SYNC >> (31 - k)) & 1 for k in range(32)]
+        for w in batch:
+            bits += [(int(w) >> k) & 1 for k in range(32)]
+    return np.array(bits, dtype=np.uint8)
+
+
+def pocsag_pcm(bits, baud, amplitude=8000, noise=0.0, lead=0, trail=0, seed=0, flip=None):
+    """NRZ PCM at 38 400 Hz: a 1 is a negative sample (pager_pocsag.c:91).  `flip`: indices of bits to invert
+    (channel errors).  lead / trail: noise-only samples before / after."""
+    spb = 38400 // baud
+    b = np.array(bits, dtype=np.int64)
+    if flip is not None and len(flip):
+        b[np.asarray(flip)] ^= 1
+    rng = np.random.RandomState(seed)
+    sig = np.repeat(np.where(b == 1, -amplitude, amplitude), spb).astype(np.float64)
+    x = np.concatenate([np.zeros(lead), sig, np.zeros(trail)])
+    if noise > 0:
+        x = x + rng.normal(0.0, noise, size=x.size)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
+
+
+def pocsag_fm_iq(bits, baud, sample_rate_hz, carrier_hz, deviation_hz=4500.0, amplitude=9000.0, lead=0, trail=0,
+                 noise=200.0, seed=0):
+    """2-FSK at `carrier_hz` from the tuner centre: bit 1 -> -deviation (negative discriminator output)."""
+    spb = int(round(sample_rate_hz / baud))
+    f = np.concatenate([np.zeros(lead), np.repeat(np.where(np.asarray(bits) == 1, -deviation_hz, deviation_hz), spb),
+                        np.zeros(trail)]) + carrier_hz
+    ph = 2.0 * np.pi * np.cumsum(f) / sample_rate_hz
+    rng = np.random.RandomState(seed)
+    i = amplitude * np.cos(ph) + rng.normal(0.0, noise, size=ph.size)
+    q = amplitude * np.sin(ph) + rng.normal(0.0, noise, size=ph.size)
+    out = np.empty((ph.size, 2), np.int16)
+    out[:, 0] = np.clip(np.round(i), -32768, 32767)
+    out[:, 1] = np.clip(np.round(q), -32768, 32767)
+    return out
