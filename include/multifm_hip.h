@@ -207,6 +207,10 @@ size_t mfm_resampler_max_out(const struct mfm_resampler *r);
  */
 int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, size_t in_stride, size_t nr_in,
                                  void *stream, int16_t **d_out, size_t *out_stride, size_t *nr_out);
+/* Host in, device out: the PCM is staged to the device on `stream` (what a decoder-shaped host reading FIFOs
+ * uses, so that only the input crosses PCIe); otherwise as mfm_resampler_process_device. */
+int mfm_resampler_process_host_to_device(struct mfm_resampler *r, const int16_t *pcm, size_t in_stride, size_t nr_in,
+                                         void *stream, int16_t **d_out, size_t *out_stride, size_t *nr_out);
 /* Host convenience (tests, harnesses): same, host in / host out, synchronous; out is [channel][out_stride]. */
 int mfm_resampler_process_host(struct mfm_resampler *r, const int16_t *pcm, size_t in_stride, size_t nr_in,
                                int16_t *out, size_t out_stride, size_t *nr_out);

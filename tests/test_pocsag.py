@@ -155,6 +155,64 @@ def test_oracle_message_layer_replays_from_events(ora, pkg):
     assert any(int(e["nr_ok"]) < 16 for e in ev if e["type"] == ora.EV_BATCH)  # the triple error ended a batch early
 
 
+HOST_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tsl-sdr_amd", "host", "libmfm_host.so")
+
+
+class HostPager:
+    """tsl-sdr_amd/host/mfm_pager_pocsag.c through ctypes: collects the pages its callbacks receive."""
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint16, C.c_uint32, C.POINTER(C.c_char), C.c_size_t, C.c_uint8)
+
+    def __init__(self):
+        if not os.path.exists(HOST_SO):
+            pytest.fail(f"{HOST_SO} missing: run make -C tsl-sdr_amd")
+        self.h = C.CDLL(HOST_SO)
+        self.pages = []
+        self._num = self.CB(lambda p, baud, cap, data, n, fn: self._page(3, baud, cap, data, n, fn))
+        self._alpha = self.CB(lambda p, baud, cap, data, n, fn: self._page(2, baud, cap, data, n, fn))
+        self.p = C.c_void_p()
+        self.h.pager_pocsag_new.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, self.CB, self.CB, C.c_bool]
+        self.h.pager_pocsag_on_events.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.h.pager_pocsag_delete.argtypes = [C.POINTER(C.c_void_p)]
+        assert self.h.pager_pocsag_new(C.byref(self.p), 929612500, self._num, self._alpha, False) == 0
+
+    def _page(self, kind, baud, cap, data, n, fn):
+        self.pages.append((kind, int(baud), int(cap), int(fn), C.string_at(data, n)))
+        return 0
+
+    def on_events(self, ev):
+        ev = np.ascontiguousarray(ev)
+        assert self.h.pager_pocsag_on_events(self.p, ev.ctypes.data, ev.size) == 0
+
+    def close(self):
+        assert self.h.pager_pocsag_delete(C.byref(self.p)) == 0
+
+
+def _to_product_events(ev, pkg, channel=0):
+    out = np.zeros(ev.size, pkg.binding.POCSAG_EVENT_DTYPE)
+    for k in ("type", "baud", "aux", "sample", "nr_ok", "fail_mask", "raw", "corrected"):
+        out[k] = ev[k]
+    out["channel"] = channel
+    return out
+
+
+def test_host_page_assembly_from_events(ora, pkg):
+    """The C host's message layer (mfm_pager_pocsag.c), fed the oracle's events in the product's event layout,
+    delivers the pages the oracle's embedded message layer delivers - including the early termination on an
+    uncorrectable word and the flush when sync is lost."""
+    sy = pkg.synth
+    assert pkg.binding.POCSAG_EVENT_DTYPE.itemsize == 160 == C.sizeof(pkg.binding.PocsagEvent)
+    pcm = _pocsag_channels(sy, ora, 420000)
+    for c in range(pcm.shape[0]):
+        ev, msgs = ora.Pocsag().feed(pcm[c])
+        hp = HostPager()
+        half = ev.size // 2
+        hp.on_events(_to_product_events(ev[:half], pkg))
+        hp.on_events(_to_product_events(ev[half:], pkg))
+        hp.close()
+        assert hp.pages == [(m[0], m[1], m[2], m[3], m[4]) for m in msgs], f"channel {c}"
+    assert len(msgs) > 0
+
+
 # ---- GPU parity ---------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
@@ -325,3 +383,56 @@ def test_gpu_chain_iq_to_pocsag_codewords(ora, pkg):
         assert int((want["type"] == ora.EV_BATCH).sum()) >= 1
         if c == 0:
             assert [m[4].rstrip(b"\x00") for m in pages][:1] == [b"HELLO MI355X\x04"]
+
+
+def _json_lines(pages):
+    """decoder/decoder.c:264-318 with the clock pinned to the epoch (MFM_DECODER_FIXED_TIME)"""
+    esc = {0x0A: "\\n", 0x0D: "\\n", 0x22: '\\"', 0x5C: "\\\\", 0x2F: "\\/", 0x08: "<BKSP>", 0x0C: "<FF>", 0x09: "\\t",
+           0x03: " ", 0x04: " ", 0x17: " "}
+    out = []
+    for kind, baud, cap, fn, text, _ in pages:
+        body = "".join(esc.get(ch, chr(ch) if 0x20 <= ch < 0x7F else "\\u%04x" % ch) for ch in text)
+        out.append('{"proto":"pocsag","type":"%s","timestamp":"1970-01-01 00:00:00 UTC","baud":%d,"capCode":%d,'
+                   '"function":%d,"message":"%s"}\n' % ("alphanumeric" if kind == 2 else "numeric", baud, cap, fn, body))
+    return "".join(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [[], ["-i", "-b", "-p", "0.999"]])
+def test_decoder_amd_json_matches_oracle(tmp_path, ora, pkg, opts):
+    """the decoder-shaped driver (decoder/decoder.c:580-673 loop, :264-318 output) on
+    three 48 kS/s PCM files -> 4/5 -> 38 400 Hz -> POCSAG; the JSON lines must be what the oracle chain's pages
+    print as."""
+    import json
+    import subprocess
+    sy = pkg.synth
+    tool = os.path.join(os.path.dirname(HOST_SO), "decoder_amd")
+    msgs = _messages(sy) + [(0x2AAAA, 7, 1, sy.pocsag_alpha_words('quote " slash / back \\ tab\t nl\n bell\x07 end\x17'))]
+    bits = sy.pocsag_bits(sy.pocsag_batches(msgs))
+    total = 900000
+    chans = []
+    for baud, seed in ((1200, 1), (2400, 2), (512, 3)):
+        x = sy.pocsag_pcm(bits, baud, noise=900, lead=9000 + 111 * seed, trail=40000, seed=seed, rate=48000)
+        x = np.concatenate([x, np.random.RandomState(seed).normal(0, 900, total).round().astype(np.int16)])[:total]
+        chans.append(x)
+    taps = sy.design_lpf(81, 0.45 / 5, 1.0) * 4
+    (tmp_path / "filter.json").write_text(json.dumps({"lpfCoeffs": [float(t) for t in taps]}))
+    invert = "-i" in opts
+    paths = []
+    for c, x in enumerate(chans):
+        p = tmp_path / f"ch{c}.pcm"
+        p.write_bytes(((-x.astype(np.int32)).astype(np.int16) if invert else x).tobytes())
+        paths.append(str(p))
+    out = tmp_path / "pages.json"
+    env = dict(os.environ, MFM_DECODER_FIXED_TIME="1")
+    r = subprocess.run([tool, "-I", "4", "-D", "5", "-S", "48000", "-F", str(tmp_path / "filter.json"), "-f", "929612500",
+                        "-m", "POCSAG", "-c", "-o", str(out), "-B", "100000"] + opts + paths,
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rtaps = ora.quantize_taps(taps)
+    for c, x in enumerate(chans):
+        xin = (-x.astype(np.int32)).astype(np.int16) if invert else x
+        res = ora.Resampler(rtaps, 4, 5, dc_pole=0.999 if "-b" in opts else None, invert=invert)
+        _, pages = ora.Pocsag().feed(res.feed(xin))
+        assert len(pages) >= 3
+        assert (tmp_path / f"pages.json.{c}").read_text() == _json_lines(pages), f"channel {c}"

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mfm_engine_stream", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
     "mfm_resampler_create", "mfm_resampler_destroy", "mfm_resampler_max_out", "mfm_resampler_process_device",
-    "mfm_resampler_process_host",
+    "mfm_resampler_process_host", "mfm_resampler_process_host_to_device",
     "mfm_pocsag_create", "mfm_pocsag_destroy", "mfm_pocsag_process_device", "mfm_pocsag_process_host",
     "mfm_pocsag_fetch_events", "mfm_bch3121_decode_device", "mfm_bch3121_decode_host", "mfm_hosttwin_bch3121_decode",
 ]
@@ -147,6 +147,8 @@ def load_library():
     lib.mfm_resampler_process_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.POINTER(vp),
                                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.mfm_resampler_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t, i16p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.mfm_resampler_process_host_to_device.argtypes = [vp, i16p, C.c_size_t, C.c_size_t, vp, C.POINTER(vp),
+                                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     _lib = lib
     return lib
 

@@ -324,6 +324,12 @@ const char *mfm_last_error(void)
     return g_last_error;
 }
 
+/* for the other translation units of the library (mfm_resampler.hip, mfm_pocsag.hip) */
+__attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *msg)
+{
+    snprintf(g_last_error, sizeof(g_last_error), "%s", msg);
+}
+
 size_t mfm_engine_input_bytes(uint32_t max_block_samples, uint32_t nr_taps)
 {
     return (size_t)input_capacity(max_block_samples, nr_taps) * sizeof(uint32_t);

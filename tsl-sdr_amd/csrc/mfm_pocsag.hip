@@ -36,6 +36,8 @@
 
 #include "../../include/multifm_hip.h"
 
+extern "C" __attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *msg);
+
 namespace {
 
 constexpr uint32_t PG_HIST = 65536;  /* samples of history kept in front of the newest block (>= 544 * 75 + 31 * 75) */
@@ -567,6 +569,7 @@ BchTables *g_bch_dev[64] = {};
         hipError_t err_ = (expr);                                                                            \
         if (err_ != hipSuccess) {                                                                            \
             snprintf(g_pg_error, sizeof(g_pg_error), "%s failed: %s", #expr, hipGetErrorString(err_));       \
+            mfm_internal_set_error(g_pg_error);                                                              \
             return MFM_E_DEVICE;                                                                             \
         }                                                                                                    \
     } while (0)
@@ -761,6 +764,7 @@ int mfm_pocsag_fetch_events(struct mfm_pocsag *p, struct mfm_pocsag_event *out, 
     }
     if (overflow) {
         snprintf(g_pg_error, sizeof(g_pg_error), "a channel produced more than max_events=%u events in one call", p->max_ev);
+        mfm_internal_set_error(g_pg_error);
         return MFM_E_STATE;
     }
     return MFM_OK;

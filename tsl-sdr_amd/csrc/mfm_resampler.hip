@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "../../include/multifm_hip.h"
+
+extern "C" __attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *msg);
 #include "mfm_numerics.h"
 
 namespace {
@@ -96,6 +98,7 @@ struct mfm_resampler {
     int cur = 0;
     uint32_t tail = 0; /* unconsumed samples at the front of d_x[cur] */
     uint32_t phase_id = 0;
+    int16_t *d_stage = nullptr; /* process_host_to_device: [C][max_in_samples] */
 };
 
 #define RS_TRY(expr)                                                                                         \
@@ -103,6 +106,7 @@ struct mfm_resampler {
         hipError_t err_ = (expr);                                                                            \
         if (err_ != hipSuccess) {                                                                            \
             snprintf(g_rs_error, sizeof(g_rs_error), "%s failed: %s", #expr, hipGetErrorString(err_));       \
+            mfm_internal_set_error(g_rs_error);                                                              \
             return MFM_E_DEVICE;                                                                             \
         }                                                                                                    \
     } while (0)
@@ -179,6 +183,7 @@ void mfm_resampler_destroy(struct mfm_resampler **pr)
     (void)hipFree(r->d_x[1]);
     (void)hipFree(r->d_y);
     (void)hipFree(r->d_dc);
+    (void)hipFree(r->d_stage);
     delete r;
     *pr = nullptr;
 }
@@ -239,6 +244,24 @@ int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, 
     *out_stride = r->out_cap;
     *nr_out = n_out;
     return MFM_OK;
+}
+
+int mfm_resampler_process_host_to_device(struct mfm_resampler *r, const int16_t *pcm, size_t in_stride, size_t nr_in,
+                                         void *stream, int16_t **d_out, size_t *out_stride, size_t *nr_out)
+{
+    if (!r || (!pcm && nr_in) || nr_in > r->cfg.max_in_samples) {
+        return MFM_E_INVAL;
+    }
+    RS_TRY(hipSetDevice(r->cfg.device));
+    const uint32_t C = r->cfg.nr_channels;
+    if (!r->d_stage) {
+        RS_TRY(hipMalloc(&r->d_stage, (size_t)C * r->cfg.max_in_samples * 2));
+    }
+    if (nr_in) {
+        RS_TRY(hipMemcpy2DAsync(r->d_stage, (size_t)r->cfg.max_in_samples * 2, pcm, in_stride * 2, nr_in * 2, C,
+                                hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    }
+    return mfm_resampler_process_device(r, r->d_stage, r->cfg.max_in_samples, nr_in, stream, d_out, out_stride, nr_out);
 }
 
 int mfm_resampler_process_host(struct mfm_resampler *r, const int16_t *pcm, size_t in_stride, size_t nr_in,

@@ -185,15 +185,16 @@ def pocsag_bits(batches, preamble_bits=576):
     return np.array(bits, dtype=np.uint8)
 
 
-def pocsag_pcm(bits, baud, amplitude=8000, noise=0.0, lead=0, trail=0, seed=0, flip=None):
-    """NRZ PCM at 38 400 Hz: a 1 is a negative sample (pager_pocsag.c:91).  `flip`: indices of bits to invert
-    (channel errors).  lead / trail: noise-only samples before / after."""
-    spb = 38400 // baud
+def pocsag_pcm(bits, baud, amplitude=8000, noise=0.0, lead=0, trail=0, seed=0, flip=None, rate=38400):
+    """NRZ PCM at `rate` Hz (38 400 is what the decoder wants): a 1 is a negative sample (pager_pocsag.c:91).
+    `flip`: indices of bits to invert (channel errors).  lead / trail: noise-only samples before / after."""
     b = np.array(bits, dtype=np.int64)
     if flip is not None and len(flip):
         b[np.asarray(flip)] ^= 1
     rng = np.random.RandomState(seed)
-    sig = np.repeat(np.where(b == 1, -amplitude, amplitude), spb).astype(np.float64)
+    n = (b.size * rate + baud - 1) // baud
+    idx = np.minimum((np.arange(n, dtype=np.int64) * baud) // rate, b.size - 1)
+    sig = np.where(b[idx] == 1, -amplitude, amplitude).astype(np.float64)
     x = np.concatenate([np.zeros(lead), sig, np.zeros(trail)])
     if noise > 0:
         x = x + rng.normal(0.0, noise, size=x.size)
