@@ -12,13 +12,14 @@
  *           W bit j = bits[n - j * samples_per_bit].  eye_detect[cur_word] of the reference is exactly that
  *           register, whichever slot it lives in.  Computed 32 samples at a time, bit-sliced: 32 shifted
  *           views of the bit stream (one funnel shift each) go through a carry-save adder tree.
- *   summ    one bit per 32 samples: any of the three m words non-zero.  Lets an idle channel be skipped
- *           65536 samples per step.
+ *   summ    one bit per 32 samples: some run of two or more matches touches this word (a detector needs more
+ *           than eight in a row to fire).  Lets an idle channel be skipped 65536 samples per step.
  *
  * What stays sequential is the walk from event to event (sync found -> 512 strided bits -> 32 sync bits ->
- * ...): one 64-lane wave per channel does it, finding the first "eye closes after more than spb/2 matches"
- * with a segmented wave scan over the m words, gathering the 544 strided bits of a batch with eight ballots,
- * and correcting the 16 words with a 10-bit syndrome -> flip-mask table in LDS.
+ * ...): one workgroup of four waves per channel does it.  All waves carry the same state; each finds the first
+ * "eye closes after more than spb/2 matches" with a segmented wave scan over the m words; in a transmission
+ * every wave gathers its own share of the coming slots (544 strided bits each, nine ballots), corrects the
+ * 16 words with a 10-bit syndrome -> flip-mask table in LDS, and the sync verdicts are exchanged through LDS.
  *
  * After a reset the reference's registers are zero-filled, so for 31 bit periods m differs from the
  * free-running bitmap; the walker recomputes those words itself with the pre-reset bits masked off (same
@@ -43,6 +44,8 @@ namespace {
 constexpr uint32_t PG_HIST = 65536;  /* samples of history kept in front of the newest block (>= 544 * 75 + 31 * 75) */
 constexpr uint32_t PG_GROUP = 2048;  /* alignment unit: 64 words = one wave of the match kernel = 2 summary words */
 constexpr uint32_t PG_SYNC = 0x7cd215d8u; /* pager_pocsag_priv.h:40 */
+constexpr uint32_t PG_WALK_WAVES = 4; /* waves per channel in the walker */
+constexpr uint32_t PG_SPEC = 4;       /* batch + sync slots each of them gathers per step */
 constexpr uint32_t PG_SLOW_SPAN = 31 * 75; /* samples after a reset during which some register is zero-filled */
 
 enum : uint32_t { PG_SEARCH = 0, PG_BATCH = 2, PG_SYNCWORD = 3 };
@@ -273,32 +276,73 @@ __global__ __launch_bounds__(256) void pg_slide_kernel(PgBuf dst, PgBuf src, uin
     }
 }
 
-/* the slicer: bit = sample < 0 (pager_pocsag.c:91,476,507) */
+/*
+ * The slicer: bit = sample < 0 (pager_pocsag.c:91,476,507).  HBM-bound: 2 bytes in per sample, 1/8 byte out.
+ * One lane takes 8 consecutive samples with one 16-byte load (the address is only 2-byte aligned in general:
+ * the window is aligned, the caller's rows are not), squeezes them to a byte, and four neighbouring lanes merge
+ * their bytes into a word; a wave covers 512 samples per step and PG_SLICE_U steps are in flight together.
+ */
+constexpr uint32_t PG_SLICE_U = 4;
+
+struct __attribute__((packed, aligned(2))) PgPcm8 {
+    uint32_t d[4];
+};
+
 __global__ __launch_bounds__(256) void pg_slice_kernel(PgBuf buf, const int16_t *x, size_t stride, uint32_t n, uint32_t off0,
-                                                      uint32_t ngroups)
+                                                      uint32_t nsteps)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t g = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const uint32_t s0 = (blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * PG_SLICE_U;
     const uint32_t c = blockIdx.y;
-    if (g >= ngroups) {
+    if (s0 >= nsteps) {
         return;
     }
-    const uint32_t base = (off0 & ~63u) + 64u * g; /* window-relative sample index of lane 0 */
-    const int64_t i = (int64_t)base + lane - (int64_t)off0;
-    int bit = 0;
-    if (i >= 0 && i < (int64_t)n) {
-        bit = x[(size_t)c * stride + (size_t)i] < 0;
-    }
-    const unsigned long long b = __ballot(bit);
-    if (lane == 0 || lane == 32) {
-        const uint32_t first = base + lane; /* first sample of this word */
-        uint32_t word = (uint32_t)(b >> lane);
-        uint32_t *dst = buf.plane(0, c) + (first >> 5);
-        if (first < off0) { /* the word straddles the old end: keep the bits that are already there */
-            const uint32_t keep = (off0 - first >= 32) ? 0xffffffffu : ((1u << (off0 - first)) - 1u);
-            word = (*dst & keep) | (word & ~keep);
+    const int16_t *xc = x + (size_t)c * stride;
+    const uint32_t base0 = (off0 & ~511u) + 512u * s0 + 8u * lane; /* window-relative index of my first sample */
+    uint32_t d[PG_SLICE_U][4];
+    const int64_t wave_first = (int64_t)((off0 & ~511u) + 512u * s0) - (int64_t)off0; /* input index of the wave's first sample */
+    if (wave_first >= 0 && wave_first + 512 * (int64_t)PG_SLICE_U <= (int64_t)n) {
+        /* interior (wave-uniform): all loads issued back to back */
+#pragma unroll
+        for (uint32_t k = 0; k < PG_SLICE_U; k++) {
+            const PgPcm8 v = *reinterpret_cast<const PgPcm8 *>(xc + ((int64_t)base0 + 512 * k - (int64_t)off0));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                d[k][q] = v.d[q];
+            }
         }
-        *dst = word;
+    } else { /* first / last samples of the call: element by element */
+#pragma unroll
+        for (uint32_t k = 0; k < PG_SLICE_U; k++) {
+            const int64_t i = (int64_t)base0 + 512 * k - (int64_t)off0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t i0 = i + 2 * q, i1 = i0 + 1;
+                const uint32_t lo = (i0 >= 0 && i0 < (int64_t)n) ? (uint16_t)xc[i0] : 0u;
+                const uint32_t hi = (i1 >= 0 && i1 < (int64_t)n) ? (uint16_t)xc[i1] : 0u;
+                d[k][q] = lo | (hi << 16);
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PG_SLICE_U; k++) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            b |= (((d[k][q] >> 15) & 1u) | ((d[k][q] >> 30) & 2u)) << (2 * q);
+        }
+        b |= (uint32_t)__shfl_down((int)b, 1) << 8;  /* valid in even lanes */
+        b |= (uint32_t)__shfl_down((int)b, 2) << 16; /* valid in lanes 0, 4, 8, ... */
+        if (s0 + k < nsteps && (lane & 3u) == 0) {
+            const uint32_t first = base0 + 512u * k; /* first sample of this word */
+            uint32_t *dst = buf.plane(0, c) + (first >> 5);
+            uint32_t word = b;
+            if (first < off0) { /* the word straddles the old end: keep the bits that are already there */
+                const uint32_t keep = (off0 - first >= 32) ? 0xffffffffu : ((1u << (off0 - first)) - 1u);
+                word = (*dst & keep) | (word & ~keep);
+            }
+            *dst = word;
+        }
     }
 }
 
@@ -323,8 +367,21 @@ __global__ __launch_bounds__(256) void pg_match_kernel(PgBuf buf, uint32_t w_fir
     buf.plane(1, c)[wi] = m0;
     buf.plane(2, c)[wi] = m1;
     buf.plane(3, c)[wi] = m2;
-    const unsigned long long any = __ballot((m0 | m1 | m2) != 0u);
+    /* summary bit: "a run of two or more matches touches this word" - two adjacent matches inside it, or its last
+     * sample and the next word's first both match (across a wave boundary: assume they do).  A detector can only
+     * fire after more than 8 consecutive matches, so words without the bit can be skipped by the walker. */
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t flag = 0;
+    {
+        const uint32_t ms[3] = { m0, m1, m2 };
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const uint32_t nxt = (uint32_t)__shfl_down((int)ms[d], 1);
+            const uint32_t next_first = lane == 63 ? 1u : (nxt & 1u);
+            flag |= (ms[d] & (ms[d] >> 1)) | ((ms[d] >> 31) & next_first);
+        }
+    }
+    const unsigned long long any = __ballot(flag != 0u);
     if (lane == 0 || lane == 32) {
         buf.summ(c)[(uint32_t)wi >> 5] = (uint32_t)(any >> lane);
     }
@@ -352,14 +409,15 @@ __device__ __forceinline__ uint32_t pg_wave_min(uint32_t v)
 }
 
 /* one wave per channel: pager_pocsag_on_pcm (pager_pocsag.c:434-543) from event to event */
-__global__ __launch_bounds__(64) void pg_walk_kernel(const PgWalk L)
+__global__ __launch_bounds__(64 * PG_WALK_WAVES) void pg_walk_kernel(const PgWalk L)
 {
     __shared__ BchTables T;
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t sh_sync[PG_WALK_WAVES * PG_SPEC];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(L.bch);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&T);
-        for (uint32_t i = lane; i < sizeof(BchTables) / 4; i += 64) {
+        for (uint32_t i = threadIdx.x; i < sizeof(BchTables) / 4; i += blockDim.x) {
             dst[i] = src[i];
         }
     }
@@ -375,9 +433,31 @@ __global__ __launch_bounds__(64) void pg_walk_kernel(const PgWalk L)
         const uint32_t o = (uint32_t)(n - L.ws);
         return (bits[o >> 5] >> (o & 31u)) & 1u;
     };
+    auto getbit_rel = [&](uint32_t o) { return (bits[o >> 5] >> (o & 31u)) & 1u; }; /* window-relative index */
+    /* every wave keeps the same state and takes the same decisions; wave 0 reports them, except in the slot-parallel
+     * batch step where each wave reports its own slots */
+    auto emit_at = [&](uint32_t idx, uint32_t type, uint32_t aux, uint64_t sample, uint32_t nr_ok, uint32_t fail_mask,
+                       uint32_t raw, uint32_t fixed) {
+        if (idx < L.max_ev) {
+            mfm_pocsag_event *e = &ev[idx];
+            if (lane == 0) {
+                e->type = type;
+                e->baud = st.baud;
+                e->channel = c;
+                e->aux = aux;
+                e->sample = sample;
+                e->nr_ok = nr_ok;
+                e->fail_mask = fail_mask;
+            }
+            if (lane < 16) {
+                e->raw[lane] = raw;
+                e->corrected[lane] = fixed;
+            }
+        }
+    };
     auto emit = [&](uint32_t type, uint32_t aux, uint64_t sample, uint32_t nr_ok, uint32_t fail_mask, uint32_t raw,
                     uint32_t fixed) {
-        if (nev < L.max_ev) {
+        if (nev < L.max_ev && wv == 0) {
             mfm_pocsag_event *e = &ev[nev];
             if (lane == 0) {
                 e->type = type;
@@ -508,31 +588,107 @@ __global__ __launch_bounds__(64) void pg_walk_kernel(const PgWalk L)
                 }
             }
         } else if (st.mode == PG_BATCH) {
-            /* 512 bits, one every S samples, LSB first into 16 words (pager_pocsag.c:472-481) */
+            /* 512 bits, one every S samples, LSB first into 16 words (pager_pocsag.c:472-481), then 32 bits in the
+             * sync slot, first one ending up in bit 31 (:506-513) */
             if (st.b0 + 511ull * st.S >= L.end) {
                 break;
             }
-            uint32_t myraw = 0;
+            const uint64_t avail_bits = (L.end - 1 - st.b0) / st.S + 1;
+            const uint32_t nslots = avail_bits / 544u < PG_WALK_WAVES * PG_SPEC ? (uint32_t)(avail_bits / 544u) : PG_WALK_WAVES * PG_SPEC;
+            if (nslots == 0) {
+                /* the batch is complete but its sync slot is not: report the batch now, as the reference does */
+                uint32_t myraw = 0;
 #pragma unroll
-            for (uint32_t r = 0; r < 8; r++) {
-                const uint32_t bit = getbit(st.b0 + (uint64_t)(64u * r + lane) * st.S);
-                const unsigned long long b = __ballot((int)bit);
-                if (lane == 2 * r) {
-                    myraw = (uint32_t)b;
+                for (uint32_t r = 0; r < 8; r++) {
+                    const uint32_t bit = getbit(st.b0 + (uint64_t)(64u * r + lane) * st.S);
+                    const unsigned long long b = __ballot((int)bit);
+                    if (lane == 2 * r) {
+                        myraw = (uint32_t)b;
+                    }
+                    if (lane == 2 * r + 1) {
+                        myraw = (uint32_t)(b >> 32);
+                    }
                 }
-                if (lane == 2 * r + 1) {
-                    myraw = (uint32_t)(b >> 32);
+                uint32_t rc = 0;
+                const uint32_t fixed = pg_bch_fix(&T, myraw & 0x7fffffffu, &rc); /* pager_pocsag.c:332-334 */
+                const uint32_t fail = (uint32_t)__ballot(lane < 16 && rc) & 0xffffu;
+                const uint32_t nr_ok = fail ? (uint32_t)(__ffs((int)fail) - 1) : 16u;
+                emit(MFM_POCSAG_EV_BATCH, 0, st.b0 + 511ull * st.S, nr_ok, fail, myraw, fixed);
+                st.b0 += 512ull * st.S;
+                st.mode = PG_SYNCWORD;
+            } else {
+                /* Whole slots (batch + sync word) are here.  While sync holds, the next slot starts exactly 544 bit
+                 * periods later, so up to PG_SPEC slots per wave are gathered speculatively - every load in flight
+                 * before the first ballot - by all waves at once (wave w takes slots w * PG_SPEC ...), the sync
+                 * verdicts are exchanged through LDS, and everything behind the first lost sync is dropped. */
+                const uint32_t rel0 = (uint32_t)(st.b0 - L.ws);
+                uint32_t got[PG_SPEC][9];
+#pragma unroll
+                for (uint32_t j = 0; j < PG_SPEC; j++) {
+                    const uint32_t g = wv * PG_SPEC + j;
+                    const uint32_t sb = rel0 + (g < nslots ? 544u * g * st.S : 0u);
+#pragma unroll
+                    for (uint32_t r = 0; r < 8; r++) {
+                        got[j][r] = getbit_rel(sb + (64u * r + lane) * st.S);
+                    }
+                    got[j][8] = getbit_rel(sb + (512u + (lane & 31u)) * st.S);
+                }
+                uint32_t raws[PG_SPEC], syncs[PG_SPEC];
+#pragma unroll
+                for (uint32_t j = 0; j < PG_SPEC; j++) {
+                    raws[j] = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < 8; r++) {
+                        const unsigned long long b = __ballot((int)got[j][r]);
+                        /* word 2r -> lane 2r, word 2r+1 -> lane 2r+1.  There is no clang builtin for v_writelane here,
+                         * and the compiler does not pad hazards around inline asm: the ballot is a v_cmp writing VCC,
+                         * and v_writelane reading it straight away sees the previous value (measured), hence s_nop. */
+                        asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"
+                                     : "+v"(raws[j])
+                                     : "s"((uint32_t)b), "n"(2 * r), "s"((uint32_t)(b >> 32)), "n"(2 * r + 1));
+                    }
+                    syncs[j] = __brev((uint32_t)__ballot((int)got[j][8]));
+                    if (lane == 0) {
+                        sh_sync[wv * PG_SPEC + j] = syncs[j];
+                    }
+                }
+                __syncthreads();
+                /* first slot whose sync word is bad (nslots = none) */
+                uint32_t bad = nslots;
+                {
+                    const uint32_t sw = lane < PG_WALK_WAVES * PG_SPEC ? sh_sync[lane] : PG_SYNC;
+                    const unsigned long long lost = __ballot(lane < nslots && __popc(sw ^ PG_SYNC) > 4);
+                    if (lost) {
+                        bad = (uint32_t)(__ffsll((long long)lost) - 1);
+                    }
+                }
+                __syncthreads(); /* sh_sync is reused by the next step */
+#pragma unroll
+                for (uint32_t j = 0; j < PG_SPEC; j++) {
+                    const uint32_t g = wv * PG_SPEC + j;
+                    if (g < nslots && g <= bad) {
+                        uint32_t rc = 0;
+                        const uint32_t fixed = pg_bch_fix(&T, raws[j] & 0x7fffffffu, &rc); /* pager_pocsag.c:332-334 */
+                        const uint32_t fail = (uint32_t)__ballot(lane < 16 && rc) & 0xffffu;
+                        const uint32_t nr_ok = fail ? (uint32_t)(__ffs((int)fail) - 1) : 16u;
+                        const uint64_t sb = st.b0 + (uint64_t)(544u * g) * st.S;
+                        emit_at(nev + 2 * g, MFM_POCSAG_EV_BATCH, 0, sb + 511ull * st.S, nr_ok, fail, raws[j], fixed);
+                        emit_at(nev + 2 * g + 1, g == bad ? MFM_POCSAG_EV_SYNC_LOST : MFM_POCSAG_EV_SYNC_KEPT, syncs[j],
+                                sb + 543ull * st.S, 0, 0, 0, 0);
+                    }
+                }
+                if (bad == nslots) {
+                    nev += 2 * nslots;
+                    st.b0 += (uint64_t)(544u * nslots) * st.S;
+                } else {
+                    nev += 2 * (bad + 1);
+                    st.mode = PG_SEARCH; /* pager_pocsag.c:517-523: all three detectors start from zero */
+                    st.pos = st.r = st.b0 + (uint64_t)(544u * bad + 543u) * st.S + 1;
+                    st.nr[0] = st.nr[1] = st.nr[2] = 0;
                 }
             }
-            uint32_t rc = 0;
-            const uint32_t fixed = pg_bch_fix(&T, myraw & 0x7fffffffu, &rc); /* pager_pocsag.c:332-334 */
-            const uint32_t fail = (uint32_t)__ballot(lane < 16 && rc) & 0xffffu;
-            const uint32_t nr_ok = fail ? (uint32_t)(__ffs((int)fail) - 1) : 16u;
-            emit(MFM_POCSAG_EV_BATCH, 0, st.b0 + 511ull * st.S, nr_ok, fail, myraw, fixed);
-            st.b0 += 512ull * st.S;
-            st.mode = PG_SYNCWORD;
         } else {
-            /* the 32 bits in the sync slot, first bit ends up in bit 31 (pager_pocsag.c:506-513) */
+            /* a batch was reported before its sync slot had arrived; now the 32 bits are here */
             if (st.b0 + 31ull * st.S >= L.end) {
                 break;
             }
@@ -551,7 +707,7 @@ __global__ __launch_bounds__(64) void pg_walk_kernel(const PgWalk L)
             }
         }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         L.st[c] = st;
         L.ev_count[c] = nev;
     }
@@ -615,7 +771,7 @@ int mfm_pocsag_create(struct mfm_pocsag **pp, const struct mfm_pocsag_config *cf
     }
     *pp = nullptr;
     if (cfg->abi_version != MFM_ABI_VERSION || 0 == cfg->nr_channels || 0 == cfg->max_in_samples ||
-        cfg->max_in_samples > (1u << 30)) {
+        cfg->max_in_samples > (1u << 28)) {
         return MFM_E_INVAL;
     }
     BchTables *d_bch = nullptr;
@@ -694,8 +850,9 @@ int mfm_pocsag_process_device(struct mfm_pocsag *p, const int16_t *d_pcm, size_t
     }
     const PgBuf buf = p->buf[p->cur];
     if (n) {
-        const uint32_t ngroups = (off0 + n - (off0 & ~63u) + 63) / 64;
-        hipLaunchKernelGGL(pg_slice_kernel, dim3((ngroups + 3) / 4, C), dim3(256), 0, s, buf, d_pcm, in_stride, n, off0, ngroups);
+        const uint32_t nsteps = (off0 + n - (off0 & ~511u) + 511) / 512;
+        hipLaunchKernelGGL(pg_slice_kernel, dim3((nsteps + 4 * PG_SLICE_U - 1) / (4 * PG_SLICE_U), C), dim3(256), 0, s, buf, d_pcm,
+                           in_stride, n, off0, nsteps);
         PG_TRY(hipGetLastError());
         const uint32_t w_first = (off0 & ~(PG_GROUP - 1)) / 32;
         const uint32_t w_end = (off0 + n + 31) / 32;
@@ -703,7 +860,7 @@ int mfm_pocsag_process_device(struct mfm_pocsag *p, const int16_t *d_pcm, size_t
         PG_TRY(hipGetLastError());
     }
     PgWalk W{ buf, p->ws, p->total + n, p->d_st, p->d_ev, p->d_evcount, p->max_ev, p->d_bch };
-    hipLaunchKernelGGL(pg_walk_kernel, dim3(C), dim3(64), 0, s, W);
+    hipLaunchKernelGGL(pg_walk_kernel, dim3(C), dim3(64 * PG_WALK_WAVES), 0, s, W);
     PG_TRY(hipGetLastError());
     p->total += n;
     p->last_stream = s;
