@@ -140,6 +140,18 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
  * submits them.  Returns as soon as the copy has been staged; never blocks longer than a memcpy. */
 int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples);
 
+/*
+ * Host ingest of 8-bit captures: the byte pairs are staged as they are (half the
+ * PCIe bytes of mfm_engine_push) and widened to int16 on the device exactly as the reference's front ends do on
+ * the host.  nr_samples IQ pairs = 2 * nr_samples bytes.
+ */
+#define MFM_IN_CS16 0       /* interleaved int16, same as mfm_engine_push (multifm/file_if.c:46-64) */
+#define MFM_IN_CS8 1        /* signed bytes, sign-extended (multifm/file_if.c:66-111) */
+#define MFM_IN_CU8 2        /* file_if's "cu8": bytes read as SIGNED, minus 127; after an odd number of samples the
+                               last one is stored without the subtraction (multifm/file_if.c:113-157) */
+#define MFM_IN_RTLSDR_U8 3  /* unsigned bytes, (b - 127) << 7 (multifm/rtl_sdr_if.c:146-158) */
+int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format);
+
 /* Oldest finished block, in submit order (blocks with zero outputs are skipped).  Waits for the
  * device.  MFM_E_DONE when nothing is pending.  The block stays valid until release(). */
 int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk);

@@ -608,3 +608,27 @@ void mfmo_resampler_quantize_taps(const double *taps, size_t n, int16_t *out)
         out[i] = (int16_t)(taps[i] * (double)(1 << MFMO_Q_SHIFT)); /* decoder/decoder.c:530-533 */
     }
 }
+
+/* ---- 8-bit ingest ---------------------------------------------------------------------------------------- */
+
+void mfmo_unpack_bytes(const uint8_t *in, size_t nr_bytes, int format, int16_t *out)
+{
+    if (format == 3) {
+        /* rtl_sdr_if.c:156-158 (the generic branch; the NEON branch computes the same values) */
+        for (size_t i = 0; i < nr_bytes; i++) {
+            out[i] = (int16_t)(((int16_t)in[i] - 127) << 7);
+        }
+        return;
+    }
+    const int8_t *sin = (const int8_t *)in; /* file_if.c:76,122: the bounce buffer is read through an int8_t pointer */
+    const size_t rem = nr_bytes % 4, body = nr_bytes - rem;
+    for (size_t i = 0; i < body; i++) {
+        out[i] = (format == 2) ? (int16_t)((int16_t)sin[i] - 127) : (int16_t)sin[i]; /* :91-96, :139-144 */
+    }
+    /* :98-102 / :146-150: the remainder is stored as a bare cast in BOTH formats.  (The 4-wide loop of the
+     * reference has already run over these elements and past the end of the read; its results there are
+     * overwritten here.) */
+    for (size_t i = body; i < nr_bytes; i++) {
+        out[i] = (int16_t)sin[i];
+    }
+}

@@ -154,6 +154,12 @@ void mfmo_dc_blocker_apply(struct mfmo_dc_blocker *b, int16_t *samples, size_t n
 /* decoder/decoder.c:530-533: double taps -> Q14 int16 by truncation */
 void mfmo_resampler_quantize_taps(const double *taps, size_t n, int16_t *out);
 
+/* ---- 8-bit ingest -------------------------------------------------------------
+ * format 1: multifm/file_if.c:66-111 (cs8: sign extension); 2: multifm/file_if.c:113-157 (cu8: bytes read as signed,
+ * minus 127, the remainder loop of :146-150 storing the bare cast); 3: multifm/rtl_sdr_if.c:146-158 ((u8 - 127) << 7).
+ * nr_bytes = bytes of ONE read (2 per sample); out receives nr_bytes int16 values. */
+void mfmo_unpack_bytes(const uint8_t *in, size_t nr_bytes, int format, int16_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,8 @@ def lib():
         o.mfmo_dc_blocker_apply.restype = None
         o.mfmo_resampler_quantize_taps.argtypes = [C.POINTER(C.c_double), C.c_size_t, _i16p]
         o.mfmo_resampler_quantize_taps.restype = None
+        o.mfmo_unpack_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _i16p]
+        o.mfmo_unpack_bytes.restype = None
         u32p = C.POINTER(C.c_uint32)
         o.mfmo_bch_tables.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
         o.mfmo_bch_tables.restype = None
@@ -334,3 +336,11 @@ class PocsagMsgDec:
 
     def __del__(self):
         self.close()
+
+
+def unpack_bytes(raw, fmt):
+    """one read of 8-bit samples -> int16, as file_if.c (fmt 1 cs8, 2 cu8) / rtl_sdr_if.c (fmt 3) widen it"""
+    a = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    out = np.zeros(a.size, np.int16)
+    lib().mfmo_unpack_bytes(a.ctypes.data, a.size, fmt, p16(out))
+    return out

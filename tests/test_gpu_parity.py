@@ -253,3 +253,57 @@ def test_full_size_block_properties(pkg, ora, kernel):
     small, _ = eng.run(iq, (1 << 20) - 77)
     eng.close()
     assert np.array_equal(big, small)
+
+
+def test_oracle_unpack_known_answers(ora):
+    """the reference's 8-bit widenings restated (file_if.c:66-157, rtl_sdr_if.c:146-158)."""
+    raw = np.array([0x7F, 0x80, 0xFF, 0x01, 0x00, 0x7F, 0x80, 0xFF], np.uint8)
+    assert list(ora.unpack_bytes(raw, 1)) == [127, -128, -1, 1, 0, 127, -128, -1]
+    assert list(ora.unpack_bytes(raw, 2)) == [0, -255, -128, -126, -127, 0, -255, -128]
+    assert list(ora.unpack_bytes(np.array([0, 127, 128, 255], np.uint8), 3)) == [-16256, 0, 128, 16384]
+    # three samples = 6 bytes: the last sample falls into the remainder loop and is stored as a bare cast
+    assert list(ora.unpack_bytes(raw[:6], 2)) == [0, -255, -128, -126, 0, 127]
+    assert list(ora.unpack_bytes(raw[:6], 1)) == [127, -128, -1, 1, 0, 127]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_gpu_ingest_of_8bit_formats(pkg, ora, fmt):
+    """mfm_engine_push_bytes: raw byte pairs over PCIe, widened on the device; PCM must equal the oracle run on the
+    reference's host-side widening of the same reads (odd and short block sizes included)."""
+    fs, decim = 1000000, 40
+    taps = pkg.synth.design_lpf(64, 12500.0, fs)
+    offs = [112500, -200000, 3125]
+    rng = np.random.RandomState(fmt)
+    sizes = [4096, 4095, 1, 7, 8, 9, 65536, 12345, 4096, 333]
+    n = sum(sizes)
+    raw = rng.randint(0, 256, size=(n, 2)).astype(np.uint8)
+    eng = pkg.Engine(fs, decim, 65536, device=0)
+    for o in offs:
+        eng.add_channel(int(o), taps, 1.0)
+    eng.commit()
+    pos, iq, got = 0, [], []
+    for m in sizes:
+        blk = raw[pos:pos + m]
+        iq.append(ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+        while True:
+            rc = eng.push_bytes(blk, fmt)
+            if rc == 0:
+                break
+            assert rc == pkg.binding.MFM_E_BUSY
+            got.append(eng.fetch()[1])
+        pos += m
+    eng.sync()
+    while True:
+        b = eng.fetch()
+        if b is None:
+            break
+        got.append(b[1])
+    eng.close()
+    iq = np.concatenate(iq)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[0] for o in offs])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[1] for o in offs])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    got = np.concatenate(got, axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)

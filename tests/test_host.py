@@ -145,10 +145,13 @@ def test_frame_pool_and_refcount_contract(host):
     assert host.frame_alloc_delete(C.byref(fa)) == 0
 
 
-def _run_multifm(tmp_path, pkg, fmt, iq16, raw_bytes, fs, decim, center, chans, taps_file, gains_db=None):
+def _run_multifm(tmp_path, pkg, fmt, iq16, raw_bytes, fs, decim, center, chans, taps_file, gains_db=None, gpu_unpack=None):
     cap = tmp_path / f"cap_{fmt}.bin"
     cap.write_bytes(raw_bytes)
-    cfg = {"device": {"type": "file", "filename": str(cap), "fileFormat": fmt}, "sampleRateHz": fs,
+    dev = {"type": "file", "filename": str(cap), "fileFormat": fmt}
+    if gpu_unpack is not None:
+        dev["gpuUnpack"] = gpu_unpack
+    cfg = {"device": dev, "sampleRateHz": fs,
            "centerFreqHz": center, "nrSampBufs": 32, "decimationFactor": decim, "channels": []}
     outs = []
     for i, f in enumerate(chans):
@@ -172,16 +175,17 @@ def _run_multifm(tmp_path, pkg, fmt, iq16, raw_bytes, fs, decim, center, chans, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt", ["cs16", "cs8", "cu8"])
-def test_multifm_driver_on_file_input(tmp_path, pkg, ora, fmt):
+@pytest.mark.parametrize("fmt,gpu_unpack", [("cs16", None), ("cs8", None), ("cu8", None), ("cs8", False), ("cu8", False)])
+def test_multifm_driver_on_file_input(tmp_path, pkg, ora, fmt, gpu_unpack):
     """BASELINE configs[0]: etc/multifm_1ch.json values (fs 1.0 MS/s, D 40, channel at +112.5 kHz) plus a second
     channel with dBGain, fed from a file through file_if's three sample formats; the FIFO byte streams must be
-    the oracle's PCM."""
+    the oracle's PCM.  8-bit formats are widened on the GPU by default and on the host with
+    "gpuUnpack": false; both must reproduce file_if.c, including the last sample of the odd-sized final read."""
     fs, decim, center = 1000000, 40, 929500000
     offs, gains_db = [112500, -200000], [None, 4.0]
     taps_file = os.path.join(ROOT, "etc", "lpf_25khz_1000k_128.json")
     taps = np.array(json.load(open(taps_file))["lpfTaps"])
-    n = 4096 * 37 + 1234  # last buffer is a partial one
+    n = 4096 * 37 + 1233  # last buffer is a partial one with an odd number of samples
     if fmt == "cs16":
         iq = pkg.synth.synth_iq(n, fs, offs, seed=91)
         raw = iq.tobytes()
@@ -189,10 +193,11 @@ def test_multifm_driver_on_file_input(tmp_path, pkg, ora, fmt):
         rng = np.random.RandomState(92)
         b = rng.randint(0, 256, size=(n, 2)).astype(np.uint8)
         raw = b.tobytes()
-        s8 = b.view(np.int8).astype(np.int16)
-        # file_if.c:92-96 (cs8: plain widening) and :139-143 (cu8: bytes read as SIGNED, minus 127)
-        iq = s8 if fmt == "cs8" else (s8 - 127).astype(np.int16)
-    pcm, q = _run_multifm(tmp_path, pkg, fmt, iq, raw, fs, decim, center, offs, taps_file, gains_db)
+        # file_if.c:66-157, one read of 4096 samples at a time
+        code = 1 if fmt == "cs8" else 2
+        iq = np.concatenate([ora.unpack_bytes(b[i:i + 4096], code) for i in range(0, n, 4096)]).reshape(-1, 2)
+        assert fmt == "cs8" or iq[-1, 0] == np.int8(b[-1, 0])  # the quirk: no -127 on the very last sample
+    pcm, q = _run_multifm(tmp_path, pkg, fmt, iq, raw, fs, decim, center, offs, taps_file, gains_db, gpu_unpack)
     gains = [1.0, 10.0 ** (4.0 / 10.0)]
     cre = np.stack([ora.make_taps(taps, o, fs, g)[0] for o, g in zip(offs, gains)])
     cim = np.stack([ora.make_taps(taps, o, fs, g)[1] for o, g in zip(offs, gains)])

@@ -16,12 +16,13 @@ MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_D
 MFM_ABI_VERSION = 1
 MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
+MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
 ABI_SYMBOLS = [
     "mfm_engine_input_bytes", "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
     "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
-    "mfm_engine_submit", "mfm_engine_push", "mfm_engine_fetch", "mfm_engine_release",
+    "mfm_engine_submit", "mfm_engine_push", "mfm_engine_push_bytes", "mfm_engine_fetch", "mfm_engine_release",
     "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
     "mfm_engine_stream", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
@@ -106,6 +107,7 @@ def load_library():
     lib.mfm_engine_acquire_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.mfm_engine_submit.argtypes = [vp, C.c_size_t, vp, C.c_int]
     lib.mfm_engine_push.argtypes = [vp, i16p, C.c_size_t]
+    lib.mfm_engine_push_bytes.argtypes = [vp, vp, C.c_size_t, C.c_int]
     lib.mfm_engine_fetch.argtypes = [vp, C.POINTER(Block)]
     lib.mfm_engine_release.argtypes = [vp]
     lib.mfm_engine_last_output_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t),
@@ -242,6 +244,12 @@ class Engine:
         """iq: int16 array of interleaved I,Q (2*n elements)."""
         a = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)
         return self.lib.mfm_engine_push(self.h, _i16p(a), a.size // 2)
+
+    def push_bytes(self, raw, fmt):
+        """raw: 8-bit IQ pairs as uint8/int8 (2*n elements) or int16 for MFM_IN_CS16; widened on the device."""
+        a = np.ascontiguousarray(raw).reshape(-1)
+        nr = a.size // 2
+        return self.lib.mfm_engine_push_bytes(self.h, a.ctypes.data, nr, fmt)
 
     def fetch(self):
         """Oldest finished block as (first_output, pcm[C][n] copy, iq[C][n][2] copy or None); None when drained."""

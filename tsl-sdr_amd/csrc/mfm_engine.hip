@@ -170,6 +170,7 @@ struct mfm_engine {
     uint32_t *d_in[2] = { nullptr, nullptr };
     bool own_in = false;
     uint32_t *h_in[2] = { nullptr, nullptr }; /* pinned, for push() */
+    uint16_t *d_raw[2] = { nullptr, nullptr }; /* push_bytes(): 8-bit IQ pairs as they came off the wire */
     hipEvent_t in_free[2] = { nullptr, nullptr };
     hipEvent_t in_ready = nullptr;
     int cur_in = 0;
@@ -234,6 +235,9 @@ void free_device(mfm_engine *e)
         if (e->own_in) {
             (void)hipFree(e->d_in[i]);
         }
+        if (e->d_raw[i]) {
+            (void)hipFree(e->d_raw[i]);
+        }
         if (e->h_in[i]) {
             (void)hipHostFree(e->h_in[i]);
         }
@@ -297,6 +301,59 @@ int write_state_fresh(mfm_engine *e)
     }
     e->parity = 0;
     return MFM_OK;
+}
+
+/*
+ * 8-bit ingest on the device.  The reference widens 8-bit captures to int16 on the
+ * host before anything else sees them: cs8 is a plain sign extension (multifm/file_if.c:91-103); cu8 reads the
+ * bytes as SIGNED and subtracts 127 (:122,:139-151; after an odd number of samples the last one misses the
+ * subtraction, :146-150); the RTL-SDR front end computes (u8 - 127) << 7 (multifm/rtl_sdr_if.c:146-158).
+ * Here the raw byte pairs cross PCIe (half the bytes) and are widened where the channel kernel will read them.
+ * HBM-bound: 2 bytes in, 4 bytes out per sample; one lane handles 8 samples (16 B in, 2 x 16 B out).
+ */
+__device__ __forceinline__ uint32_t mfm_widen_pair(uint32_t two_bytes, int format)
+{
+    int32_t a, b;
+    if (format == MFM_IN_RTLSDR_U8) {
+        a = (((int32_t)(two_bytes & 0xffu)) - 127) * 128;
+        b = (((int32_t)((two_bytes >> 8) & 0xffu)) - 127) * 128;
+    } else {
+        a = (int8_t)(two_bytes & 0xffu);
+        b = (int8_t)((two_bytes >> 8) & 0xffu);
+        if (format == MFM_IN_CU8) {
+            a -= 127;
+            b -= 127;
+        }
+    }
+    return mfm_pack16(a, b);
+}
+
+__global__ __launch_bounds__(256) void mfm_unpack_kernel(const uint16_t *raw, uint32_t *dst, uint32_t nr_samples, int format)
+{
+    const uint32_t ngroups = nr_samples / 8;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4 *>(raw)[g];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[2 * k] = mfm_widen_pair(w[k] & 0xffffu, format);
+            o[2 * k + 1] = mfm_widen_pair(w[k] >> 16, format);
+        }
+        reinterpret_cast<uint4 *>(dst)[2 * g] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4 *>(dst)[2 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    /* the last nr_samples % 8, one lane each */
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = ngroups * 8 + t;
+    if (s < nr_samples) {
+        uint32_t out = mfm_widen_pair(raw[s], format);
+        if (format == MFM_IN_CU8 && (nr_samples & 1u) && s == nr_samples - 1) {
+            const uint32_t two = raw[s]; /* file_if.c:146-150: the remainder loop stores the bare cast */
+            out = mfm_pack16((int8_t)(two & 0xffu), (int8_t)(two >> 8));
+        }
+        dst[s] = out;
+    }
 }
 
 } /* namespace */
@@ -989,6 +1046,55 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
     /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
     memcpy(e->h_in[cur], iq, nr_samples * 4);
     HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
+    return mfm_engine_submit(e, nr_samples, e->s_in, 1);
+}
+
+int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format)
+{
+    if (!e || !bytes) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (format == MFM_IN_CS16) {
+        return mfm_engine_push(e, static_cast<const int16_t *>(bytes), nr_samples);
+    }
+    if (format != MFM_IN_CS8 && format != MFM_IN_CU8 && format != MFM_IN_RTLSDR_U8) {
+        return fail(MFM_E_INVAL, "unknown sample format %d", format);
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (0 == nr_samples || nr_samples > e->cfg.max_block_samples) {
+        return fail(MFM_E_INVAL, "block of %zu samples (max %u)", nr_samples, e->cfg.max_block_samples);
+    }
+    if (!(e->cfg.flags & MFM_F_DEVICE_ONLY)) {
+        std::lock_guard<std::mutex> guard(e->mu);
+        const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
+        if (n_avail >= e->nr_taps && e->slots[e->submit_seq % e->nslots].state != OutSlot::FREE) {
+            return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
+        }
+    }
+    void *dst = nullptr;
+    size_t cap = 0;
+    int rc = mfm_engine_acquire_input(e, &dst, &cap);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    const int cur = e->cur_in;
+    if (!e->h_in[cur]) {
+        HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cfg.max_block_samples * 4, hipHostMallocDefault));
+    }
+    if (!e->d_raw[cur]) {
+        HIP_TRY(hipMalloc(&e->d_raw[cur], (size_t)e->cfg.max_block_samples * 2 + 16));
+    }
+    /* acquire_input() waited for the kernel that consumed this pair; the unpack kernel of the previous use of
+     * d_raw[cur] ran before that kernel on the same stream order */
+    memcpy(e->h_in[cur], bytes, nr_samples * 2);
+    HIP_TRY(hipMemcpyAsync(e->d_raw[cur], e->h_in[cur], nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
+    uint32_t blocks = (uint32_t)((nr_samples / 8 + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(mfm_unpack_kernel, dim3(blocks), dim3(256), 0, e->s_in, e->d_raw[cur], static_cast<uint32_t *>(dst),
+                       (uint32_t)nr_samples, format);
+    HIP_TRY(hipGetLastError());
     return mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 

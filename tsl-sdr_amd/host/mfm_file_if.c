@@ -5,7 +5,7 @@
  * cs16|cs8|cu8}; 4096 complex samples per buffer (:18); cs16 is read straight into the buffer (:46-64);
  * cs8 / cu8 go through a bounce buffer and are widened to int16 (:66-157).  Two quirks of the reference
  * are kept because they are behaviour: cu8 treats the bytes as SIGNED before subtracting 127
- * (:122,:140), and no pacing is applied (time_per_buf_ns is never set, :197).  One is not: at end of file
+ * (:122,:140) and skips the subtraction for the last sample of an odd-sized final read (:146-150), and no pacing is applied (time_per_buf_ns is never set, :197).  One is not: at end of file
  * the reference delivers a 0-sample buffer and aborts on TSL_BUG_ON (receiver.c:84); here the front end
  * marks the input done and stops.
  */
@@ -31,6 +31,7 @@ struct file_worker_thread {
     enum file_worker_sample_format sample_format;
     void *bounce_buf;
     size_t bounce_buf_bytes;
+    bool gpu_unpack; /* device stanza "gpuUnpack" (default true): widen 8-bit formats on the GPU */
 };
 
 /* read until `want` bytes or end of file (a pipe may return short reads) */
@@ -68,6 +69,15 @@ static aresult_t _file_fill(struct file_worker_thread *thr, struct sample_buf *s
         return A_OK;
     }
 
+    if (thr->gpu_unpack) {
+        /* hand the bytes over as they are; the engine widens them on the device (half the PCIe traffic) */
+        if (FAILED(_file_read_full(thr->fd, sbuf->data_buf, thr->bounce_buf_bytes, &nr_read))) {
+            return A_E_INVAL;
+        }
+        sbuf->sample_type = thr->sample_format == FILE_WORKER_SAMPLE_FORMAT_S8 ? RAW_COMPLEX_INT_8 : RAW_COMPLEX_FILE_UINT_8;
+        sbuf->nr_samples = (uint32_t)(nr_read / 2);
+        return A_OK;
+    }
     if (FAILED(_file_read_full(thr->fd, thr->bounce_buf, thr->bounce_buf_bytes, &nr_read))) {
         return A_E_INVAL;
     }
@@ -77,8 +87,13 @@ static aresult_t _file_fill(struct file_worker_thread *thr, struct sample_buf *s
             out[i] = in[i];
         }
     } else {
-        for (size_t i = 0; i < nr_read; i++) {
+        /* the reference's remainder loop stores the last nr_read % 4 values without the subtraction (:146-150) */
+        const size_t body = nr_read - nr_read % 4;
+        for (size_t i = 0; i < body; i++) {
             out[i] = (int16_t)((int16_t)in[i] - 127);
+        }
+        for (size_t i = body; i < nr_read; i++) {
+            out[i] = in[i];
         }
     }
     sbuf->nr_samples = (uint32_t)(nr_read / 2);
@@ -168,6 +183,8 @@ aresult_t file_worker_thread_new(struct receiver **pthr, struct config *cfg)
     }
     thr->fd = fd;
     thr->sample_format = sample_format;
+    thr->gpu_unpack = true;
+    (void)config_get_boolean(&devcfg, &thr->gpu_unpack, "gpuUnpack");
     if (sample_format != FILE_WORKER_SAMPLE_FORMAT_S16) {
         thr->bounce_buf_bytes = SAMPLES_PER_BUF * 2 * sizeof(int8_t);
         if (FAILED(ret = TACALLOC(&thr->bounce_buf, SAMPLES_PER_BUF, 2 * sizeof(int8_t), SYS_CACHE_LINE_LENGTH))) {

@@ -235,7 +235,20 @@ aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *bu
      * buffer goes back to the pool right away. */
     atomic_store((_Atomic uint32_t *)&buf->refcount, 1);
     for (;;) {
-        int rc = mfm_engine_push(rx->engine, (const int16_t *)buf->data_buf, buf->nr_samples);
+        int rc;
+        switch (buf->sample_type) {
+        case RAW_COMPLEX_INT_8:
+            rc = mfm_engine_push_bytes(rx->engine, buf->data_buf, buf->nr_samples, MFM_IN_CS8);
+            break;
+        case RAW_COMPLEX_FILE_UINT_8:
+            rc = mfm_engine_push_bytes(rx->engine, buf->data_buf, buf->nr_samples, MFM_IN_CU8);
+            break;
+        case RAW_COMPLEX_RTLSDR_UINT_8:
+            rc = mfm_engine_push_bytes(rx->engine, buf->data_buf, buf->nr_samples, MFM_IN_RTLSDR_U8);
+            break;
+        default:
+            rc = mfm_engine_push(rx->engine, (const int16_t *)buf->data_buf, buf->nr_samples);
+        }
         if (MFM_OK == rc) {
             break;
         }

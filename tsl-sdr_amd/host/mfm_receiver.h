@@ -29,6 +29,11 @@ enum sample_type {
     COMPLEX_INT_16 = 3,
     REAL_UINT_32 = 4,
     COMPLEX_UINT_32 = 5,
+    /* not in the reference: data_buf holds 8-bit IQ pairs exactly as a front end received them; the engine widens
+     * them on the GPU the way that front end would have on the host (mfm_engine_push_bytes, MFM_IN_*) */
+    RAW_COMPLEX_INT_8 = 101,       /* file_if "cs8" */
+    RAW_COMPLEX_FILE_UINT_8 = 102, /* file_if "cu8" */
+    RAW_COMPLEX_RTLSDR_UINT_8 = 103,
 };
 
 struct sample_buf;
