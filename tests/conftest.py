@@ -14,6 +14,13 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
+    # Let torch bring the HIP runtime up before the engine library does: a test that imports torch after the
+    # library has created its streams has been seen to get "No HIP GPUs are available" from torch on the GPU box.
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     from __graft_entry__ import load_package
     return load_package()
 

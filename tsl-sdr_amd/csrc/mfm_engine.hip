@@ -556,13 +556,16 @@ int mfm_engine_commit(struct mfm_engine *e)
     e->nslices = (e->ngroups + e->gpw - 1) / e->gpw;
     e->cap_in = input_capacity(e->cfg.max_block_samples, T);
     e->out_stride = ((e->cap_in - T) / D + 1 + 1) & ~1u;
-    if ((uint64_t)C * e->out_stride >= (1ull << 31)) {
-        return fail(MFM_E_INVAL, "channels x outputs per block = %llu exceeds 2^31 (use smaller blocks)",
-                    (unsigned long long)C * e->out_stride);
-    }
     e->any_iq = false;
     for (const Channel &c : e->chans) {
         e->any_iq |= c.want_iq;
+    }
+    /* the kernels address outputs with 32-bit byte offsets from the buffer base: 2 bytes per PCM sample, 4 per
+     * filtered-IQ sample, plus the dump slots behind the last row */
+    const uint64_t out_limit = e->any_iq ? (1ull << 30) : (1ull << 31);
+    if ((uint64_t)C * e->out_stride + 64 >= out_limit) {
+        return fail(MFM_E_INVAL, "channels x outputs per block = %llu exceeds %llu (use smaller blocks)",
+                    (unsigned long long)C * e->out_stride, (unsigned long long)out_limit);
     }
 
     /* ---- tap table: [group][chunk][tap in chunk][channel in group]{(cr,-ci),(ci,cr)} ---- */
@@ -800,9 +803,11 @@ int mfm_engine_commit(struct mfm_engine *e)
     for (int i = 0; i < e->nslots; i++) {
         OutSlot &s = e->slots[i];
         const size_t pcm_bytes = (size_t)C * e->out_stride * sizeof(int16_t);
-        HIP_TRY(hipMalloc(&s.d_pcm, pcm_bytes));
+        /* + a dump slot per lane behind the last channel row: the MFMA kernel stores unconditionally and sends
+         * what is not an output there */
+        HIP_TRY(hipMalloc(&s.d_pcm, pcm_bytes + 64 * sizeof(int16_t)));
         if (e->any_iq) {
-            HIP_TRY(hipMalloc(&s.d_iq, pcm_bytes * 2));
+            HIP_TRY(hipMalloc(&s.d_iq, pcm_bytes * 2 + 64 * sizeof(uint32_t)));
         }
         if (!dev_only) {
             HIP_TRY(hipHostMalloc(&s.h_pcm, pcm_bytes, hipHostMallocDefault));

@@ -39,7 +39,6 @@
 #include "mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
-typedef short mfm_s2 __attribute__((ext_vector_type(2)));
 
 #define MFM_M_NT (MFM_MFMA_NW * 64)
 
@@ -65,15 +64,54 @@ typedef short mfm_s2 __attribute__((ext_vector_type(2)));
 #define MFM_M_ITERS 2 /* iterations per tile: a tile is 62 new outputs */
 #define MFM_M_CH 4    /* 16-byte staging chunks a thread owns per tile (>= ceil(samples/4/512)) */
 
-static __device__ __forceinline__ int mfm_dot2m(uint32_t a, uint32_t b, int c)
+/* 4 * ((hh << 16) + (md << 8) + ll): the recombined sum (K + 8192 ride in through ll) times 4, so that bits 29:14
+ * (round_q30_q15 + int16 truncation) land in the upper half-word */
+static __device__ __forceinline__ uint32_t mfm_combine_x4(int hh, int md, int ll)
 {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(mfm_s2, a), __builtin_bit_cast(mfm_s2, b), c, false);
+    /* two v_lshl_add_u32 and a shift (written out as three shifts the compiler spends four instructions) */
+    return (((((uint32_t)hh << 8) + (uint32_t)md) << 8) + (uint32_t)ll) << 2;
 }
 
-/* (hh << 16) + (md << 8) + ll: the recombined sum, already carrying K + 8192 through ll */
-static __device__ __forceinline__ uint32_t mfm_combine(int hh, int md, int ll)
+/* upper half-words of two dwords as (re | im << 16): one v_perm_b32 */
+static __device__ __forceinline__ uint32_t mfm_pack_hi(uint32_t re_x4, uint32_t im_x4)
 {
-    return ((((uint32_t)hh << 8) + (uint32_t)md) << 8) + (uint32_t)ll;
+    return __builtin_amdgcn_perm(im_x4, re_x4, 0x07060302u);
+}
+
+/*
+ * o = f * r + 8192 for a packed complex f and the two packed rotator operands: two VOP3P v_dot2_i32_i16 with the
+ * bias as an SGPR operand.  The builtin compiles to v_dot2c_i32_i16, which needs its accumulator preloaded by a
+ * v_mov.  The compiler does not pad hazards around inline asm, so the 3 wait states a DOT result needs before
+ * another VALU instruction reads it are part of the block.
+ */
+static __device__ __forceinline__ void mfm_rotate_biased(uint32_t f, uint2 r, uint32_t *o_re, uint32_t *o_im)
+{
+    asm("v_dot2_i32_i16 %0, %2, %3, %5\n\tv_dot2_i32_i16 %1, %2, %4, %5\n\ts_nop 2"
+        : "=&v"(*o_re), "=&v"(*o_im)
+        : "v"(f), "v"(r.x), "v"(r.y), "s"(8192));
+}
+
+/* s = q * conj(p) (multifm/fm_demod.c:55-64), wrapping int32: s_re by dot2, the two cross products by
+ * v_mad_i32_i16 with op_sel; same hazard padding as above (two instructions + s_nop 0 after the DOT) */
+static __device__ __forceinline__ void mfm_conj_mul(uint32_t q, uint32_t p, int *s_re, int *s_im)
+{
+    int u, t;
+    asm("v_dot2_i32_i16 %0, %3, %4, 0\n\t"
+        "v_mad_i32_i16 %1, %3, %4, 0 op_sel:[1,0,0,0]\n\t"
+        "v_mad_i32_i16 %2, %3, %4, 0 op_sel:[0,1,0,0]\n\t"
+        "s_nop 0"
+        : "=&v"(*s_re), "=&v"(u), "=&v"(t)
+        : "v"(q), "v"(p));
+    *s_im = (int)((uint32_t)u - (uint32_t)t); /* q_im*p_re - q_re*p_im */
+}
+
+/* Launder a value the compiler would otherwise use to hoist address arithmetic of rarely executed code (slice
+ * change, first / last tile of a pass) out of the tile loop: those 64-bit addresses then sit in VGPRs for the whole
+ * loop and push hot values into scratch, and every scratch reload is a VMEM access that costs a vmcnt(0). */
+static __device__ __forceinline__ uint32_t mfm_opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 /* bits 29:14 of two biased sums packed as (re | im << 16): round_q30_q15 + int16 truncation */
@@ -109,14 +147,15 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
     const uint32_t buf_bytes = 2u * L.plane_bytes; /* one staging buffer = H plane + L plane */
-    const float2 *lut = reinterpret_cast<const float2 *>(smem + L.lut_off);
+    const float *lut_t = reinterpret_cast<const float *>(smem + L.lut_off), *lut_d = lut_t + 256;
 
-    /* atan LUT: 256 x {T[i], T[i+1]-T[i]}, once per workgroup (its LDS region is never restaged) */
+    /* atan LUT, once per workgroup (its LDS region is never restaged): global {T[i], T[i+1]-T[i]} pairs are
+     * split into T[256] followed by dT[256] so that a look-up is two ds_read_b32 into the halves of register pairs */
     {
         uint32_t *lut_s = reinterpret_cast<uint32_t *>(smem + L.lut_off);
         const uint32_t *lut_g = reinterpret_cast<const uint32_t *>(L.lut);
         for (uint32_t i = tid; i < 512; i += MFM_M_NT) {
-            lut_s[i] = lut_g[i];
+            lut_s[(i >> 1) + ((i & 1u) << 8)] = lut_g[i];
         }
     }
 
@@ -145,7 +184,8 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         int gs = (int)(tile * L.ot * D) + (4 * (int)(tid + (uint32_t)j * MFM_M_NT) - (int)D);
         gs = gs < 0 ? 0 : gs;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
-        return *reinterpret_cast<const uint4 *>(L.x + (uint32_t)gs);
+        /* uniform base + 32-bit byte offset: one VGPR of address instead of a 64-bit pair */
+        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
         if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
@@ -210,6 +250,24 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     __syncthreads();
     MFM_STAMP(2);
 
+    /* Vector memory in this loop is straight-line code: every load and store below is issued on every path
+     * (row blocks past the end are clamped, outputs that must not be written go to a dump slot behind the output
+     * buffer, staging runs even when there is no next tile).  s_waitcnt vmcnt is one in-order counter; with
+     * loads or stores under branches the compiler cannot count what is in flight and falls back to vmcnt(0) in
+     * front of every reuse of a register - which put the full store round trip on the critical path several
+     * times per iteration.  The rotator entries of iteration i+1 are requested right after the epilogue of
+     * iteration i, ahead of its PCM stores, so waiting for them never waits for those stores. */
+    auto rot_load = [&](const uint32_t koff[2], uint32_t it, uint2 out[2][2]) {
+        const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            out[0][c] = *reinterpret_cast<const uint2 *>(rot_it + koff[c]);
+            out[1][c] = *reinterpret_cast<const uint2 *>(rot_it + koff[c] + 16u * 8u);
+        }
+    };
+    uint2 rv[2][2];
+    rot_load(k_off, 0, rv);
+
     uint32_t cur = 0;
     while (have) {
         /* the tile after this one (persistent loop, stride = grid) is staged while this one computes */
@@ -219,37 +277,36 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
         const uint32_t rb = slice * MFM_MFMA_NW + wave; /* this wave's block of 16 rows = 8 channels */
         const bool rb_valid = rb < L.nrb;
-        const uint32_t ch0 = rb * 8u + 2u * kg;        /* this lane's channels: ch0 (regs 0,1), ch0+1 (regs 2,3) */
+        const uint32_t rbc = rb_valid ? rb : L.nrb - 1u; /* a wave past the last row block recomputes it, stores nothing */
+        const uint32_t ch0 = rbc * 8u + 2u * kg;       /* this lane's channels: ch0 (regs 0,1), ch0+1 (regs 2,3) */
         const int rel_first = (int)(tile * L.ot) - 1;  /* output index (this pass) of column 0 */
+        const bool last_tile = (tile + 1u) * L.ot >= L.n_new; /* holds output n_new - 1 */
 
         if (slice != slice_loaded) {
-            if (rb_valid) {
-                /* A operand: 16 rows x (64*KQ) elements, both byte planes, already in fragment order */
-                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rb * KQ * 2 * 64 + lane;
+            /* A operand: 16 rows x (64*KQ) elements, both byte planes, already in fragment order */
+            const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rbc * KQ * 2 * 64 + mfm_opaque(lane);
 #pragma unroll
-                for (int kq = 0; kq < KQ; kq++) {
-                    a_h[kq] = ap[(kq * 2 + 0) * 64];
-                    a_l[kq] = ap[(kq * 2 + 1) * 64];
-                }
-                /* 128 * sum_k W[row][k] + 8192 for rows 4kg..4kg+3 */
-                krow = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rb * 16 + 4 * kg);
-                /* settle these loads now: they stay live across the whole tile loop, and without this the
-                 * compiler waits vmcnt(0) at their first use in every iteration - which would also drain
-                 * the next tile's prefetch loads in the middle of the matrix work */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int kq = 0; kq < KQ; kq++) {
-                    asm volatile("" : "+v"(a_h[kq]), "+v"(a_l[kq]));
-                }
-                asm volatile("" : "+v"(krow));
+            for (int kq = 0; kq < KQ; kq++) {
+                a_h[kq] = ap[(kq * 2 + 0) * 64];
+                a_l[kq] = ap[(kq * 2 + 1) * 64];
             }
+            /* 128 * sum_k W[row][k] + 8192 for rows 4kg..4kg+3 */
+            krow = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rbc * 16 + 4 * mfm_opaque(kg));
+            /* settle these loads now: they stay live across the whole tile loop, and without this the
+             * compiler waits vmcnt(0) at their first use in every iteration */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kq = 0; kq < KQ; kq++) {
+                asm volatile("" : "+v"(a_h[kq]), "+v"(a_l[kq]));
+            }
+            asm volatile("" : "+v"(krow));
             slice_loaded = slice;
         }
 
-        uint32_t k_off_n[2] = { 0, 0 };
+        uint32_t k_off_n[2] = { k_off[0], k_off[1] };
         if (have_n) {
             const uint32_t rb_n = slice_n * MFM_MFMA_NW + wave;
-            rot_offsets(tile_n, rb_n * 8u + 2u * kg, rb_n < L.nrb, k_off_n);
+            rot_offsets(tile_n, (rb_n < L.nrb ? rb_n : L.nrb - 1u) * 8u + 2u * kg, true, k_off_n);
         }
 
         const uint8_t *plane_h = smem + cur * buf_bytes, *plane_l = plane_h + L.plane_bytes;
@@ -260,153 +317,158 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         if (tile == 0) {
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const uint32_t chn = ch0 + c;
-                carry[c] = L.st_in[(rb_valid && chn < L.nchan) ? chn : 0u].carry_q;
+                const uint32_t chn = mfm_opaque(ch0) + c;
+                carry[c] = L.st_in[chn < L.nchan ? chn : 0u].carry_q;
             }
         }
 
 #pragma unroll
         for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
-            /* Vector-memory order matters (vmcnt is one in-order counter): first the rotator entries of
-             * this iteration's columns (L2 hits, needed right after the matrix work; their addresses do not
-             * depend on data), then this iteration's share of the next tile's input (HBM, needed only at
-             * the end of the iteration) - waiting for the former then leaves the latter in flight.  The
-             * barrier pins VMEM order only; everything else may still be scheduled across it. */
-            const uint8_t *rot_it = reinterpret_cast<const uint8_t *>(L.rot) + (size_t)it * MFM_M_NEW * 8u;
-            uint2 rv[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                rv[0][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c]);
-                rv[1][c] = *reinterpret_cast<const uint2 *>(rot_it + k_off[c] + 16u * 8u);
-            }
-            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
-            /* unconditional (a workgroup's last tile re-reads its own samples and discards them): a load
-             * under a run-time condition cannot be counted, and the wait for the rotator entries above
-             * would degrade to vmcnt(0) */
+            /* this iteration's share of the next tile's input (a workgroup's last tile re-reads its own samples
+             * and stages them into the idle buffer) */
             uint4 pre[MFM_M_CH / MFM_M_ITERS];
 #pragma unroll
             for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
                 pre[u] = stage_load(have_n ? tile_n : tile, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
             }
 
+            /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
+            mfm_v4i hh[2], md[2], ll[2];
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) {
+                hh[gq] = mfm_v4i{ 0, 0, 0, 0 };
+                md[gq] = mfm_v4i{ 0, 0, 0, 0 };
+                ll[gq] = krow;
+            }
+            const uint32_t ibase = it * MFM_M_NEW * rs;
+#pragma unroll
+            for (int kq = 0; kq < KQ; kq++) {
+                mfm_v4i b_h[2], b_l[2];
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    const uint32_t at = ibase + boff[kq] + (uint32_t)gq * 16u * rs;
+                    b_h[gq] = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
+                    b_l[gq] = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
+                }
+                hh[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[0], hh[0], 0, 0, 0);
+                hh[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[1], hh[1], 0, 0, 0);
+                md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[0], md[0], 0, 0, 0);
+                md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[1], md[1], 0, 0, 0);
+                ll[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[0], ll[0], 0, 0, 0);
+                ll[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[1], ll[1], 0, 0, 0);
+                md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[0], md[0], 0, 0, 0);
+                md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[1], md[1], 0, 0, 0);
+            }
+            /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) has been seen to leave the
+             * MFMA -> VALU read hazard unpadded here (caught by the parity tests: tile 0 passed, later tiles did
+             * not).  16 wait states cover a 16x16x64 MFMA. */
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFM_STAMP(6);
+
+            /* ---- epilogue: lane (kg, n) holds channels ch0, ch0+1 for columns n (group 0) and 16+n
+             *      (group 1); written in phases so the four independent chains interleave ---- */
             uint32_t q[2][2];
             int pcm[2][2];
-            if (rb_valid) {
-                /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
-                mfm_v4i hh[2], md[2], ll[2];
 #pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-                    hh[gq] = mfm_v4i{ 0, 0, 0, 0 };
-                    md[gq] = mfm_v4i{ 0, 0, 0, 0 };
-                    ll[gq] = krow;
-                }
-                const uint32_t ibase = it * MFM_M_NEW * rs;
-#pragma unroll
-                for (int kq = 0; kq < KQ; kq++) {
-                    mfm_v4i b_h[2], b_l[2];
-#pragma unroll
-                    for (int gq = 0; gq < 2; gq++) {
-                        const uint32_t at = ibase + boff[kq] + (uint32_t)gq * 16u * rs;
-                        b_h[gq] = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
-                        b_l[gq] = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
-                    }
-                    hh[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[0], hh[0], 0, 0, 0);
-                    hh[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[1], hh[1], 0, 0, 0);
-                    md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[0], md[0], 0, 0, 0);
-                    md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[1], md[1], 0, 0, 0);
-                    ll[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[0], ll[0], 0, 0, 0);
-                    ll[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[1], ll[1], 0, 0, 0);
-                    md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[0], md[0], 0, 0, 0);
-                    md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[1], md[1], 0, 0, 0);
-                }
-                /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) pads the MFMA -> VALU
-                 * read hazard inside a basic block but not across a branch it places here, and the first
-                 * reads then see the accumulator before the last v_mfma retired (caught by the parity
-                 * tests: tile 0 passed, later tiles did not).  16 wait states cover a 16x16x64 MFMA. */
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                MFM_STAMP(6);
-
-                /* ---- epilogue: lane (kg, n) holds channels ch0, ch0+1 for columns n (group 0) and 16+n
-                 *      (group 1); written in phases so the four independent chains interleave ---- */
-#pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        /* a + 8192 (mod 2^32); r14(a) truncated to int16 is bits 29:14 (filter/complex.h:30-34) */
-                        const uint32_t a_re = mfm_combine(hh[gq][2 * c], md[gq][2 * c], ll[gq][2 * c]);
-                        const uint32_t a_im = mfm_combine(hh[gq][2 * c + 1], md[gq][2 * c + 1], ll[gq][2 * c + 1]);
-                        const uint32_t f = mfm_round_pack(a_re, a_im);
-                        /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
-                        const uint32_t o_re = (uint32_t)mfm_dot2m(f, rv[gq][c].x, 8192);
-                        const uint32_t o_im = (uint32_t)mfm_dot2m(f, rv[gq][c].y, 8192);
-                        q[gq][c] = mfm_round_pack(o_re, o_im);
-                    }
-                }
-                if (it == 0) {
-                    /* column 0 of the pass is the last filtered sample of the previous pass (a select, not
-                     * a branch: see the hazard note above) */
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        q[0][c] = use_carry ? carry[c] : q[0][c];
-                    }
-                }
+            for (int gq = 0; gq < 2; gq++) {
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    /* previous output of the same channel: the lane to the left; column 16's is column 15 */
-                    const uint32_t p0 =
-                        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[0][c], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-                    const int wrap = __builtin_amdgcn_update_dpp(0, (int)q[0][c], 0x121 /* row_ror:1 */, 0xf, 0xf, false);
-                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(wrap, (int)q[1][c], 0x111 /* row_shr:1 */,
-                                                                              0xf, 0xf, false);
-                    const uint32_t pp[2] = { p0, p1 };
-#pragma unroll
-                    for (int gq = 0; gq < 2; gq++) {
-                        /* multifm/fm_demod.c:55-64: s = q * conj(p), wrapping int32 */
-                        const int s_re = mfm_dot2m(q[gq][c], pp[gq], 0);
-                        int u, t;
-                        asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(u) : "v"(q[gq][c]), "v"(pp[gq]));
-                        asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[0,1,0,0]" : "=v"(t) : "v"(q[gq][c]), "v"(pp[gq]));
-                        const int s_im = (int)((uint32_t)u - (uint32_t)t); /* q_im*p_re - q_re*p_im */
-                        pcm[gq][c] = mfm_discriminate(s_re, s_im, lut);
-                    }
+                    /* 4 * (a + 8192) (mod 2^32); r14(a) truncated to int16 is bits 29:14 of a + 8192
+                     * (filter/complex.h:30-34), i.e. the upper half-word here */
+                    const uint32_t a_re = mfm_combine_x4(hh[gq][2 * c], md[gq][2 * c], ll[gq][2 * c]);
+                    const uint32_t a_im = mfm_combine_x4(hh[gq][2 * c + 1], md[gq][2 * c + 1], ll[gq][2 * c + 1]);
+                    const uint32_t f = mfm_pack_hi(a_re, a_im);
+                    /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
+                    uint32_t o_re, o_im;
+                    mfm_rotate_biased(f, rv[gq][c], &o_re, &o_im);
+                    q[gq][c] = mfm_round_pack(o_re, o_im);
                 }
             }
-
-            /* the prefetched samples go to the other staging buffer before this iteration's PCM stores are
-             * issued, so the wait for them does not also wait for those stores */
-            if (have_n) {
+            if (it == 0) {
+                /* column 0 of the pass is the last filtered sample of the previous pass */
 #pragma unroll
-                for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
-                    stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
+                for (int c = 0; c < 2; c++) {
+                    q[0][c] = use_carry ? carry[c] : q[0][c];
                 }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                /* previous output of the same channel: the lane to the left; column 16's is column 15.
+                 * bound_ctrl: lanes without a source read 0 and no "old" value has to be set up (column 0 of
+                 * group 0 is never stored, so what its lane gets does not matter) */
+                const uint32_t p0 =
+                    (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[0][c], 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+                const int wrap = __builtin_amdgcn_update_dpp(0, (int)q[0][c], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(wrap, (int)q[1][c], 0x111 /* row_shr:1 */,
+                                                                          0xf, 0xf, false);
+                const uint32_t pp[2] = { p0, p1 };
+                int s_re[2], s_im[2], out[2];
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    mfm_conj_mul(q[gq][c], pp[gq], &s_re[gq], &s_im[gq]);
+                }
+                mfm_discriminate2(s_re, s_im, lut_t, lut_d, out);
+                pcm[0][c] = out[0];
+                pcm[1][c] = out[1];
+            }
+
+            /* rotator entries of the next iteration (of the next tile after the last one) */
+            uint2 rvn[2][2];
+            if (it + 1 < MFM_M_ITERS) {
+                rot_load(k_off, it + 1, rvn);
+            } else {
+                rot_load(k_off_n, 0, rvn);
             }
             __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
 
-            if (rb_valid) {
+            /* the prefetched samples go to the other staging buffer */
+#pragma unroll
+            for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
+                stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
+            }
+            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
+
+            /* PCM: every lane stores its four values; the ones that are not outputs (column 0 of group 0, columns
+             * past n_new, channels past the end) go to the dump slot */
+            const uint32_t dump = L.nchan * L.out_stride + lane;
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) {
+                const int rel = rel_first + (int)(it * MFM_M_NEW + 16u * gq + n);
+                const bool col_ok = rb_valid && (gq != 0 || n != 0) && (rel < (int)L.n_new);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t chn = ch0 + c;
+                    const bool ok = col_ok && chn < L.nchan;
+                    const uint32_t at = ok ? chn * L.out_stride + (uint32_t)rel : dump; /* fits 32 bits (engine checks) */
+                    *reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + (at << 1)) = (int16_t)pcm[gq][c];
+                    if (DBG_IQ) {
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + (at << 2)) = q[gq][c];
+                    }
+                }
+            }
+            if (last_tile) {
+                /* the one sample the next pass starts from */
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) {
                     const int rel = rel_first + (int)(it * MFM_M_NEW + 16u * gq + n);
-                    const bool store_ok = (gq != 0 || n != 0) && (rel < (int)L.n_new);
-                    if (store_ok) {
 #pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            const uint32_t chn = ch0 + c;
-                            if (chn < L.nchan) {
-                                const uint32_t at = chn * L.out_stride + (uint32_t)rel; /* fits 32 bits (engine checks) */
-                                L.pcm[at] = (int16_t)pcm[gq][c];
-                                if (DBG_IQ) {
-                                    L.iq_dbg[at] = q[gq][c];
-                                }
-                                if (rel == (int)L.n_new - 1) {
-                                    L.st_out[chn].carry_q = q[gq][c];
-                                }
-                            }
+                    for (int c = 0; c < 2; c++) {
+                        const uint32_t chn = mfm_opaque(ch0) + c;
+                        if (rb_valid && (gq != 0 || n != 0) && rel == (int)L.n_new - 1 && chn < L.nchan) {
+                            L.st_out[chn].carry_q = q[gq][c];
                         }
                     }
                 }
-                MFM_STAMP(7);
+            }
+            MFM_STAMP(7);
+#pragma unroll
+            for (int gq = 0; gq < 2; gq++) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    rv[gq][c] = rvn[gq][c];
+                }
             }
         }
 
@@ -414,7 +476,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             /* rotator index of the next pass's first output, one lane per channel pair */
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const uint32_t chn = ch0 + c;
+                const uint32_t chn = mfm_opaque(ch0) + c;
                 if (chn < L.nchan) {
                     const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chn * 8;
                     const uint32_t mu = ip[2], lam = ip[3], lam_magic = ip[4];

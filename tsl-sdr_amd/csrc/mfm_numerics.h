@@ -116,16 +116,31 @@ MFM_HD int32_t mfm_discriminate(int32_t s_re, int32_t s_im, MFM_LUT_T lut)
 #endif
     const float y = (float)s_im, x = (float)s_re; /* fm_demod.c:68 */
     const float ya = __builtin_fabsf(y), xa = __builtin_fabsf(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* one instruction each (operands are converted integers, never NaN; fmaxf/fminf would add canonicalising
+     * self-maxes) */
+    float mx, mn;
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
+#else
     const bool tall = ya > xa;
     const float mx = tall ? ya : xa, mn = tall ? xa : ya;
+#endif
 
     /* fast_atan2f.c:114-117: z = min/max (equal magnitudes give x_abs/y_abs = 1) */
     const float z = mfm_div_unit(mn, mx);
 
     /* :121-132, both arms evaluated, no branch (idx is 0 when z is below the threshold or NaN) */
     float alpha = z * 255.0f;               /* :125 */
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* z is in [0, 1] or NaN, so (int)alpha is in [0, 255] (NaN converts to 0) and needs no mask; alpha - (float)idx
+     * is alpha - floor(alpha), exact, which is what v_fract_f32 returns */
+    const int idx = (int)alpha;             /* :126 */
+    alpha = __builtin_amdgcn_fractf(alpha); /* :127 */
+#else
     const int idx = ((int)alpha) & 0xff;    /* :126 */
     alpha = alpha - (float)idx;             /* :127 */
+#endif
     const float t0 = MFM_LUT_X(lut[idx]), dt = MFM_LUT_Y(lut[idx]);
     const float prod = dt * alpha;
     const float interp = t0 + prod;         /* :130-131, unfused */
@@ -143,9 +158,10 @@ MFM_HD int32_t mfm_discriminate(int32_t s_re, int32_t s_im, MFM_LUT_T lut)
     const float sc = __builtin_fmaf(mag, MFM_Q14_OVER_PI_HI, lo);
 #if defined(__HIP_DEVICE_COMPILE__)
     /* sign of y = sign of s_im; (0,0) made z NaN and NaN converts to 0 (v_cvt_i32_f32), which is
-     * fast_atan2f.c:111-112's answer */
-    const float signed_sc = __int_as_float((__float_as_int(sc) & 0x7fffffff) | (s_im & (int32_t)0x80000000));
-    return (int32_t)signed_sc;
+     * fast_atan2f.c:111-112's answer.  One v_bfi_b32 (the compiler splits the and/and/or form). */
+    int32_t signed_sc;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(signed_sc) : "s"(0x7fffffff), "v"(sc), "v"(s_im));
+    return (int32_t)__int_as_float(signed_sc);
 #else
     int32_t pcm = (int32_t)sc;
     pcm = (s_im >= 0) ? pcm : -pcm;
@@ -153,3 +169,76 @@ MFM_HD int32_t mfm_discriminate(int32_t s_re, int32_t s_im, MFM_LUT_T lut)
     return (mx > 0.0f) ? pcm : 0;
 #endif
 }
+
+#if defined(__HIPCC__)
+/*
+ * Two discriminators at once, for the MFMA kernel: the float chain (division refinement, table interpolation,
+ * octant offset, Q14 scaling) is written on 2-vectors so that it compiles to packed FP32 instructions
+ * (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction, same results as the scalar
+ * form above).  t_lut / d_lut are the table and its first difference as two separate arrays, so the four
+ * look-ups land directly in register pairs.
+ */
+typedef float mfm_v2f __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ void mfm_discriminate2(const int32_t s_re[2], const int32_t s_im[2], const float *t_lut,
+                                                         const float *d_lut, int32_t pcm[2])
+{
+#if defined(__HIP_DEVICE_COMPILE__) /* the host pass only needs the declaration */
+#pragma clang fp contract(off)
+    mfm_v2f mx, mn, r0;
+    float x[2], y[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        x[i] = (float)s_re[i];
+        y[i] = (float)s_im[i];
+        float a, b;
+        asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(a) : "v"(x[i]), "v"(y[i]));
+        asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(b) : "v"(x[i]), "v"(y[i]));
+        mx[i] = a;
+        mn[i] = b;
+        r0[i] = __builtin_amdgcn_rcpf(a);
+    }
+    /* mfm_div_unit */
+    const mfm_v2f one = { 1.0f, 1.0f };
+    const mfm_v2f e0 = __builtin_elementwise_fma(-mx, r0, one);
+    const mfm_v2f r1 = __builtin_elementwise_fma(e0, r0, r0);
+    const mfm_v2f q0 = mn * r1;
+    const mfm_v2f e1 = __builtin_elementwise_fma(-mx, q0, mn);
+    const mfm_v2f q1 = __builtin_elementwise_fma(e1, r1, q0);
+    const mfm_v2f e2 = __builtin_elementwise_fma(-mx, q1, mn);
+    const mfm_v2f z = __builtin_elementwise_fma(e2, r1, q1);
+
+    const mfm_v2f alpha = z * 255.0f;
+    mfm_v2f frac, t0, dt;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = (int)alpha[i];
+        frac[i] = __builtin_amdgcn_fractf(alpha[i]);
+        t0[i] = t_lut[idx];
+        dt[i] = d_lut[idx];
+    }
+    const mfm_v2f prod = dt * frac;
+    const mfm_v2f interp = t0 + prod;
+    mfm_v2f k, u;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float base = (z[i] < MFM_TAN_MAP_RES_F) ? z[i] : interp[i];
+        const bool x_nonneg = s_re[i] >= 0, wide = __builtin_fabsf(x[i]) > __builtin_fabsf(y[i]);
+        k[i] = wide ? (x_nonneg ? 0.0f : MFM_PI_F) : MFM_HALF_PI_F;
+        u[i] = (x_nonneg == wide) ? base : -base;
+    }
+    const mfm_v2f mag = k + u;
+    const mfm_v2f lo = mag * MFM_Q14_OVER_PI_LO;
+    const mfm_v2f hi = { MFM_Q14_OVER_PI_HI, MFM_Q14_OVER_PI_HI };
+    const mfm_v2f sc = __builtin_elementwise_fma(mag, hi, lo);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int32_t signed_sc;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(signed_sc) : "s"(0x7fffffff), "v"(sc[i]), "v"(s_im[i]));
+        pcm[i] = (int32_t)__int_as_float(signed_sc);
+    }
+#else
+    (void)s_re, (void)s_im, (void)t_lut, (void)d_lut, (void)pcm;
+#endif
+}
+#endif
