@@ -26,7 +26,7 @@ eng.sync()
 buf = np.zeros(64 * 128, np.uint64)
 assert eng.lib.mfm_trace_read(buf.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
 buf = buf.reshape(64, 64, 2)
-names = {1: "start", 2: "prologue done", 3: "barrier1", 4: "staged", 5: "barrier2", 6: "mfma done", 7: "epilogue done"}
+names = {1: "start", 2: "prologue done", 3: "barrier1", 4: "staged", 5: "barrier2", 6: "mfma done", 7: "stores issued", 8: "epilogue done", 9: "staged (lds)"}
 for wg in (0, 1, 8, 63):
     t0 = int(buf[wg, 0, 1])
     print(f"--- workgroup {wg}")

@@ -619,7 +619,8 @@ int mfm_engine_commit(struct mfm_engine *e)
             const uint32_t nst = ((cand * D + 32u * kq) + 3u) & ~3u;
             const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
             const uint32_t pb = rows * rs_m;
-            const uint32_t need = 4u * pb + 2048u; /* two staging buffers x two byte planes + atan LUT */
+            /* two staging buffers x two byte planes + atan LUT + rotator constants of up to 256 channels */
+            const uint32_t need = 4u * pb + 2048u + (C <= 256u ? 32u * C : 0u);
             if (need <= 80u * 1024u && nst / 4u <= 4u * MFM_MFMA_NW * 64u) {
                 ot = cand;
                 plane = pb;
@@ -939,6 +940,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.rs = e->m_rs;
             M.plane_bytes = e->m_plane_bytes;
             M.lut_off = e->m_lut_off;
+            M.tbl_off = C <= 256u ? e->m_lut_off + 2048u : 0u;
             M.nslices = e->m_nslices;
             M.nrb = e->m_nrb;
             M.ntiles = (n_new + e->m_ot - 1u) / e->m_ot;

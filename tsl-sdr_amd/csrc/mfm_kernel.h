@@ -75,6 +75,8 @@ struct mfm_launch_mfma {
     uint32_t rs;          /* LDS row stride in bytes (row = 2*D plane bytes), rs/16 odd */
     uint32_t plane_bytes; /* bytes of one byte-plane in LDS (16-byte multiple) */
     uint32_t lut_off;     /* byte offset of the atan LUT in LDS */
+    uint32_t tbl_off;     /* byte offset of the per-channel rotator constants in LDS (8 dwords per channel:
+                             mfm_chan_info with kb in pad[0]); 0 = too many channels, read them from global */
     uint32_t nslices;     /* ceil(row blocks / MFM_MFMA_NW) */
     uint32_t nrb;         /* row blocks of 16 rows (= 8 channels) */
     uint32_t ntiles, nitems;

@@ -159,6 +159,18 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         }
     }
 
+    /* rotator constants of every channel {rot_base, -, mu, lam, lam_magic, kb, -, -}: each tile needs them to place
+     * its first column in the rotator tables.  Read from global memory they were the only vector-memory loads at
+     * the head of a tile, and waiting for them (in-order vmcnt) also waited for the previous tile's PCM stores. */
+    const uint32_t *tbl = L.tbl_off ? reinterpret_cast<const uint32_t *>(smem + L.tbl_off) : nullptr;
+    if (L.tbl_off) {
+        uint32_t *tbl_s = reinterpret_cast<uint32_t *>(smem + L.tbl_off);
+        const uint32_t *info_g = reinterpret_cast<const uint32_t *>(L.info);
+        for (uint32_t i = tid; i < L.nchan * 8u; i += MFM_M_NT) {
+            tbl_s[i] = ((i & 7u) == 5u) ? L.st_in[i >> 3].kb : info_g[i];
+        }
+    }
+
     /* per-lane LDS byte offset of the B fragment of k-step kq for column n of the first group */
     uint32_t boff[KQ];
 #pragma unroll
@@ -207,10 +219,20 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         for (int c = 0; c < 2; c++) {
             const uint32_t chn = ch0 + c;
             const uint32_t chs = (valid && chn < L.nchan) ? chn : 0u;
-            const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chs * 8;
-            const uint4 inf = *reinterpret_cast<const uint4 *>(ip);
-            const uint32_t lam_magic = ip[4];
-            const uint32_t kb = L.st_in[chs].kb;
+            uint4 inf;
+            uint32_t lam_magic, kb;
+            if (tbl) {
+                const uint4 *tp = reinterpret_cast<const uint4 *>(tbl + chs * 8u);
+                inf = tp[0];
+                const uint2 hi = *reinterpret_cast<const uint2 *>(tp + 1);
+                lam_magic = hi.x;
+                kb = hi.y;
+            } else {
+                const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)mfm_opaque(chs) * 8;
+                inf = *reinterpret_cast<const uint4 *>(ip);
+                lam_magic = ip[4];
+                kb = L.st_in[mfm_opaque(chs)].kb;
+            }
             const uint32_t mu = inf.z, lam = inf.w;
             int k = (int)kb + rel_first; /* >= -1; entry -1 of every table is a readable dummy */
             if (k >= (int)mu) {
@@ -243,11 +265,11 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             stage_store(0, j, v[j]);
         }
     }
+    __syncthreads();
     uint32_t k_off[2] = { 0, 0 };
     if (have) {
         rot_offsets(tile, (slice * MFM_MFMA_NW + wave) * 8u + 2u * kg, slice * MFM_MFMA_NW + wave < L.nrb, k_off);
     }
-    __syncthreads();
     MFM_STAMP(2);
 
     /* Vector memory in this loop is straight-line code: every load and store below is issued on every path
@@ -332,6 +354,8 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 pre[u] = stage_load(have_n ? tile_n : tile, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
             }
 
+            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM); /* keep them ahead of the matrix work */
+
             /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
             mfm_v4i hh[2], md[2], ll[2];
 #pragma unroll
@@ -414,6 +438,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 pcm[1][c] = out[1];
             }
 
+            MFM_STAMP(8);
             /* rotator entries of the next iteration (of the next tile after the last one) */
             uint2 rvn[2][2];
             if (it + 1 < MFM_M_ITERS) {
@@ -430,6 +455,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             }
             __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
 
+            MFM_STAMP(9);
             /* PCM: every lane stores its four values; the ones that are not outputs (column 0 of group 0, columns
              * past n_new, channels past the end) go to the dump slot */
             const uint32_t dump = L.nchan * L.out_stride + lane;
