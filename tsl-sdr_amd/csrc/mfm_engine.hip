@@ -172,6 +172,8 @@ struct mfm_engine {
     uint32_t *h_in[2] = { nullptr, nullptr }; /* pinned, for push() */
     uint16_t *d_raw[2] = { nullptr, nullptr }; /* push_bytes(): 8-bit IQ pairs as they came off the wire */
     hipEvent_t in_free[2] = { nullptr, nullptr };
+    hipEvent_t in_free_wait[2] = { nullptr, nullptr }; /* what acquire_input() waits on: in_free[i], or the timing
+                                                          event recorded at the same point of the stream */
     hipEvent_t in_ready = nullptr;
     int cur_in = 0;
     uint32_t tail = 0; /* samples of history at the front of d_in[cur_in] */
@@ -838,7 +840,9 @@ int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacit
     }
     HIP_TRY(hipSetDevice(e->cfg.device));
     /* the kernel that last read this buffer (two submits ago) must be done with it */
-    HIP_TRY(hipEventSynchronize(e->in_free[e->cur_in]));
+    if (e->in_free_wait[e->cur_in]) {
+        HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
+    }
     *d_dst = e->d_in[e->cur_in] + e->tail;
     if (capacity_samples) {
         *capacity_samples = e->cap_in - e->tail;
@@ -886,6 +890,8 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
     }
 
+    bool tail_in_kernel = false;
+    hipEvent_t timing_end = nullptr;
     if (n_new) {
         const uint32_t ot = 64u * e->opl;
         mfm_launch L{};
@@ -947,6 +953,14 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
             M.nchan = C;
             M.out_stride = e->out_stride;
+            M.skew = 0; /* measured: no gain on MI355X (tools/ab.sh MFM_SKEW=..); kept as a knob */
+            if (const char *sk = getenv("MFM_SKEW")) {
+                M.skew = (uint32_t)atoi(sk);
+            }
+            M.tail_src = n_new * D;
+            M.tail_n = n_avail - n_new * D;
+            M.tail_dst = e->d_in[cur ^ 1];
+            tail_in_kernel = true;
             M.afrag = e->d_afrag;
             M.krow = e->d_krow;
             M.info = e->d_info;
@@ -976,6 +990,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         }
         if (timing) {
             HIP_TRY(hipEventRecord(e->t1[ti], e->s_compute));
+            timing_end = e->t1[ti];
             e->t_head++;
         }
         e->parity ^= 1;
@@ -983,20 +998,28 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         e->grid_last = e->use_mfma ? L.ntiles : ((L.ntiles + 7) / 8) * 8 * L.nslices;
     }
 
-    /* carry the unconsumed tail to the front of the other staging buffer */
+    /* carry the unconsumed tail to the front of the other staging buffer (the MFMA kernel has done it itself) */
     const uint32_t consumed = n_new * D;
     const uint32_t new_tail = n_avail - consumed;
-    if (new_tail) {
+    if (new_tail && !tail_in_kernel) {
         HIP_TRY(hipMemcpyAsync(e->d_in[cur ^ 1], e->d_in[cur] + consumed, (size_t)new_tail * 4,
                                hipMemcpyDeviceToDevice, e->s_compute));
     }
-    HIP_TRY(hipEventRecord(e->in_free[cur], e->s_compute));
+    /* Every event record is a packet the command processor handles between two kernels (about 4 us each on
+     * MI355X).  When the kernel carried the tail itself and its end is already stamped by the timing event, that
+     * event also says "this input buffer is free". */
+    if (tail_in_kernel && timing_end) {
+        e->in_free_wait[cur] = timing_end;
+    } else {
+        HIP_TRY(hipEventRecord(e->in_free[cur], e->s_compute));
+        e->in_free_wait[cur] = e->in_free[cur];
+    }
 
     if (n_new) {
         slot->first_output = e->outputs;
         slot->nr_outputs = n_new;
         if (dev_only) {
-            HIP_TRY(hipEventRecord(slot->ready, e->s_compute));
+            /* nothing waits on slot->ready in device-only mode: consumers are ordered by the stream */
         } else {
             HIP_TRY(hipEventRecord(e->kernel_done, e->s_compute));
             HIP_TRY(hipStreamWaitEvent(e->s_out, e->kernel_done, 0));

@@ -81,6 +81,10 @@ struct mfm_launch_mfma {
     uint32_t nrb;         /* row blocks of 16 rows (= 8 channels) */
     uint32_t ntiles, nitems;
     uint32_t nchan, out_stride;
+    uint32_t skew;        /* units of ~128 clocks waves 4..7 wait after each tile barrier (staggers the LDS-heavy
+                             matrix phase of the two halves of a workgroup) */
+    uint32_t tail_src, tail_n; /* samples x[tail_src .. tail_src + tail_n) are the history the next block needs ... */
+    uint32_t *tail_dst;   /* ... at the front of the other input buffer (workgroup 0 copies them) */
     const uint32_t *afrag;   /* [nrb][kq][plane hi,lo][lane][4 dwords] */
     const int32_t *krow;     /* [nrb][16]: 128 * sum_k W[row][k] + 8192 */
     const struct mfm_chan_info *info;

@@ -251,6 +251,14 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     mfm_v4i krow = { 0, 0, 0, 0 };
     uint32_t slice_loaded = 0xffffffffu;
 
+    /* the unconsumed samples at the end of this block are the head of the next one: carried over here instead of
+     * by a separate copy behind the kernel (one stream operation less per block) */
+    if (blockIdx.x == 0) {
+        for (uint32_t i = tid; i < L.tail_n; i += MFM_M_NT) {
+            L.tail_dst[i] = L.x[L.tail_src + i];
+        }
+    }
+
     /* ---- first tile of this workgroup: staged synchronously into buffer 0 ---- */
     uint32_t item = blockIdx.x, tile, slice;
     bool have = mfm_decode_item(L, item, &tile, &slice);
@@ -520,6 +528,11 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
         MFM_STAMP(4);
         __syncthreads(); /* next tile's image is complete and nobody reads the current one any more */
+        if (wave >= MFM_MFMA_NW / 2) {
+            for (uint32_t z = 0; z < L.skew; z++) {
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         MFM_STAMP(5);
         cur ^= 1u;
         item = item_n;
