@@ -102,6 +102,7 @@ def main():
     # with one rank, so the N>1 plumbing can be exercised on a single-GPU box
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # no version banner on stdout
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -214,11 +215,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, fs, decim, taps, offs, gains, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
 
     eng.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would come out
+        # after anything Python prints: flush it first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
