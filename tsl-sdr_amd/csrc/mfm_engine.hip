@@ -155,6 +155,7 @@ struct mfm_engine {
     bool use_mfma = false;
     uint32_t m_ks = 0, m_ot = 0, m_rs = 0, m_plane_bytes = 0, m_lut_off = 0, m_krow_off = 0, m_nrb = 0,
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
+    bool m_fixed_planes = false;
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
 
@@ -607,7 +608,13 @@ int mfm_engine_commit(struct mfm_engine *e)
             kq *= 2;
         }
         const uint32_t row_bytes = 2u * D;
-        const uint32_t rs_m = ((row_bytes / 16u) & 1u) ? row_bytes : row_bytes + 16u;
+        /* LDS row stride: an ODD multiple of 32 bytes.  tools/ubench_lds.hip: the B-fragment read pattern (lane
+         * 16 kg + n reads 16 bytes at n * rs + 16 kg) runs at the full ds_read_b128 rate for rs = 224 and at 76-81 %
+         * of it for 80, 144, 176, 192, 208, 272 - odd multiples of 16 bytes are not enough. */
+        uint32_t rs_m = (row_bytes + 31u) / 32u * 32u;
+        if (((rs_m / 32u) & 1u) == 0u) {
+            rs_m += 32u;
+        }
         uint32_t ot = 0, plane = 0, lds = 0;
         const uint32_t want[] = { 2u * 31u }; /* new outputs per tile: two 31-output iterations */
         uint32_t forced_ot = 0;
@@ -621,9 +628,10 @@ int mfm_engine_commit(struct mfm_engine *e)
             const uint32_t nst = ((cand * D + 32u * kq) + 3u) & ~3u;
             const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
             const uint32_t pb = rows * rs_m;
-            /* two staging buffers x two byte planes + atan LUT + rotator constants of up to 256 channels */
-            const uint32_t need = 4u * pb + 2048u + (C <= 256u ? 32u * C : 0u);
-            if (need <= 80u * 1024u && nst / 4u <= 4u * MFM_MFMA_NW * 64u) {
+            /* two staging buffers x two byte planes + atan LUT + staging offsets + rotator constants of up to 256 channels */
+            const uint32_t need = 4u * pb + 2048u + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u + (C <= 256u ? 32u * C : 0u);
+            /* up to 80 KB two workgroups share a CU; beyond that one per CU is still far better than the v_dot2 kernel */
+            if (need <= 150u * 1024u && nst / 4u <= MFM_M_CH_MAX * MFM_MFMA_NW * 64u) {
                 ot = cand;
                 plane = pb;
                 lds = need;
@@ -639,6 +647,18 @@ int mfm_engine_commit(struct mfm_engine *e)
             e->m_plane_bytes = plane;
             e->m_lut_off = 4u * plane;
             e->m_lds_bytes = lds;
+            /* planes at a fixed 16 KiB pitch when they fit and two workgroups still share a CU: the kernel then
+             * reaches the low-byte plane and the second staging buffer through instruction immediates */
+            e->m_fixed_planes = false;
+            if (plane <= MFM_M_PLANE_DIST) {
+                const uint32_t lds_fixed = 4u * MFM_M_PLANE_DIST + (lds - 4u * plane);
+                if (2u * lds_fixed <= 160u * 1024u) {
+                    e->m_fixed_planes = true;
+                    e->m_lut_off = 4u * MFM_M_PLANE_DIST;
+                    e->m_lds_bytes = lds_fixed;
+                    lds = lds_fixed;
+                }
+            }
             e->m_nrb = (2u * C + 15u) / 16u;
             e->m_nslices = (e->m_nrb + MFM_MFMA_NW - 1u) / MFM_MFMA_NW;
             e->m_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
@@ -945,8 +965,10 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.nstage = ((e->m_ot * D + 32u * e->m_ks) + 3u) & ~3u;
             M.rs = e->m_rs;
             M.plane_bytes = e->m_plane_bytes;
+            M.fixed_planes = e->m_fixed_planes ? 1u : 0u;
             M.lut_off = e->m_lut_off;
-            M.tbl_off = C <= 256u ? e->m_lut_off + 2048u : 0u;
+            M.sta_off = e->m_lut_off + 2048u;
+            M.tbl_off = C <= 256u ? M.sta_off + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u : 0u;
             M.nslices = e->m_nslices;
             M.nrb = e->m_nrb;
             M.ntiles = (n_new + e->m_ot - 1u) / e->m_ot;

@@ -65,6 +65,9 @@ struct mfm_launch {
 #define MFM_MFMA_NW 8            /* waves per workgroup; each owns 16 GEMM rows = 8 channels */
 #define MFM_MFMA_KQ_MAX 4        /* k-steps of 64 int16 elements (= 32 complex taps) held in registers */
 
+#define MFM_M_PLANE_DIST 16384u
+#define MFM_M_CH_MAX 4u /* at most this many 16-byte staging chunks per thread and tile */
+
 struct mfm_launch_mfma {
     const uint32_t *x;
     uint32_t n_avail, n_new, decim;
@@ -72,9 +75,12 @@ struct mfm_launch_mfma {
     uint32_t kq;          /* k-steps of 64 elements: padded taps = 32 * kq */
     uint32_t ot;          /* NEW outputs per workgroup tile: 31 per N-tile of 32 columns */
     uint32_t nstage;      /* samples staged per tile: ot*D + 32*kq, rounded up to 4 */
-    uint32_t rs;          /* LDS row stride in bytes (row = 2*D plane bytes), rs/16 odd */
+    uint32_t rs;          /* LDS row stride in bytes (row = 2*D plane bytes), an odd multiple of 32 */
     uint32_t plane_bytes; /* bytes of one byte-plane in LDS (16-byte multiple) */
+    uint32_t fixed_planes; /* 1: the four planes sit MFM_M_PLANE_DIST bytes apart (H0, L0, H1, L1) whatever their size,
+                              so the distance is an instruction immediate; 0: packed, plane_bytes apart */
     uint32_t lut_off;     /* byte offset of the atan LUT in LDS */
+    uint32_t sta_off;     /* byte offset of the staging-offset table in LDS: [MFM_M_CH_MAX][512 threads] dwords */
     uint32_t tbl_off;     /* byte offset of the per-channel rotator constants in LDS (8 dwords per channel:
                              mfm_chan_info with kb in pad[0]); 0 = too many channels, read them from global */
     uint32_t nslices;     /* ceil(row blocks / MFM_MFMA_NW) */

@@ -62,20 +62,43 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 /* sched_barrier mask: ALU | VALU | SALU | MFMA | DS | DS-read | DS-write may cross, vector memory may not */
 #define MFM_SCHED_ALL_BUT_VMEM 0x38F
 #define MFM_M_ITERS 2 /* iterations per tile: a tile is 62 new outputs */
-#define MFM_M_CH 4    /* 16-byte staging chunks a thread owns per tile (>= ceil(samples/4/512)) */
 
-/* 4 * ((hh << 16) + (md << 8) + ll): the recombined sum (K + 8192 ride in through ll) times 4, so that bits 29:14
- * (round_q30_q15 + int16 truncation) land in the upper half-word */
-static __device__ __forceinline__ uint32_t mfm_combine_x4(int hh, int md, int ll)
+/* (hh << 16) + (md << 8) + ll: the recombined sum, K + 8192 riding in through ll.  Two v_lshl_add_u32; left to
+ * itself the compiler canonicalises the expression into two shifts and a three-operand add. */
+static __device__ __forceinline__ uint32_t mfm_combine(int hh, int md, int ll)
 {
-    /* two v_lshl_add_u32 and a shift (written out as three shifts the compiler spends four instructions) */
-    return (((((uint32_t)hh << 8) + (uint32_t)md) << 8) + (uint32_t)ll) << 2;
+    uint32_t t, a;
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(hh), "v"(md));
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a) : "v"(t), "v"(ll));
+    return a;
 }
 
-/* upper half-words of two dwords as (re | im << 16): one v_perm_b32 */
-static __device__ __forceinline__ uint32_t mfm_pack_hi(uint32_t re_x4, uint32_t im_x4)
+/*
+ * Four times "bits 29:14 of re_b and of im_b as (re | im << 16)" (round_q30_q15 + int16 truncation of biased sums):
+ * two sub-dword shifts per pair - v_lshrrev_b32 with dst_sel WORD_0 / WORD_1 writes the 16 result bits straight into
+ * its half of the destination - instead of shift, shift, merge.  A VALU write with dst_sel needs one wait state
+ * before the register is read again (the second shift preserves, i.e. reads, the other half); the four pairs are
+ * interleaved so that an independent instruction always sits in between, and the block ends with the wait state
+ * for whoever reads p[3] next.  (The compiler does not pad hazards around inline asm.)
+ */
+static __device__ __forceinline__ void mfm_round_pack4(const uint32_t re_b[4], const uint32_t im_b[4], uint32_t p[4])
 {
-    return __builtin_amdgcn_perm(im_x4, re_x4, 0x07060302u);
+    uint32_t p0, p1, p2, p3;
+    asm("v_lshrrev_b32_sdwa %0, 14, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, 14, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %2, 14, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %3, 14, %7 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %0, 14, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, 14, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %2, 14, %10 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %3, 14, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+        : "v"(re_b[0]), "v"(re_b[1]), "v"(re_b[2]), "v"(re_b[3]), "v"(im_b[0]), "v"(im_b[1]), "v"(im_b[2]), "v"(im_b[3]));
+    p[0] = p0;
+    p[1] = p1;
+    p[2] = p2;
+    p[3] = p3;
 }
 
 /*
@@ -114,12 +137,6 @@ static __device__ __forceinline__ uint32_t mfm_opaque(uint32_t v)
     return v;
 }
 
-/* bits 29:14 of two biased sums packed as (re | im << 16): round_q30_q15 + int16 truncation */
-static __device__ __forceinline__ uint32_t mfm_round_pack(uint32_t re_b, uint32_t im_b)
-{
-    return ((re_b >> 14) & 0xffffu) | ((im_b << 2) & 0xffff0000u);
-}
-
 /* decode a persistent-loop item into (tile, slice): XCD-aware, the slices of one tile run back to back
  * on one XCD (see mfm_kernel.hip) */
 static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L, uint32_t item, uint32_t *tile,
@@ -131,7 +148,11 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
     return item < L.nitems && *tile < L.ntiles;
 }
 
-template <int KQ, bool DBG_IQ> /* KQ = k-steps of 64 elements (32 complex taps) */
+/* KQ = k-steps of 64 elements (32 complex taps); FIXP: planes at a fixed pitch; NCH = 16-byte staging chunks a thread
+ * owns per tile = ceil(samples per tile / 4 / 512).  A compile-time count: a chunk nobody needs would still be loaded
+ * (loads in this loop are unconditional), and with 62 outputs x 96 samples that was a fourth chunk per thread, 8 KB of
+ * somebody else's tile per tile - a third on top of the input traffic. */
+template <int KQ, bool DBG_IQ, bool FIXP, int NCH>
 __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -146,7 +167,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     MFM_STAMP(1);
     const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
-    const uint32_t buf_bytes = 2u * L.plane_bytes; /* one staging buffer = H plane + L plane */
+    /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
+     * offset field of the LDS instructions instead of costing a v_add each (ds_read has no SGPR offset) */
+    const uint32_t plane_dist = FIXP ? MFM_M_PLANE_DIST : L.plane_bytes;
+    const uint32_t buf_bytes = 2u * plane_dist;
     const float *lut_t = reinterpret_cast<const float *>(smem + L.lut_off), *lut_d = lut_t + 256;
 
     /* atan LUT, once per workgroup (its LDS region is never restaged): global {T[i], T[i+1]-T[i]} pairs are
@@ -179,13 +203,17 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         boff[kq] = (n + e / row_bytes) * rs + e % row_bytes;
     }
 
-    /* staging: this thread owns chunks q = tid + j * MFM_M_NT, j = 0 .. MFM_M_CH-1 of every tile; their
+    /* staging: this thread owns chunks q = tid + j * MFM_M_NT, j = 0 .. NCH-1 of every tile; their
      * place in the LDS image never changes */
-    uint32_t st_at[MFM_M_CH];
+    constexpr int NCH0 = (NCH + 1) / 2; /* chunks prefetched during iteration 0; the rest during iteration 1 */
+    /* where this thread's chunks go in the LDS image never changes; the offsets cost a division by the row length,
+     * so they are computed once - and parked in LDS rather than in VGPRs, which are all taken while the matrix
+     * phase runs (a spilled offset would come back through scratch, i.e. through vmcnt) */
+    uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
 #pragma unroll
-    for (int j = 0; j < MFM_M_CH; j++) {
+    for (int j = 0; j < NCH; j++) {
         const uint32_t p8 = (tid + (uint32_t)j * MFM_M_NT) * 8u;
-        st_at[j] = (p8 / row_bytes) * rs + p8 % row_bytes;
+        sta_s[j * MFM_M_NT + tid] = (p8 / row_bytes) * rs + p8 % row_bytes;
     }
 
     auto stage_load = [&](uint32_t tile, int j) -> uint4 {
@@ -207,9 +235,9 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             hi.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
             lo.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) ^ 0x80808080u;
             lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) ^ 0x80808080u;
-            uint8_t *base = smem + buf * buf_bytes + st_at[j];
+            uint8_t *base = smem + buf * buf_bytes + sta_s[j * MFM_M_NT + tid]; /* own slot: no barrier needed */
             *reinterpret_cast<uint2 *>(base) = hi;
-            *reinterpret_cast<uint2 *>(base + L.plane_bytes) = lo;
+            *reinterpret_cast<uint2 *>(base + plane_dist) = lo;
         }
     };
     /* where column 0 of tile `tile` sits in this lane's two channels' rotator tables */
@@ -263,13 +291,13 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     uint32_t item = blockIdx.x, tile, slice;
     bool have = mfm_decode_item(L, item, &tile, &slice);
     if (have) {
-        uint4 v[MFM_M_CH];
+        uint4 v[NCH];
 #pragma unroll
-        for (int j = 0; j < MFM_M_CH; j++) {
+        for (int j = 0; j < NCH; j++) {
             v[j] = stage_load(tile, j);
         }
 #pragma unroll
-        for (int j = 0; j < MFM_M_CH; j++) {
+        for (int j = 0; j < NCH; j++) {
             stage_store(0, j, v[j]);
         }
     }
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             rot_offsets(tile_n, (rb_n < L.nrb ? rb_n : L.nrb - 1u) * 8u + 2u * kg, true, k_off_n);
         }
 
-        const uint8_t *plane_h = smem + cur * buf_bytes, *plane_l = plane_h + L.plane_bytes;
+        const uint8_t *plane_h = smem + cur * buf_bytes, *plane_l = plane_h + plane_dist;
 
         /* first tile of the pass: its column 0 is the previous pass's last filtered sample */
         const bool use_carry = (tile == 0) && (n == 0);
@@ -356,10 +384,14 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
             /* this iteration's share of the next tile's input (a workgroup's last tile re-reads its own samples
              * and stages them into the idle buffer) */
-            uint4 pre[MFM_M_CH / MFM_M_ITERS];
+            static_assert(MFM_M_ITERS == 2, "chunk split below assumes two iterations per tile");
+            const int ch_first = it == 0 ? 0 : NCH0, ch_count = it == 0 ? NCH0 : NCH - NCH0;
+            uint4 pre[NCH0];
 #pragma unroll
-            for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
-                pre[u] = stage_load(have_n ? tile_n : tile, (int)it * (MFM_M_CH / MFM_M_ITERS) + u);
+            for (int u = 0; u < NCH0; u++) {
+                if (u < ch_count) {
+                    pre[u] = stage_load(have_n ? tile_n : tile, ch_first + u);
+                }
             }
 
             __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM); /* keep them ahead of the matrix work */
@@ -403,19 +435,33 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
              *      (group 1); written in phases so the four independent chains interleave ---- */
             uint32_t q[2][2];
             int pcm[2][2];
+            {
+                /* a + 8192 (mod 2^32); r14(a) truncated to int16 is bits 29:14 (filter/complex.h:30-34) */
+                uint32_t a_re[4], a_im[4], f[4], o_re[4], o_im[4], qq[4];
 #pragma unroll
-            for (int gq = 0; gq < 2; gq++) {
+                for (int gq = 0; gq < 2; gq++) {
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    /* 4 * (a + 8192) (mod 2^32); r14(a) truncated to int16 is bits 29:14 of a + 8192
-                     * (filter/complex.h:30-34), i.e. the upper half-word here */
-                    const uint32_t a_re = mfm_combine_x4(hh[gq][2 * c], md[gq][2 * c], ll[gq][2 * c]);
-                    const uint32_t a_im = mfm_combine_x4(hh[gq][2 * c + 1], md[gq][2 * c + 1], ll[gq][2 * c + 1]);
-                    const uint32_t f = mfm_pack_hi(a_re, a_im);
-                    /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
-                    uint32_t o_re, o_im;
-                    mfm_rotate_biased(f, rv[gq][c], &o_re, &o_im);
-                    q[gq][c] = mfm_round_pack(o_re, o_im);
+                    for (int c = 0; c < 2; c++) {
+                        a_re[2 * gq + c] = mfm_combine(hh[gq][2 * c], md[gq][2 * c], ll[gq][2 * c]);
+                        a_im[2 * gq + c] = mfm_combine(hh[gq][2 * c + 1], md[gq][2 * c + 1], ll[gq][2 * c + 1]);
+                    }
+                }
+                mfm_round_pack4(a_re, a_im, f);
+                /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        mfm_rotate_biased(f[2 * gq + c], rv[gq][c], &o_re[2 * gq + c], &o_im[2 * gq + c]);
+                    }
+                }
+                mfm_round_pack4(o_re, o_im, qq);
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        q[gq][c] = qq[2 * gq + c];
+                    }
                 }
             }
             if (it == 0) {
@@ -458,8 +504,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
             /* the prefetched samples go to the other staging buffer */
 #pragma unroll
-            for (int u = 0; u < MFM_M_CH / MFM_M_ITERS; u++) {
-                stage_store(cur ^ 1u, (int)it * (MFM_M_CH / MFM_M_ITERS) + u, pre[u]);
+            for (int u = 0; u < NCH0; u++) {
+                if (u < ch_count) {
+                    stage_store(cur ^ 1u, ch_first + u, pre[u]);
+                }
             }
             __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
 
@@ -550,9 +598,9 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
     if (L->ntiles == 0) {
         return hipSuccess;
     }
-#define MFM_LAUNCH_M(KQ_, DBG_)                                                                              \
+#define MFM_LAUNCH_N(KQ_, DBG_, FIXP_, NCH_)                                                                 \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_>;                                                       \
+        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_>;                                          \
         static uint32_t lds_set_ = 0;                                                                        \
         if (lds_bytes > lds_set_) {                                                                          \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
@@ -564,15 +612,34 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         }                                                                                                    \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
     } while (0)
+#define MFM_LAUNCH_M(KQ_, DBG_, FIXP_)                                                                       \
+    do {                                                                                                     \
+        switch (nch) {                                                                                       \
+        case 1: MFM_LAUNCH_N(KQ_, DBG_, FIXP_, 1); break;                                                    \
+        case 2: MFM_LAUNCH_N(KQ_, DBG_, FIXP_, 2); break;                                                    \
+        case 3: MFM_LAUNCH_N(KQ_, DBG_, FIXP_, 3); break;                                                    \
+        default: MFM_LAUNCH_N(KQ_, DBG_, FIXP_, 4); break;                                                   \
+        }                                                                                                    \
+    } while (0)
 #define MFM_LAUNCH_KQ(KQ_)                                                                                   \
     do {                                                                                                     \
         if (dbg_iq) {                                                                                        \
-            MFM_LAUNCH_M(KQ_, true);                                                                         \
+            if (L->fixed_planes) {                                                                           \
+                MFM_LAUNCH_M(KQ_, true, true);                                                               \
+            } else {                                                                                         \
+                MFM_LAUNCH_M(KQ_, true, false);                                                              \
+            }                                                                                                \
+        } else if (L->fixed_planes) {                                                                        \
+            MFM_LAUNCH_M(KQ_, false, true);                                                                  \
         } else {                                                                                             \
-            MFM_LAUNCH_M(KQ_, false);                                                                        \
+            MFM_LAUNCH_M(KQ_, false, false);                                                                 \
         }                                                                                                    \
     } while (0)
 
+    const uint32_t nch = ((L->nstage >> 2) + MFM_M_NT - 1) / MFM_M_NT; /* 16-byte chunks per thread and tile */
+    if (nch < 1 || nch > MFM_M_CH_MAX) {
+        return hipErrorInvalidValue;
+    }
     switch (L->kq) {
     case 1: MFM_LAUNCH_KQ(1); break;
     case 2: MFM_LAUNCH_KQ(2); break;
@@ -581,5 +648,6 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
     }
 #undef MFM_LAUNCH_KQ
 #undef MFM_LAUNCH_M
+#undef MFM_LAUNCH_N
     return hipGetLastError();
 }
