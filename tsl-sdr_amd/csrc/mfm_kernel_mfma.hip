@@ -74,31 +74,25 @@ static __device__ __forceinline__ uint32_t mfm_combine(int hh, int md, int ll)
 }
 
 /*
- * Four times "bits 29:14 of re_b and of im_b as (re | im << 16)" (round_q30_q15 + int16 truncation of biased sums):
- * two sub-dword shifts per pair - v_lshrrev_b32 with dst_sel WORD_0 / WORD_1 writes the 16 result bits straight into
- * its half of the destination - instead of shift, shift, merge.  A VALU write with dst_sel needs one wait state
- * before the register is read again (the second shift preserves, i.e. reads, the other half); the four pairs are
- * interleaved so that an independent instruction always sits in between, and the block ends with the wait state
- * for whoever reads p[3] next.  (The compiler does not pad hazards around inline asm.)
+ * Twice "bits 29:14 of re_b and of im_b as (re | im << 16)" (round_q30_q15 + int16 truncation of biased sums): two
+ * sub-dword shifts per pair - v_lshrrev_b32 with dst_sel WORD_0 / WORD_1 writes the 16 result bits straight into its
+ * half of the destination - instead of shift, shift, merge.  A VALU write with dst_sel needs one wait state before the
+ * register is read again (the second shift preserves, i.e. reads, the other half); the two pairs are interleaved so
+ * that an independent instruction sits in between, and the block ends with the wait state for whoever reads p[1]
+ * next.  (The compiler does not pad hazards around inline asm.)
  */
-static __device__ __forceinline__ void mfm_round_pack4(const uint32_t re_b[4], const uint32_t im_b[4], uint32_t p[4])
+static __device__ __forceinline__ void mfm_round_pack2(const uint32_t re_b[2], const uint32_t im_b[2], uint32_t p[2])
 {
-    uint32_t p0, p1, p2, p3;
-    asm("v_lshrrev_b32_sdwa %0, 14, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %1, 14, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %2, 14, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %3, 14, %7 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %0, 14, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %1, 14, %9 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %2, 14, %10 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %3, 14, %11 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+    uint32_t p0, p1;
+    asm("v_lshrrev_b32_sdwa %0, 14, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, 14, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %0, 14, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, 14, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
         "s_nop 0"
-        : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
-        : "v"(re_b[0]), "v"(re_b[1]), "v"(re_b[2]), "v"(re_b[3]), "v"(im_b[0]), "v"(im_b[1]), "v"(im_b[2]), "v"(im_b[3]));
+        : "=&v"(p0), "=&v"(p1)
+        : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]));
     p[0] = p0;
     p[1] = p1;
-    p[2] = p2;
-    p[3] = p3;
 }
 
 /*
@@ -205,7 +199,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
     /* staging: this thread owns chunks q = tid + j * MFM_M_NT, j = 0 .. NCH-1 of every tile; their
      * place in the LDS image never changes */
-    constexpr int NCH0 = (NCH + 1) / 2; /* chunks prefetched during iteration 0; the rest during iteration 1 */
     /* where this thread's chunks go in the LDS image never changes; the offsets cost a division by the row length,
      * so they are computed once - and parked in LDS rather than in VGPRs, which are all taken while the matrix
      * phase runs (a spilled offset would come back through scratch, i.e. through vmcnt) */
@@ -380,90 +373,70 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             }
         }
 
+        /* The whole next tile is requested now and written to LDS at the end of this tile: the loads stay in flight
+         * for the full tile instead of one iteration (a workgroup's last tile re-reads its own samples and stages them
+         * into the idle buffer). */
+        uint4 pre[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            pre[j] = stage_load(have_n ? tile_n : tile, j);
+        }
+        __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM); /* keep them ahead of the matrix work */
+
 #pragma unroll
         for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
-            /* this iteration's share of the next tile's input (a workgroup's last tile re-reads its own samples
-             * and stages them into the idle buffer) */
-            static_assert(MFM_M_ITERS == 2, "chunk split below assumes two iterations per tile");
-            const int ch_first = it == 0 ? 0 : NCH0, ch_count = it == 0 ? NCH0 : NCH - NCH0;
-            uint4 pre[NCH0];
-#pragma unroll
-            for (int u = 0; u < NCH0; u++) {
-                if (u < ch_count) {
-                    pre[u] = stage_load(have_n ? tile_n : tile, ch_first + u);
-                }
-            }
-
-            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM); /* keep them ahead of the matrix work */
-
-            /* ---- GEMM: 16 rows x (2 x 16) columns x (64*KQ) elements, four byte-plane products ---- */
-            mfm_v4i hh[2], md[2], ll[2];
+            static_assert(MFM_M_ITERS == 2, "two iterations per tile");
+            uint32_t q[2][2];
+            /* The two 16-column groups of an iteration one after the other: three accumulators (hh, md, ll) and one
+             * pair of B fragments are live at a time instead of six and four - the registers that buys go into the
+             * whole-tile prefetch above and into fetching the next k-step's fragments while this one multiplies.
+             * (md is hit twice per k-step; tools/ubench_mfma_dep.hip: hh, md, ll, md runs at the full MFMA rate.) */
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) {
-                hh[gq] = mfm_v4i{ 0, 0, 0, 0 };
-                md[gq] = mfm_v4i{ 0, 0, 0, 0 };
-                ll[gq] = krow;
-            }
-            const uint32_t ibase = it * MFM_M_NEW * rs;
+                /* ---- GEMM: 16 rows x 16 columns x (64*KQ) elements, four byte-plane products ---- */
+                mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = krow;
+                const uint32_t gbase = (it * MFM_M_NEW + 16u * (uint32_t)gq) * rs;
+                mfm_v4i bh[2], bl[2];
+                bh[0] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[0]);
+                bl[0] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[0]);
 #pragma unroll
-            for (int kq = 0; kq < KQ; kq++) {
-                mfm_v4i b_h[2], b_l[2];
-#pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-                    const uint32_t at = ibase + boff[kq] + (uint32_t)gq * 16u * rs;
-                    b_h[gq] = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
-                    b_l[gq] = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
-                }
-                hh[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[0], hh[0], 0, 0, 0);
-                hh[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h[1], hh[1], 0, 0, 0);
-                md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[0], md[0], 0, 0, 0);
-                md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l[1], md[1], 0, 0, 0);
-                ll[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[0], ll[0], 0, 0, 0);
-                ll[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l[1], ll[1], 0, 0, 0);
-                md[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[0], md[0], 0, 0, 0);
-                md[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h[1], md[1], 0, 0, 0);
-            }
-            /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) has been seen to leave the
-             * MFMA -> VALU read hazard unpadded here (caught by the parity tests: tile 0 passed, later tiles did
-             * not).  16 wait states cover a 16x16x64 MFMA. */
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFM_STAMP(6);
-
-            /* ---- epilogue: lane (kg, n) holds channels ch0, ch0+1 for columns n (group 0) and 16+n
-             *      (group 1); written in phases so the four independent chains interleave ---- */
-            uint32_t q[2][2];
-            int pcm[2][2];
-            {
-                /* a + 8192 (mod 2^32); r14(a) truncated to int16 is bits 29:14 (filter/complex.h:30-34) */
-                uint32_t a_re[4], a_im[4], f[4], o_re[4], o_im[4], qq[4];
-#pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        a_re[2 * gq + c] = mfm_combine(hh[gq][2 * c], md[gq][2 * c], ll[gq][2 * c]);
-                        a_im[2 * gq + c] = mfm_combine(hh[gq][2 * c + 1], md[gq][2 * c + 1], ll[gq][2 * c + 1]);
+                for (int kq = 0; kq < KQ; kq++) {
+                    const int cb = kq & 1, nb = cb ^ 1;
+                    if (kq + 1 < KQ) {
+                        bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
+                        bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
                     }
+                    hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
+                    md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
+                    ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
+                    md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
                 }
-                mfm_round_pack4(a_re, a_im, f);
+                /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) has been seen to leave the
+                 * MFMA -> VALU read hazard unpadded here (caught by the parity tests: tile 0 passed, later tiles did
+                 * not).  16 wait states cover a 16x16x64 MFMA. */
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+
+                /* recombine, r14, derotate, r14: lane (kg, n) holds channels ch0, ch0+1 of column 16 gq + n */
+                uint32_t a_re[2], a_im[2], f[2], o_re[2], o_im[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    /* a + 8192 (mod 2^32); r14(a) truncated to int16 is bits 29:14 (filter/complex.h:30-34) */
+                    a_re[c] = mfm_combine(hh[2 * c], md[2 * c], ll[2 * c]);
+                    a_im[c] = mfm_combine(hh[2 * c + 1], md[2 * c + 1], ll[2 * c + 1]);
+                }
+                mfm_round_pack2(a_re, a_im, f);
                 /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
 #pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        mfm_rotate_biased(f[2 * gq + c], rv[gq][c], &o_re[2 * gq + c], &o_im[2 * gq + c]);
-                    }
+                for (int c = 0; c < 2; c++) {
+                    mfm_rotate_biased(f[c], rv[gq][c], &o_re[c], &o_im[c]);
                 }
-                mfm_round_pack4(o_re, o_im, qq);
-#pragma unroll
-                for (int gq = 0; gq < 2; gq++) {
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        q[gq][c] = qq[2 * gq + c];
-                    }
-                }
+                mfm_round_pack2(o_re, o_im, q[gq]);
             }
+            MFM_STAMP(6);
+
+            int pcm[2][2];
             if (it == 0) {
                 /* column 0 of the pass is the last filtered sample of the previous pass */
 #pragma unroll
@@ -502,14 +475,14 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             }
             __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
 
-            /* the prefetched samples go to the other staging buffer */
+            if (it + 1 == MFM_M_ITERS) {
+                /* the prefetched samples go to the other staging buffer */
 #pragma unroll
-            for (int u = 0; u < NCH0; u++) {
-                if (u < ch_count) {
-                    stage_store(cur ^ 1u, ch_first + u, pre[u]);
+                for (int j = 0; j < NCH; j++) {
+                    stage_store(cur ^ 1u, j, pre[j]);
                 }
+                __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
             }
-            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
 
             MFM_STAMP(9);
             /* PCM: every lane stores its four values; the ones that are not outputs (column 0 of group 0, columns
