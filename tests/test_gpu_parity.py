@@ -99,6 +99,20 @@ def test_cfg3_shard_of_1024_channels(pkg, ora, kernel):
     _check(pkg, ora, fs, decim, taps, shard, iq, 1 << 17, want_iq=False, kernel=kernel)
 
 
+@pytest.mark.parametrize("ntaps,want_iq", [(512, False), (512, True), (256, False), (160, False)])
+def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntaps, want_iq):
+    """129..512 taps (the 512-tap etc/flex_25khz_lpf file of BASELINE configs[4]) at the 2.4 MS/s, D = 96 geometry: the
+    MFMA kernel re-reads the tap fragments from L2 in chunks of 128 taps; 24 channels = three row blocks, several
+    blocks so that tiles, passes and the carried state are all exercised."""
+    fs, decim, _, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=24)
+    taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
+    iq = pkg.synth.synth_iq(96 * 2500 + ntaps, fs, offs[:3], seed=ntaps)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 16, want_iq=want_iq)
+    assert eng.stats()["kernel_variant"] == 1, "long filters should run on the matrix cores too"
+    eng.close()
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
+
+
 def test_cfg5_airspy_rate(pkg, ora):
     """BASELINE configs[4] (int16 path): fs 10 MS/s, D=400, 512 taps."""
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=24)
@@ -107,7 +121,8 @@ def test_cfg5_airspy_rate(pkg, ora):
 
 
 @pytest.mark.parametrize("decim,ntaps", [(1, 16), (2, 9), (7, 33), (8, 8), (8, 17), (16, 64), (24, 100), (25, 128),
-                                         (40, 128), (96, 96), (97, 128), (104, 128), (128, 128), (200, 256)])
+                                         (40, 128), (96, 96), (97, 128), (104, 128), (128, 128), (200, 256),
+                                         (96, 512), (96, 256), (64, 300), (40, 200), (8, 160), (48, 129)])
 def test_odd_geometries(pkg, ora, decim, ntaps):
     """decimationFactor 1 (etc/multifm_file.json), taps == decimation, odd tap counts, D not dividing anything."""
     fs = 1000000

@@ -594,7 +594,7 @@ int mfm_engine_commit(struct mfm_engine *e)
      *      in registers and every tap splits into two signed bytes ---- */
     std::vector<uint32_t> afrag;
     std::vector<int32_t> krow;
-    e->use_mfma = (D % 8 == 0) && T <= 32u * MFM_MFMA_KQ_MAX && !getenv("MFM_FORCE_DOT2");
+    e->use_mfma = (D % 8 == 0) && T <= 32u * MFM_MFMA_KQ_STREAM_MAX && !getenv("MFM_FORCE_DOT2");
     for (const Channel &ch : e->chans) {
         for (uint32_t i = 0; i < T && e->use_mfma; i++) {
             if (ch.cre[i] > 32639 || ch.cim[i] > 32639 || ch.cim[i] < -32639) {
@@ -629,7 +629,8 @@ int mfm_engine_commit(struct mfm_engine *e)
             const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
             const uint32_t pb = rows * rs_m;
             /* two staging buffers x two byte planes + atan LUT + staging offsets + rotator constants of up to 256 channels */
-            const uint32_t need = 4u * pb + 2048u + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u + (C <= 256u ? 32u * C : 0u);
+            const uint32_t need = 4u * pb + 2048u + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u + (kq > MFM_MFMA_KQ_MAX ? 2048u : 0u) +
+                                  (C <= 256u ? 32u * C : 0u);
             /* up to 80 KB two workgroups share a CU; beyond that one per CU is still far better than the v_dot2 kernel */
             if (need <= 150u * 1024u && nst / 4u <= MFM_M_CH_MAX * MFM_MFMA_NW * 64u) {
                 ot = cand;
@@ -650,7 +651,7 @@ int mfm_engine_commit(struct mfm_engine *e)
             /* planes at a fixed 16 KiB pitch when they fit and two workgroups still share a CU: the kernel then
              * reaches the low-byte plane and the second staging buffer through instruction immediates */
             e->m_fixed_planes = false;
-            if (plane <= MFM_M_PLANE_DIST) {
+            if (plane <= MFM_M_PLANE_DIST && kq <= MFM_MFMA_KQ_MAX) { /* the streaming variants are built for packed planes */
                 const uint32_t lds_fixed = 4u * MFM_M_PLANE_DIST + (lds - 4u * plane);
                 if (2u * lds_fixed <= 160u * 1024u) {
                     e->m_fixed_planes = true;
@@ -968,7 +969,8 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.fixed_planes = e->m_fixed_planes ? 1u : 0u;
             M.lut_off = e->m_lut_off;
             M.sta_off = e->m_lut_off + 2048u;
-            M.tbl_off = C <= 256u ? M.sta_off + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u : 0u;
+            M.bof_off = M.sta_off + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u;
+            M.tbl_off = C <= 256u ? M.bof_off + (e->m_ks > MFM_MFMA_KQ_MAX ? 2048u : 0u) : 0u;
             M.nslices = e->m_nslices;
             M.nrb = e->m_nrb;
             M.ntiles = (n_new + e->m_ot - 1u) / e->m_ot;

@@ -64,6 +64,7 @@ struct mfm_launch {
  * ------------------------------------------------------------------------------------------- */
 #define MFM_MFMA_NW 8            /* waves per workgroup; each owns 16 GEMM rows = 8 channels */
 #define MFM_MFMA_KQ_MAX 4        /* k-steps of 64 int16 elements (= 32 complex taps) held in registers */
+#define MFM_MFMA_KQ_STREAM_MAX 16 /* longer filters (up to 512 taps): the A operand is streamed from L2 in chunks of 4 k-steps */
 
 #define MFM_M_PLANE_DIST 16384u
 #define MFM_M_CH_MAX 4u /* at most this many 16-byte staging chunks per thread and tile */
@@ -81,6 +82,7 @@ struct mfm_launch_mfma {
                               so the distance is an instruction immediate; 0: packed, plane_bytes apart */
     uint32_t lut_off;     /* byte offset of the atan LUT in LDS */
     uint32_t sta_off;     /* byte offset of the staging-offset table in LDS: [MFM_M_CH_MAX][512 threads] dwords */
+    uint32_t bof_off;     /* streaming variant (kq > 4): byte offset of the B-fragment offset table in LDS, [64 lanes][16] uint16 */
     uint32_t tbl_off;     /* byte offset of the per-channel rotator constants in LDS (8 dwords per channel:
                              mfm_chan_info with kb in pad[0]); 0 = too many channels, read them from global */
     uint32_t nslices;     /* ceil(row blocks / MFM_MFMA_NW) */

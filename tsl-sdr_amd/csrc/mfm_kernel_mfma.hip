@@ -145,8 +145,10 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
 /* KQ = k-steps of 64 elements (32 complex taps); FIXP: planes at a fixed pitch; NCH = 16-byte staging chunks a thread
  * owns per tile = ceil(samples per tile / 4 / 512).  A compile-time count: a chunk nobody needs would still be loaded
  * (loads in this loop are unconditional), and with 62 outputs x 96 samples that was a fourth chunk per thread, 8 KB of
- * somebody else's tile per tile - a third on top of the input traffic. */
-template <int KQ, bool DBG_IQ, bool FIXP, int NCH>
+ * somebody else's tile per tile - a third on top of the input traffic.
+ * KC = 1: the taps (A operand, KQ k-steps) stay in registers for the whole launch.  KC > 1 (filters of 129..512 taps):
+ * KQ = 4 and the A operand is re-read from L2 in KC chunks of four k-steps in every iteration. */
+template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC>
 __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -190,6 +192,16 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     }
 
     /* per-lane LDS byte offset of the B fragment of k-step kq for column n of the first group */
+    if (KC > 1) {
+        /* B-fragment offsets of all 4 * KC k-steps: too many for registers, a division each to recompute -> LDS */
+        uint16_t *bof_w = reinterpret_cast<uint16_t *>(smem + L.bof_off);
+        for (uint32_t i = tid; i < 64u * 16u; i += MFM_M_NT) {
+            const uint32_t ln = i >> 4, kqi = i & 15u;
+            const uint32_t e = 64u * kqi + 16u * (ln >> 4);
+            bof_w[i] = (uint16_t)(((ln & 15u) + e / row_bytes) * rs + e % row_bytes);
+        }
+    }
+    const uint16_t *bof_s = reinterpret_cast<const uint16_t *>(smem + L.bof_off) + lane * 16u;
     uint32_t boff[KQ];
 #pragma unroll
     for (int kq = 0; kq < KQ; kq++) {
@@ -335,20 +347,24 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
         if (slice != slice_loaded) {
             /* A operand: 16 rows x (64*KQ) elements, both byte planes, already in fragment order */
-            const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rbc * KQ * 2 * 64 + mfm_opaque(lane);
+            if (KC == 1) {
+                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rbc * KQ * 2 * 64 + mfm_opaque(lane);
 #pragma unroll
-            for (int kq = 0; kq < KQ; kq++) {
-                a_h[kq] = ap[(kq * 2 + 0) * 64];
-                a_l[kq] = ap[(kq * 2 + 1) * 64];
+                for (int kq = 0; kq < KQ; kq++) {
+                    a_h[kq] = ap[(kq * 2 + 0) * 64];
+                    a_l[kq] = ap[(kq * 2 + 1) * 64];
+                }
             }
             /* 128 * sum_k W[row][k] + 8192 for rows 4kg..4kg+3 */
             krow = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rbc * 16 + 4 * mfm_opaque(kg));
             /* settle these loads now: they stay live across the whole tile loop, and without this the
              * compiler waits vmcnt(0) at their first use in every iteration */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (KC == 1) {
 #pragma unroll
-            for (int kq = 0; kq < KQ; kq++) {
-                asm volatile("" : "+v"(a_h[kq]), "+v"(a_l[kq]));
+                for (int kq = 0; kq < KQ; kq++) {
+                    asm volatile("" : "+v"(a_h[kq]), "+v"(a_l[kq]));
+                }
             }
             asm volatile("" : "+v"(krow));
             slice_loaded = slice;
@@ -377,11 +393,13 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
          * for the full tile instead of one iteration (a workgroup's last tile re-reads its own samples and stages them
          * into the idle buffer). */
         uint4 pre[NCH];
+        if (KC == 1) {
 #pragma unroll
-        for (int j = 0; j < NCH; j++) {
-            pre[j] = stage_load(have_n ? tile_n : tile, j);
+            for (int j = 0; j < NCH; j++) {
+                pre[j] = stage_load(have_n ? tile_n : tile, j);
+            }
+            __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM); /* keep them ahead of the matrix work */
         }
-        __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM); /* keep them ahead of the matrix work */
 
 #pragma unroll
         for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
@@ -391,34 +409,9 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
              * pair of B fragments are live at a time instead of six and four - the registers that buys go into the
              * whole-tile prefetch above and into fetching the next k-step's fragments while this one multiplies.
              * (md is hit twice per k-step; tools/ubench_mfma_dep.hip: hh, md, ll, md runs at the full MFMA rate.) */
-#pragma unroll
-            for (int gq = 0; gq < 2; gq++) {
-                /* ---- GEMM: 16 rows x 16 columns x (64*KQ) elements, four byte-plane products ---- */
-                mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = krow;
-                const uint32_t gbase = (it * MFM_M_NEW + 16u * (uint32_t)gq) * rs;
-                mfm_v4i bh[2], bl[2];
-                bh[0] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[0]);
-                bl[0] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[0]);
-#pragma unroll
-                for (int kq = 0; kq < KQ; kq++) {
-                    const int cb = kq & 1, nb = cb ^ 1;
-                    if (kq + 1 < KQ) {
-                        bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
-                        bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
-                    }
-                    hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
-                    md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
-                    ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
-                    md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
-                }
-                /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) has been seen to leave the
-                 * MFMA -> VALU read hazard unpadded here (caught by the parity tests: tile 0 passed, later tiles did
-                 * not).  16 wait states cover a 16x16x64 MFMA. */
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-
-                /* recombine, r14, derotate, r14: lane (kg, n) holds channels ch0, ch0+1 of column 16 gq + n */
+            /* recombine, r14, derotate, r14 for one column group: lane (kg, n) holds channels ch0, ch0+1 of column
+             * 16 gq + n */
+            auto finish_group = [&](int gq, const mfm_v4i &hh, const mfm_v4i &md, const mfm_v4i &ll) {
                 uint32_t a_re[2], a_im[2], f[2], o_re[2], o_im[2];
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -433,6 +426,86 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     mfm_rotate_biased(f[c], rv[gq][c], &o_re[c], &o_im[c]);
                 }
                 mfm_round_pack2(o_re, o_im, q[gq]);
+            };
+            if (KC > 1) {
+                /* ---- long filters: A operand streamed.  Both column groups accumulate while a chunk of taps is in
+                 *      registers, so every chunk is read once per iteration (8 KB per wave, L2 hits) ---- */
+                mfm_v4i hh2[2], md2[2], ll2[2];
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    hh2[gq] = mfm_v4i{ 0, 0, 0, 0 };
+                    md2[gq] = mfm_v4i{ 0, 0, 0, 0 };
+                    ll2[gq] = krow;
+                }
+                const uint32_t ibase = it * MFM_M_NEW * rs;
+#pragma unroll 1
+                for (int ck = 0; ck < KC; ck++) {
+                    const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) +
+                                        ((size_t)rbc * (KQ * KC) + (size_t)ck * KQ) * 2 * 64 + lane;
+#pragma unroll
+                    for (int kq = 0; kq < KQ; kq++) {
+                        a_h[kq] = ap[(kq * 2 + 0) * 64];
+                        a_l[kq] = ap[(kq * 2 + 1) * 64];
+                    }
+                    const uint2 bo = *reinterpret_cast<const uint2 *>(bof_s + ck * KQ); /* four uint16 offsets */
+                    const uint32_t bo4[4] = { bo.x & 0xffffu, bo.x >> 16, bo.y & 0xffffu, bo.y >> 16 };
+#pragma unroll
+                    for (int kq = 0; kq < KQ; kq++) {
+#pragma unroll
+                        for (int gq = 0; gq < 2; gq++) {
+                            const uint32_t at = ibase + bo4[kq] + (uint32_t)gq * 16u * rs;
+                            const mfm_v4i b_h = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
+                            const mfm_v4i b_l = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
+                            hh2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h, hh2[gq], 0, 0, 0);
+                            md2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l, md2[gq], 0, 0, 0);
+                            ll2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l, ll2[gq], 0, 0, 0);
+                            md2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h, md2[gq], 0, 0, 0);
+                        }
+                    }
+                }
+                if (it == 0) {
+                    /* the next tile's samples: requested behind this iteration's tap loads, so that waiting for taps
+                     * (vmcnt is in order) does not wait for HBM */
+#pragma unroll
+                    for (int j = 0; j < NCH; j++) {
+                        pre[j] = stage_load(have_n ? tile_n : tile, j);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                finish_group(0, hh2[0], md2[0], ll2[0]);
+                finish_group(1, hh2[1], md2[1], ll2[1]);
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    /* ---- GEMM: 16 rows x 16 columns x (64*KQ) elements, four byte-plane products ---- */
+                    mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = krow;
+                    const uint32_t gbase = (it * MFM_M_NEW + 16u * (uint32_t)gq) * rs;
+                    mfm_v4i bh[2], bl[2];
+                    bh[0] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[0]);
+                    bl[0] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[0]);
+    #pragma unroll
+                    for (int kq = 0; kq < KQ; kq++) {
+                        const int cb = kq & 1, nb = cb ^ 1;
+                        if (kq + 1 < KQ) {
+                            bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
+                            bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
+                        }
+                        hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
+                        md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
+                        ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
+                        md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
+                    }
+                    /* The accumulators are read by VALU code right below.  hipcc (ROCm 7.2) has been seen to leave the
+                     * MFMA -> VALU read hazard unpadded here (caught by the parity tests: tile 0 passed, later tiles did
+                     * not).  16 wait states cover a 16x16x64 MFMA. */
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+    
+                    finish_group(gq, hh, md, ll);
+                }
             }
             MFM_STAMP(6);
 
@@ -572,8 +645,10 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         return hipSuccess;
     }
 #define MFM_LAUNCH_N(KQ_, DBG_, FIXP_, NCH_)                                                                 \
+    MFM_LAUNCH_C(KQ_, DBG_, FIXP_, NCH_, 1)
+#define MFM_LAUNCH_C(KQ_, DBG_, FIXP_, NCH_, KC_)                                                            \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_>;                                          \
+        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_>;                                     \
         static uint32_t lds_set_ = 0;                                                                        \
         if (lds_bytes > lds_set_) {                                                                          \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
@@ -613,14 +688,47 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
     if (nch < 1 || nch > MFM_M_CH_MAX) {
         return hipErrorInvalidValue;
     }
+#define MFM_LAUNCH_S(KC_)                                                                                    \
+    do {                                                                                                     \
+        if (dbg_iq) {                                                                                        \
+            switch (nch) {                                                                                   \
+            case 1: MFM_LAUNCH_C(4, true, false, 1, KC_); break;                                             \
+            case 2: MFM_LAUNCH_C(4, true, false, 2, KC_); break;                                             \
+            case 3: MFM_LAUNCH_C(4, true, false, 3, KC_); break;                                             \
+            default: MFM_LAUNCH_C(4, true, false, 4, KC_); break;                                            \
+            }                                                                                                \
+        } else {                                                                                             \
+            switch (nch) {                                                                                   \
+            case 1: MFM_LAUNCH_C(4, false, false, 1, KC_); break;                                            \
+            case 2: MFM_LAUNCH_C(4, false, false, 2, KC_); break;                                            \
+            case 3: MFM_LAUNCH_C(4, false, false, 3, KC_); break;                                            \
+            default: MFM_LAUNCH_C(4, false, false, 4, KC_); break;                                           \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+
     switch (L->kq) {
     case 1: MFM_LAUNCH_KQ(1); break;
     case 2: MFM_LAUNCH_KQ(2); break;
     case 4: MFM_LAUNCH_KQ(4); break;
+    case 8:
+        if (L->fixed_planes) {
+            return hipErrorInvalidValue; /* the streaming variants are built for packed planes only */
+        }
+        MFM_LAUNCH_S(2);
+        break;
+    case 16:
+        if (L->fixed_planes) {
+            return hipErrorInvalidValue;
+        }
+        MFM_LAUNCH_S(4);
+        break;
     default: return hipErrorInvalidValue;
     }
+#undef MFM_LAUNCH_S
 #undef MFM_LAUNCH_KQ
 #undef MFM_LAUNCH_M
 #undef MFM_LAUNCH_N
+#undef MFM_LAUNCH_C
     return hipGetLastError();
 }

@@ -76,6 +76,9 @@ CONFIGS = {
     "cfg3_1024ch": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, nr_channels=1024),
     "pocsag_rtlsdr": dict(fs=1200000, decim=25, taps=128, cutoff=12500.0, offsets=[-320000, -492000],
                           gains_db=[4.0, 0.0]),
+    # the FLEX 25 kHz LPF of configs[4] (512 taps, etc/flex_25khz_lpf*.json) at the 2.4 MS/s / D = 96 geometry
+    "cfg2_64ch_512taps": dict(fs=2400000, decim=96, taps=512, cutoff=12500.0, nr_channels=64),
+    "cfg2_64ch_256taps": dict(fs=2400000, decim=96, taps=256, cutoff=12500.0, nr_channels=64),
     "cfg5_airspy": dict(fs=10000000, decim=400, taps=512, cutoff=12500.0, nr_channels=2048),
 }
 
