@@ -59,7 +59,8 @@ struct mfm_launch {
 
 /* ---------------------------------------------------------------------------------------------
  * FIR-as-GEMM variant (mfm_kernel_mfma.hip): exact int16 arithmetic through four int8 MFMA
- * products.  Used when decimation % 8 == 0, taps <= 32 * MFM_MFMA_KQ_MAX and every tap fits
+ * products.  Used when decimation % 8 == 0, taps <= 32 * MFM_MFMA_KQ_STREAM_MAX (streamed beyond 32 * MFM_MFMA_KQ_MAX),
+ * the tile fits LDS and every tap fits
  * +-32639; otherwise the v_dot2 kernel above runs.
  * ------------------------------------------------------------------------------------------- */
 #define MFM_MFMA_NW 8            /* waves per workgroup; each owns 16 GEMM rows = 8 channels */
