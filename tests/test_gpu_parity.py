@@ -113,6 +113,15 @@ def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntap
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
 
 
+@pytest.mark.parametrize("nch", [1, 7, 61, 65, 130])
+def test_channel_counts_that_do_not_fill_row_blocks(pkg, ora, nch):
+    """The matrix kernel works on blocks of 8 channels per wave and 64 per workgroup slice: counts that leave a row
+    block, a wave or a whole slice partly empty (clamped row blocks, dump-slot stores) must still be exact."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=nch)
+    iq = pkg.synth.synth_iq(96 * 700 + 128, fs, offs[:3], seed=nch)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, gains=gains, want_iq=(nch == 61))
+
+
 def test_cfg5_airspy_rate(pkg, ora):
     """BASELINE configs[4] (int16 path): fs 10 MS/s, D=400, 512 taps."""
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=24)
