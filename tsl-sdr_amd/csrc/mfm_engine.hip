@@ -156,6 +156,7 @@ struct mfm_engine {
     uint32_t m_ks = 0, m_ot = 0, m_rs = 0, m_plane_bytes = 0, m_lut_off = 0, m_krow_off = 0, m_nrb = 0,
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
     bool m_fixed_planes = false;
+    uint32_t m_ah_mask = 0; /* k-steps whose high-byte tap plane is not all zero */
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
 
@@ -682,6 +683,7 @@ int mfm_engine_commit(struct mfm_engine *e)
             };
             /* v_mfma_i32_16x16x64_i8 A operand: lane (kg = lane >> 4, i = lane & 15) holds row i,
              * elements 64*kq + 16*kg + j, j = 0..15 */
+            e->m_ah_mask = 0;
             afrag.assign((size_t)e->m_nrb * kq * 2 * 64 * 4, 0u);
             krow.assign((size_t)e->m_nrb * 16, 0);
             uint8_t *ab = reinterpret_cast<uint8_t *>(afrag.data());
@@ -697,6 +699,9 @@ int mfm_engine_commit(struct mfm_engine *e)
                         const uint32_t kst = k / 64u, gg = (k % 64u) / 16u, j = k % 16u;
                         const uint32_t ln = gg * 16u + i;
                         const size_t base = ((((size_t)rb * kq + kst) * 2u) * 64u + ln) * 16u + j;
+                        if (wh != 0) {
+                            e->m_ah_mask |= 1u << kst;
+                        }
                         ab[base] = (uint8_t)(int8_t)wh;              /* plane 0: high bytes */
                         ab[base + 64u * 16u] = (uint8_t)(int8_t)wl;  /* plane 1: low bytes */
                     }
@@ -977,6 +982,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
             M.nchan = C;
             M.out_stride = e->out_stride;
+            M.ah_mask = getenv("MFM_ALL_PLANES") ? 0xffffu : e->m_ah_mask;
             M.skew = 0; /* measured: no gain on MI355X (tools/ab.sh MFM_SKEW=..); kept as a knob */
             if (const char *sk = getenv("MFM_SKEW")) {
                 M.skew = (uint32_t)atoi(sk);

@@ -90,6 +90,9 @@ struct mfm_launch_mfma {
     uint32_t nrb;         /* row blocks of 16 rows (= 8 channels) */
     uint32_t ntiles, nitems;
     uint32_t nchan, out_stride;
+    uint32_t ah_mask;     /* bit kq set: some tap of k-step kq (32 complex taps) lies outside [-128, 127], i.e. its high-byte
+                             plane is not all zero.  Low-pass taps decay towards both ends, so for the outer k-steps the two
+                             products with the high-byte plane are zero and are not computed. */
     uint32_t skew;        /* units of ~128 clocks waves 4..7 wait after each tile barrier (staggers the LDS-heavy
                              matrix phase of the two halves of a workgroup) */
     uint32_t tail_src, tail_n; /* samples x[tail_src .. tail_src + tail_n) are the history the next block needs ... */

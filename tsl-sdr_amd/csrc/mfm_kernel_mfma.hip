@@ -147,8 +147,9 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
  * (loads in this loop are unconditional), and with 62 outputs x 96 samples that was a fourth chunk per thread, 8 KB of
  * somebody else's tile per tile - a third on top of the input traffic.
  * KC = 1: the taps (A operand, KQ k-steps) stay in registers for the whole launch.  KC > 1 (filters of 129..512 taps):
- * KQ = 4 and the A operand is re-read from L2 in KC chunks of four k-steps in every iteration. */
-template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC>
+ * KQ = 4 and the A operand is re-read from L2 in KC chunks of four k-steps in every iteration.
+ * AHM >= 0: L.ah_mask as a compile-time constant (no branches between the MFMAs of a k-step); -1: read at run time. */
+template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM>
 __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 #endif
     MFM_STAMP(1);
     const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
+    const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
     /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
      * offset field of the LDS instructions instead of costing a v_add each (ds_read has no SGPR offset) */
@@ -456,8 +458,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                             const uint32_t at = ibase + bo4[kq] + (uint32_t)gq * 16u * rs;
                             const mfm_v4i b_h = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
                             const mfm_v4i b_l = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
-                            hh2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h, hh2[gq], 0, 0, 0);
-                            md2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l, md2[gq], 0, 0, 0);
+                            if ((ah_mask >> (ck * KQ + kq)) & 1u) {
+                                hh2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h, hh2[gq], 0, 0, 0);
+                                md2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_l, md2[gq], 0, 0, 0);
+                            }
                             ll2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_l, ll2[gq], 0, 0, 0);
                             md2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h, md2[gq], 0, 0, 0);
                         }
@@ -492,8 +496,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                             bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
                             bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
                         }
-                        hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
-                        md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
+                        if ((ah_mask >> kq) & 1u) { /* uniform: skipped where the high-byte tap plane is all zero */
+                            hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
+                            md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
+                        }
                         ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
                         md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
                     }
@@ -645,10 +651,21 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         return hipSuccess;
     }
 #define MFM_LAUNCH_N(KQ_, DBG_, FIXP_, NCH_)                                                                 \
-    MFM_LAUNCH_C(KQ_, DBG_, FIXP_, NCH_, 1)
-#define MFM_LAUNCH_C(KQ_, DBG_, FIXP_, NCH_, KC_)                                                            \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_>;                                     \
+        /* the usual case - 128-tap low-pass, only the two middle k-steps carry taps beyond one byte - and the  \
+         * all-planes case get branch-free kernels; anything else reads the mask at run time */               \
+        if (KQ_ == 4 && !DBG_ && L->ah_mask == 0x6u) {                                                       \
+            MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, 1, (KQ_ == 4 && !DBG_) ? 0x6 : -1);                         \
+        } else if (KQ_ == 4 && !DBG_ && L->ah_mask == 0xfu) {                                                \
+            MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, 1, (KQ_ == 4 && !DBG_) ? 0xf : -1);                         \
+        } else {                                                                                             \
+            MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, 1, -1);                                                     \
+        }                                                                                                    \
+    } while (0)
+#define MFM_LAUNCH_C(KQ_, DBG_, FIXP_, NCH_, KC_) MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, KC_, -1)
+#define MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_)                                                      \
+    do {                                                                                                     \
+        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_>;                               \
         static uint32_t lds_set_ = 0;                                                                        \
         if (lds_bytes > lds_set_) {                                                                          \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
@@ -730,5 +747,6 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 #undef MFM_LAUNCH_M
 #undef MFM_LAUNCH_N
 #undef MFM_LAUNCH_C
+#undef MFM_LAUNCH_A
     return hipGetLastError();
 }
