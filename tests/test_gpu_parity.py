@@ -123,10 +123,28 @@ def test_channel_counts_that_do_not_fill_row_blocks(pkg, ora, nch):
 
 
 def test_cfg5_airspy_rate(pkg, ora):
-    """BASELINE configs[4] (int16 path): fs 10 MS/s, D=400, 512 taps."""
+    """BASELINE configs[4] (int16 path): fs 10 MS/s, D=400, 512 taps.  A 62-output tile of 400-sample strides does not
+    fit LDS: single-iteration tiles (31 outputs, up to 8 staging chunks per thread) with streamed taps."""
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=24)
     iq = pkg.synth.synth_iq(400 * 900 + 512, fs, offs[:3], seed=24)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 17, want_iq=False)
+    st = eng.stats()
+    eng.close()
+    assert st["kernel_variant"] == 1 and st["outputs_per_tile"] == 31
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17, want_iq=False)
+
+
+@pytest.mark.parametrize("decim,ntaps", [(256, 256), (200, 256), (320, 512), (136, 160), (176, 192), (400, 400)])
+def test_large_decimations_use_single_iteration_tiles(pkg, ora, decim, ntaps):
+    fs = 4000000
+    taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
+    offs = [12345, -250000, 1000000, -1234567, 31250]
+    iq = pkg.synth.synth_iq(decim * 300 + ntaps + 3, fs, offs[:3], seed=decim)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 16, want_iq=False)
+    assert eng.stats()["kernel_variant"] == 1
+    eng.close()
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=(decim == 256))
 
 
 @pytest.mark.parametrize("decim,ntaps", [(1, 16), (2, 9), (7, 33), (8, 8), (8, 17), (16, 64), (24, 100), (25, 128),

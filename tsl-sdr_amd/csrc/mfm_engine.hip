@@ -617,7 +617,7 @@ int mfm_engine_commit(struct mfm_engine *e)
             rs_m += 32u;
         }
         uint32_t ot = 0, plane = 0, lds = 0;
-        const uint32_t want[] = { 2u * 31u }; /* new outputs per tile: two 31-output iterations */
+        const uint32_t want[] = { 2u * 31u, 31u }; /* new outputs per tile: two 31-output iterations, or one for large decimations */
         uint32_t forced_ot = 0;
         if (const char *f = getenv("MFM_OT")) {
             forced_ot = (uint32_t)atoi(f);
@@ -630,10 +630,17 @@ int mfm_engine_commit(struct mfm_engine *e)
             const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
             const uint32_t pb = rows * rs_m;
             /* two staging buffers x two byte planes + atan LUT + staging offsets + rotator constants of up to 256 channels */
-            const uint32_t need = 4u * pb + 2048u + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u + (kq > MFM_MFMA_KQ_MAX ? 2048u : 0u) +
+            const uint32_t nch_t = (nst / 4u + MFM_MFMA_NW * 64u - 1u) / (MFM_MFMA_NW * 64u); /* staging chunks per thread */
+            const uint32_t need = 4u * pb + 2048u + nch_t * MFM_MFMA_NW * 64u * 4u + (kq > MFM_MFMA_KQ_MAX ? 2048u : 0u) +
                                   (C <= 256u ? 32u * C : 0u);
             /* up to 80 KB two workgroups share a CU; beyond that one per CU is still far better than the v_dot2 kernel */
-            if (need <= 150u * 1024u && nst / 4u <= MFM_M_CH_MAX * MFM_MFMA_NW * 64u) {
+            /* the kernels are built for up to 4 chunks per thread with two iterations, up to MFM_M_CH_MAX with one
+             * (and then only for 128-tap-class and longer filters) */
+            const uint32_t nch_max = cand == 62u ? 4u : MFM_M_CH_MAX;
+            if (cand == 31u && kq < MFM_MFMA_KQ_MAX) {
+                continue;
+            }
+            if (need <= 150u * 1024u && nch_t <= nch_max) {
                 ot = cand;
                 plane = pb;
                 lds = need;
@@ -652,7 +659,7 @@ int mfm_engine_commit(struct mfm_engine *e)
             /* planes at a fixed 16 KiB pitch when they fit and two workgroups still share a CU: the kernel then
              * reaches the low-byte plane and the second staging buffer through instruction immediates */
             e->m_fixed_planes = false;
-            if (plane <= MFM_M_PLANE_DIST && kq <= MFM_MFMA_KQ_MAX) { /* the streaming variants are built for packed planes */
+            if (plane <= MFM_M_PLANE_DIST && kq <= MFM_MFMA_KQ_MAX && ot == 62u) { /* streaming / single-iteration variants: packed planes */
                 const uint32_t lds_fixed = 4u * MFM_M_PLANE_DIST + (lds - 4u * plane);
                 if (2u * lds_fixed <= 160u * 1024u) {
                     e->m_fixed_planes = true;
@@ -974,7 +981,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.fixed_planes = e->m_fixed_planes ? 1u : 0u;
             M.lut_off = e->m_lut_off;
             M.sta_off = e->m_lut_off + 2048u;
-            M.bof_off = M.sta_off + MFM_M_CH_MAX * MFM_MFMA_NW * 64u * 4u;
+            M.bof_off = M.sta_off + ((M.nstage / 4u + MFM_MFMA_NW * 64u - 1u) / (MFM_MFMA_NW * 64u)) * MFM_MFMA_NW * 64u * 4u;
             M.tbl_off = C <= 256u ? M.bof_off + (e->m_ks > MFM_MFMA_KQ_MAX ? 2048u : 0u) : 0u;
             M.nslices = e->m_nslices;
             M.nrb = e->m_nrb;

@@ -68,14 +68,15 @@ struct mfm_launch {
 #define MFM_MFMA_KQ_STREAM_MAX 16 /* longer filters (up to 512 taps): the A operand is streamed from L2 in chunks of 4 k-steps */
 
 #define MFM_M_PLANE_DIST 16384u
-#define MFM_M_CH_MAX 4u /* at most this many 16-byte staging chunks per thread and tile */
+#define MFM_M_CH_MAX 8u /* at most this many 16-byte staging chunks per thread and tile */
 
 struct mfm_launch_mfma {
     const uint32_t *x;
     uint32_t n_avail, n_new, decim;
     uint32_t x_last4;     /* last sample index at which a 16-byte load stays inside the input buffer (multiple of 4) */
     uint32_t kq;          /* k-steps of 64 elements: padded taps = 32 * kq */
-    uint32_t ot;          /* NEW outputs per workgroup tile: 31 per N-tile of 32 columns */
+    uint32_t ot;          /* NEW outputs per workgroup tile: 31 per iteration of 32 columns, two iterations (62) or, for
+                             decimations whose 62-output tile does not fit LDS, one (31) */
     uint32_t nstage;      /* samples staged per tile: ot*D + 32*kq, rounded up to 4 */
     uint32_t rs;          /* LDS row stride in bytes (row = 2*D plane bytes), an odd multiple of 32 */
     uint32_t plane_bytes; /* bytes of one byte-plane in LDS (16-byte multiple) */

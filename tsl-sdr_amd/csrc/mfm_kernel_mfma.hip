@@ -61,7 +61,6 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #define MFM_M_NEW 31 /* new outputs per 32-column iteration */
 /* sched_barrier mask: ALU | VALU | SALU | MFMA | DS | DS-read | DS-write may cross, vector memory may not */
 #define MFM_SCHED_ALL_BUT_VMEM 0x38F
-#define MFM_M_ITERS 2 /* iterations per tile: a tile is 62 new outputs */
 
 /* (hh << 16) + (md << 8) + ll: the recombined sum, K + 8192 riding in through ll.  Two v_lshl_add_u32; left to
  * itself the compiler canonicalises the expression into two shifts and a three-operand add. */
@@ -148,8 +147,9 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
  * somebody else's tile per tile - a third on top of the input traffic.
  * KC = 1: the taps (A operand, KQ k-steps) stay in registers for the whole launch.  KC > 1 (filters of 129..512 taps):
  * KQ = 4 and the A operand is re-read from L2 in KC chunks of four k-steps in every iteration.
+ * NIT = iterations (31 new outputs each) per tile: 2, or 1 when a 62-output tile does not fit LDS (large decimations).
  * AHM >= 0: L.ah_mask as a compile-time constant (no branches between the MFMAs of a k-step); -1: read at run time. */
-template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM>
+template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM, int NIT>
 __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
          * for the full tile instead of one iteration (a workgroup's last tile re-reads its own samples and stages them
          * into the idle buffer). */
         uint4 pre[NCH];
-        if (KC == 1) {
+        if (KC == 1 && NIT == 2) {
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
                 pre[j] = stage_load(have_n ? tile_n : tile, j);
@@ -404,8 +404,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         }
 
 #pragma unroll
-        for (uint32_t it = 0; it < MFM_M_ITERS; it++) {
-            static_assert(MFM_M_ITERS == 2, "two iterations per tile");
+        for (uint32_t it = 0; it < NIT; it++) {
             uint32_t q[2][2];
             /* The two 16-column groups of an iteration one after the other: three accumulators (hh, md, ll) and one
              * pair of B fragments are live at a time instead of six and four - the registers that buys go into the
@@ -513,6 +512,14 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     finish_group(gq, hh, md, ll);
                 }
             }
+            if (KC == 1 && NIT == 1) {
+                /* single-iteration tiles are the big ones (up to 8 chunks per thread): requested behind the matrix
+                 * work, when the accumulators are about to die */
+#pragma unroll
+                for (int j = 0; j < NCH; j++) {
+                    pre[j] = stage_load(have_n ? tile_n : tile, j);
+                }
+            }
             MFM_STAMP(6);
 
             int pcm[2][2];
@@ -547,14 +554,14 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             MFM_STAMP(8);
             /* rotator entries of the next iteration (of the next tile after the last one) */
             uint2 rvn[2][2];
-            if (it + 1 < MFM_M_ITERS) {
+            if (it + 1 < NIT) {
                 rot_load(k_off, it + 1, rvn);
             } else {
                 rot_load(k_off_n, 0, rvn);
             }
             __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
 
-            if (it + 1 == MFM_M_ITERS) {
+            if (it + 1 == NIT) {
                 /* the prefetched samples go to the other staging buffer */
 #pragma unroll
                 for (int j = 0; j < NCH; j++) {
@@ -663,9 +670,10 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         }                                                                                                    \
     } while (0)
 #define MFM_LAUNCH_C(KQ_, DBG_, FIXP_, NCH_, KC_) MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, KC_, -1)
-#define MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_)                                                      \
+#define MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_) MFM_LAUNCH_T(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, 2)
+#define MFM_LAUNCH_T(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_)                                                \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_>;                               \
+        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_>;                         \
         static uint32_t lds_set_ = 0;                                                                        \
         if (lds_bytes > lds_set_) {                                                                          \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
@@ -724,6 +732,44 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         }                                                                                                    \
     } while (0)
 
+    if (L->ot == MFM_M_NEW) {
+        /* single-iteration tiles (large decimations): 128-tap-class and streamed filters, packed planes */
+        if (L->fixed_planes || (L->kq != 4 && L->kq != 8 && L->kq != 16)) {
+            return hipErrorInvalidValue;
+        }
+#define MFM_LAUNCH_1N(DBG_, KC_)                                                                             \
+    do {                                                                                                     \
+        switch (nch) {                                                                                       \
+        case 1: MFM_LAUNCH_T(4, DBG_, false, 1, KC_, -1, 1); break;                                          \
+        case 2: MFM_LAUNCH_T(4, DBG_, false, 2, KC_, -1, 1); break;                                          \
+        case 3: MFM_LAUNCH_T(4, DBG_, false, 3, KC_, -1, 1); break;                                          \
+        case 4: MFM_LAUNCH_T(4, DBG_, false, 4, KC_, -1, 1); break;                                          \
+        case 5: MFM_LAUNCH_T(4, DBG_, false, 5, KC_, -1, 1); break;                                          \
+        case 6: MFM_LAUNCH_T(4, DBG_, false, 6, KC_, -1, 1); break;                                          \
+        case 7: MFM_LAUNCH_T(4, DBG_, false, 7, KC_, -1, 1); break;                                          \
+        default: MFM_LAUNCH_T(4, DBG_, false, 8, KC_, -1, 1); break;                                         \
+        }                                                                                                    \
+    } while (0)
+#define MFM_LAUNCH_1(KC_)                                                                                    \
+    do {                                                                                                     \
+        if (dbg_iq) {                                                                                        \
+            MFM_LAUNCH_1N(true, KC_);                                                                        \
+        } else {                                                                                             \
+            MFM_LAUNCH_1N(false, KC_);                                                                       \
+        }                                                                                                    \
+    } while (0)
+        switch (L->kq) {
+        case 4: MFM_LAUNCH_1(1); break;
+        case 8: MFM_LAUNCH_1(2); break;
+        default: MFM_LAUNCH_1(4); break;
+        }
+#undef MFM_LAUNCH_1
+#undef MFM_LAUNCH_1N
+        return hipGetLastError();
+    }
+    if (nch > 4) {
+        return hipErrorInvalidValue; /* two-iteration tiles are built for up to 4 chunks per thread */
+    }
     switch (L->kq) {
     case 1: MFM_LAUNCH_KQ(1); break;
     case 2: MFM_LAUNCH_KQ(2); break;
@@ -748,5 +794,6 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 #undef MFM_LAUNCH_N
 #undef MFM_LAUNCH_C
 #undef MFM_LAUNCH_A
+#undef MFM_LAUNCH_T
     return hipGetLastError();
 }
