@@ -3,11 +3,15 @@
  * real-valued rational resampler (filter/polyphase_fir.c, filter/utils.c) and DC blocker
  * (filter/dc_blocker.h).  See include/multifm_hip.h for the boundary and the reference lines.
  *
- * Kernel shape: grid = (output blocks, channels); one thread per output.  All channels share the phase
- * walk (they receive the same number of samples), so output j of a call starts at sample
- * (p0 + j*D) / I with phase (p0 + j*D) % I.  The phase filters (I x phase_len int16) sit in LDS; the PCM
- * windows overlap heavily between neighbouring threads and come through L1/L2.  This stage moves two
- * bytes per output and is nowhere near any roof; it exists so the whole chain stays on the device.
+ * Kernel shape: grid = (blocks of 1024 outputs, channels).  All channels share the phase walk (they receive the
+ * same number of samples), so output j of a call starts at sample (p0 + j*D) / I with phase (p0 + j*D) % I.
+ * A workgroup copies the input window of its 1024 outputs (about 1024 * D / I + phase length samples) into LDS -
+ * straight from where the samples lie: the unconsumed tail of the previous call (a few dozen samples per channel,
+ * ping-pong buffers) followed by the caller's PCM, no staging copy - and every thread computes 4 outputs as
+ * v_dot2_i32_i16 over sample pairs (int32 wrap-around like filter/utils.c:94-103; an odd window start costs one
+ * funnel shift per pair).  When 256 * D is a multiple of I - 4/5 for POCSAG, 16/25 for FLEX - a thread's four
+ * outputs share one phase and its coefficient pairs stay in registers; otherwise they are read from LDS.
+ * HBM traffic: 2 bytes in + 2 * I / D bytes out per PCM sample.
  * The DC blocker is a sequential IIR with a truncating shift in the loop (not associative): one thread
  * per channel.
  */
@@ -26,38 +30,122 @@ extern "C" __attribute__((visibility("hidden"))) void mfm_internal_set_error(con
 namespace {
 
 struct RsLaunch {
-    const int16_t *x; /* [C][in_cap]: carried tail followed by the new samples */
-    int16_t *y;       /* [C][out_cap] */
+    const int16_t *tail;  /* [C][tail_cap]: what the previous call left unconsumed */
+    const int16_t *pcm;   /* [C][in_stride]: this call's samples, where the caller has them */
+    int16_t *y;           /* [C][out_cap] */
     const int16_t *phase; /* [I][plen] */
-    uint32_t in_cap, out_cap, n_out, plen, interp, decim, p0, nchan, invert;
+    int16_t *tail_out;    /* [C][tail_cap]: what this call leaves unconsumed (mfm_rs_tail_kernel) */
+    size_t in_stride;
+    uint32_t tail_len, nr_in, tail_cap, out_cap, n_out, plen, interp, decim, p0, nchan, invert;
+    uint32_t pos_end, new_tail;
 };
 
-__global__ __launch_bounds__(256) void mfm_resample_kernel(const RsLaunch L)
+constexpr uint32_t RS_NT = 256, RS_OPT = 4, RS_OPB = RS_NT * RS_OPT; /* threads, outputs per thread / per block */
+constexpr uint32_t RS_PAIRS_MAX = 32;                                /* register-resident phase: up to 64 taps */
+
+/* sample v of channel c in the virtual stream "tail, then the new samples"; decoder -i negates on int16 storage */
+__device__ __forceinline__ int16_t rs_sample(const RsLaunch &L, uint32_t c, uint32_t v)
 {
-    extern __shared__ int16_t ph_s[];
-    for (uint32_t i = threadIdx.x; i < L.interp * L.plen; i += blockDim.x) {
-        ph_s[i] = L.phase[i];
+    int16_t s = 0;
+    if (v < L.tail_len) {
+        s = L.tail[(size_t)c * L.tail_cap + v];
+    } else if (v - L.tail_len < L.nr_in) {
+        s = L.pcm[(size_t)c * L.in_stride + (v - L.tail_len)];
+    }
+    return L.invert ? (int16_t)(-s) : s; /* decoder.c:624: samp[i] *= -1 */
+}
+
+/* NP > 0: coefficient pairs of the thread's phase in registers, NP = pairs per phase rounded up to a multiple of 4
+ * (the padding pairs are zero); NP = 0: pairs read from LDS, any phase length */
+template <int NP>
+__global__ __launch_bounds__(RS_NT) void mfm_resample_kernel(const RsLaunch L)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t rs_smem[];
+    uint32_t *ph_s = reinterpret_cast<uint32_t *>(rs_smem);                 /* [I][plen / 2] coefficient pairs */
+    const uint32_t npairs = L.plen / 2u;                                     /* plen is a multiple of 4 */
+    int16_t *x_s = reinterpret_cast<int16_t *>(rs_smem + (size_t)L.interp * L.plen * 2u);
+    const uint32_t c = blockIdx.y, tid = threadIdx.x;
+    const uint32_t j0 = blockIdx.x * RS_OPB;
+    const uint32_t j1 = (j0 + RS_OPB < L.n_out ? j0 + RS_OPB : L.n_out) - 1u; /* last output of the block */
+    /* filter/polyphase_fir.c:206-211 unrolled to output j: position (p0 + j D) / I, phase (p0 + j D) % I */
+    /* p0 + j D fits 32 bits for every output of a call (create() checks out_cap * D < 2^32) */
+    const uint32_t in_lo = ((L.p0 + j0 * L.decim) / L.interp) & ~1u;
+    const uint32_t in_hi = (L.p0 + j1 * L.decim) / L.interp + L.plen + 2u + 8u; /* + the zero-padded pairs */
+    for (uint32_t i = tid; i < L.interp * npairs; i += RS_NT) {
+        ph_s[i] = reinterpret_cast<const uint32_t *>(L.phase)[i];
+    }
+    for (uint32_t v = in_lo + tid; v < in_hi; v += RS_NT) {
+        x_s[v - in_lo] = rs_sample(L, c, v);
     }
     __syncthreads();
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    if (j >= L.n_out) {
-        return;
-    }
-    /* filter/polyphase_fir.c:206-211 unrolled to output j */
-    const uint64_t t = (uint64_t)L.p0 + (uint64_t)j * L.decim;
-    const uint32_t pos = (uint32_t)(t / L.interp), ph = (uint32_t)(t % L.interp);
-    const int16_t *xw = L.x + (size_t)c * L.in_cap + pos;
-    const int16_t *cf = ph_s + ph * L.plen;
-    uint32_t acc = 0; /* filter/utils.c:94-103, int32 wrap-around */
-    for (uint32_t k = 0; k < L.plen; k++) {
-        int32_t s = xw[k];
-        if (L.invert) {
-            s = (int16_t)(-s); /* decoder.c:624: samp[i] *= -1 on int16 */
+    const uint32_t *x32 = reinterpret_cast<const uint32_t *>(x_s);
+
+    /* one division per thread: its outputs are RS_NT apart, so position and phase advance by constants */
+    const uint32_t t_first = L.p0 + (j0 + tid) * L.decim;
+    uint32_t pos_abs = t_first / L.interp, ph = t_first - pos_abs * L.interp;
+    const uint32_t step_pos = (RS_NT * L.decim) / L.interp, step_ph = (RS_NT * L.decim) % L.interp;
+    constexpr bool REGCOEF = NP > 0;
+    uint32_t cw[REGCOEF ? NP : 1];
+    if (REGCOEF) {
+        /* 256 * D is a multiple of I: outputs tid, tid + 256, ... of this block have the same phase */
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)NP; i++) {
+            cw[i] = i < npairs ? ph_s[ph * npairs + i] : 0u;
         }
-        acc += (uint32_t)(s * (int32_t)cf[k]);
     }
-    L.y[(size_t)c * L.out_cap + j] = (int16_t)mfm_r14_wide((int32_t)acc); /* utils.c:112 */
+#pragma unroll
+    for (uint32_t u = 0; u < RS_OPT; u++) {
+        const uint32_t j = j0 + tid + u * RS_NT;
+        if (j >= L.n_out) {
+            break;
+        }
+        const uint32_t pos = pos_abs - in_lo;
+        const uint32_t *xw = x32 + (pos >> 1);
+        const uint32_t sh = (pos & 1u) * 16u;
+        int32_t acc = 0; /* filter/utils.c:94-103, int32 wrap-around */
+        uint32_t lo = xw[0];
+        if (REGCOEF) {
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)NP; i++) {
+                const uint32_t hi = xw[i + 1];
+                const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, sh); /* samples pos + 2i, pos + 2i + 1 */
+                asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(acc) : "v"(pr), "v"(cw[i]));
+                lo = hi;
+            }
+        } else {
+            const uint32_t *cp = ph_s + ph * npairs;
+            for (uint32_t i = 0; i < npairs; i++) {
+                const uint32_t hi = xw[i + 1];
+                const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, sh);
+                asm("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(acc) : "v"(pr), "v"(cp[i]));
+                lo = hi;
+            }
+        }
+        asm volatile("s_nop 2" : "+v"(acc)); /* a DOT result needs 3 wait states before other VALU code reads it */
+        L.y[(size_t)c * L.out_cap + j] = (int16_t)mfm_r14_wide(acc); /* utils.c:112 */
+        pos_abs += step_pos;
+        ph += step_ph;
+        if (ph >= L.interp) {
+            ph -= L.interp;
+            pos_abs += 1u;
+        }
+    }
+}
+
+/* what this call leaves unconsumed: samples pos_end .. pos_end + new_tail of the virtual stream (new_tail <= plen) */
+__global__ void mfm_rs_tail_kernel(const RsLaunch L)
+{
+    const uint32_t c = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < L.new_tail; i += blockDim.x) {
+        int16_t s = 0;
+        const uint32_t v = L.pos_end + i;
+        if (v < L.tail_len) {
+            s = L.tail[(size_t)c * L.tail_cap + v];
+        } else if (v - L.tail_len < L.nr_in) {
+            s = L.pcm[(size_t)c * L.in_stride + (v - L.tail_len)];
+        }
+        L.tail_out[(size_t)c * L.tail_cap + i] = s; /* stored as received: inversion is applied on use */
+    }
 }
 
 struct DcState {
@@ -91,12 +179,15 @@ struct mfm_resampler {
     uint32_t plen = 0;
     uint32_t in_cap = 0, out_cap = 0;
     int16_t *d_phase = nullptr;
-    int16_t *d_x[2] = { nullptr, nullptr };
+    int16_t *d_x[2] = { nullptr, nullptr }; /* [C][tail_cap] ping-pong: the samples the last call left unconsumed */
+    uint32_t tail_cap = 0;
+    uint32_t lds_bytes = 0;
+    bool reg_coef = false;
     int16_t *d_y = nullptr;
     DcState *d_dc = nullptr;
     int32_t dc_p = 0;
     int cur = 0;
-    uint32_t tail = 0; /* unconsumed samples at the front of d_x[cur] */
+    uint32_t tail = 0; /* unconsumed samples in d_x[cur] */
     uint32_t phase_id = 0;
     int16_t *d_stage = nullptr; /* process_host_to_device: [C][max_in_samples] */
 };
@@ -159,9 +250,27 @@ int mfm_resampler_create(struct mfm_resampler **pr, const struct mfm_resampler_c
     RS_TRY(hipSetDevice(cfg->device));
     RS_TRY(hipMalloc(&r->d_phase, ph.size() * 2));
     RS_TRY(hipMemcpy(r->d_phase, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+    r->tail_cap = plen + 8; /* never more than plen samples are left over (see process_device) */
     for (int i = 0; i < 2; i++) {
-        RS_TRY(hipMalloc(&r->d_x[i], (size_t)cfg->nr_channels * r->in_cap * 2));
-        RS_TRY(hipMemset(r->d_x[i], 0, (size_t)cfg->nr_channels * r->in_cap * 2));
+        RS_TRY(hipMalloc(&r->d_x[i], (size_t)cfg->nr_channels * r->tail_cap * 2));
+        RS_TRY(hipMemset(r->d_x[i], 0, (size_t)cfg->nr_channels * r->tail_cap * 2));
+    }
+    /* LDS of a workgroup: coefficient pairs + the input window of RS_OPB outputs */
+    r->lds_bytes = (uint32_t)((size_t)cfg->interpolate * plen * 2 +
+                              (((uint64_t)RS_OPB * cfg->decimate) / cfg->interpolate + plen + 32) * 2);
+    r->lds_bytes = (r->lds_bytes + 15u) & ~15u;
+    if (r->lds_bytes > 150u * 1024u) {
+        snprintf(g_rs_error, sizeof(g_rs_error), "resampling ratio %u/%u with %u taps per phase needs %u bytes of LDS per workgroup",
+                 cfg->interpolate, cfg->decimate, plen, r->lds_bytes);
+        mfm_internal_set_error(g_rs_error);
+        return MFM_E_INVAL;
+    }
+    r->reg_coef = ((uint64_t)RS_NT * cfg->decimate) % cfg->interpolate == 0 && plen / 2 <= RS_PAIRS_MAX;
+    if (r->lds_bytes > 48u * 1024u) {
+        /* only extreme decimation ratios get here: they use the LDS-coefficient variant */
+        r->reg_coef = false;
+        RS_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_resample_kernel<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
     RS_TRY(hipMalloc(&r->d_y, (size_t)cfg->nr_channels * r->out_cap * 2));
     RS_TRY(hipMalloc(&r->d_dc, (size_t)cfg->nr_channels * sizeof(DcState)));
@@ -199,17 +308,12 @@ int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, 
     if (!r || !d_pcm || !d_out || !out_stride || !nr_out) {
         return MFM_E_INVAL;
     }
-    if (nr_in > r->cfg.max_in_samples || r->tail + nr_in > r->in_cap) {
+    if (nr_in > r->cfg.max_in_samples) {
         return MFM_E_INVAL;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t C = r->cfg.nr_channels, I = r->cfg.interpolate, D = r->cfg.decimate;
     RS_TRY(hipSetDevice(r->cfg.device));
-    int16_t *x = r->d_x[r->cur];
-    if (nr_in) {
-        RS_TRY(hipMemcpy2DAsync(x + r->tail, (size_t)r->in_cap * 2, d_pcm, in_stride * 2, nr_in * 2, C,
-                                hipMemcpyDeviceToDevice, s));
-    }
     const uint32_t total = r->tail + (uint32_t)nr_in;
     /* outputs m with total - pos_m > plen  <=>  p0 + m*D < (total - plen) * I   (polyphase_fir.c:184) */
     uint32_t n_out = 0;
@@ -219,10 +323,27 @@ int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, 
             n_out = (uint32_t)((lim - r->phase_id + D - 1) / D);
         }
     }
+    const uint64_t t_end = (uint64_t)r->phase_id + (uint64_t)n_out * D;
+    const uint32_t pos_end = (uint32_t)(t_end / I);
+    /* pos_end <= total (create() checked ceil(D/I) <= plen) and total - pos_end <= plen: with outputs, t_end >= (total -
+     * plen) * I; without, total <= plen */
+    const uint32_t new_tail = total - pos_end;
+    RsLaunch L{ r->d_x[r->cur], d_pcm, r->d_y, r->d_phase, r->d_x[r->cur ^ 1], in_stride, r->tail, (uint32_t)nr_in, r->tail_cap,
+                r->out_cap, n_out, r->plen, I, D, r->phase_id, C, r->cfg.invert, pos_end, new_tail };
     if (n_out) {
-        RsLaunch L{ x, r->d_y, r->d_phase, r->in_cap, r->out_cap, n_out, r->plen, I, D, r->phase_id, C, r->cfg.invert };
-        const dim3 grid((n_out + 255) / 256, C);
-        hipLaunchKernelGGL(mfm_resample_kernel, grid, dim3(256), (size_t)I * r->plen * 2, s, L);
+        const dim3 grid((n_out + RS_OPB - 1) / RS_OPB, C);
+        const uint32_t np4 = r->reg_coef ? (r->plen / 2u + 3u) / 4u : 0u; /* register variant: pairs rounded up to 4 */
+        switch (np4) {
+        case 1: hipLaunchKernelGGL(mfm_resample_kernel<4>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 2: hipLaunchKernelGGL(mfm_resample_kernel<8>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 3: hipLaunchKernelGGL(mfm_resample_kernel<12>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 4: hipLaunchKernelGGL(mfm_resample_kernel<16>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 5: hipLaunchKernelGGL(mfm_resample_kernel<20>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 6: hipLaunchKernelGGL(mfm_resample_kernel<24>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 7: hipLaunchKernelGGL(mfm_resample_kernel<28>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        case 8: hipLaunchKernelGGL(mfm_resample_kernel<32>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        default: hipLaunchKernelGGL(mfm_resample_kernel<0>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
+        }
         RS_TRY(hipGetLastError());
         if (r->cfg.dc_block) {
             hipLaunchKernelGGL(mfm_dc_block_kernel, dim3((C + 63) / 64), dim3(64), 0, s, r->d_y, r->out_cap, n_out, C,
@@ -230,14 +351,11 @@ int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, 
             RS_TRY(hipGetLastError());
         }
     }
-    const uint64_t t_end = (uint64_t)r->phase_id + (uint64_t)n_out * D;
-    const uint32_t pos_end = (uint32_t)(t_end / I);
-    r->phase_id = (uint32_t)(t_end % I);
-    const uint32_t new_tail = total - pos_end; /* pos_end <= total: create() checked ceil(D/I) <= plen */
     if (new_tail) {
-        RS_TRY(hipMemcpy2DAsync(r->d_x[r->cur ^ 1], (size_t)r->in_cap * 2, x + pos_end, (size_t)r->in_cap * 2,
-                                (size_t)new_tail * 2, C, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(mfm_rs_tail_kernel, dim3(C), dim3(64), 0, s, L);
+        RS_TRY(hipGetLastError());
     }
+    r->phase_id = (uint32_t)(t_end % I);
     r->tail = new_tail;
     r->cur ^= 1;
     *d_out = r->d_y;
