@@ -266,7 +266,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)mfm_opaque(chs) * 8;
                 inf = *reinterpret_cast<const uint4 *>(ip);
                 lam_magic = ip[4];
-                kb = L.st_in[mfm_opaque(chs)].kb;
+                /* volatile: otherwise the compiler merges this load with the LDS one above into a flat_load through a
+                 * selected pointer, and a flat load makes every tile wait for vmcnt(0) before it can place its rotator
+                 * entries (no measurable difference in the end, but the tile prologue is free of vector memory now) */
+                kb = *reinterpret_cast<const volatile uint32_t *>(&L.st_in[mfm_opaque(chs)].kb);
             }
             const uint32_t mu = inf.z, lam = inf.w;
             int k = (int)kb + rel_first; /* >= -1; entry -1 of every table is a readable dummy */
