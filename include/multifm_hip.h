@@ -297,6 +297,58 @@ int mfm_bch3121_decode_device(uint32_t *d_words, uint8_t *d_rc, size_t n, int de
 int mfm_bch3121_decode_host(uint32_t *words, uint8_t *rc, size_t n, int device);
 
 /*
+ * ---- Floating-point IQ path (BASELINE.json configs[4] "fp32 vs int16 IQ path") ---------
+ * The reference has no floating-point channel path.  This is multifm's per-channel loop
+ *
+ *   _demod_fir_prepare               multifm/demod.c:204-269       taps = (gain * cexp(j f_offs i)) * h[i], NOT quantised
+ *   direct_fir_process               filter/direct_fir.c:328-453   complex FIR, decimation D, derotation by
+ *                                                                  cexp(-j 2 pi off D n / fs) (closed form of :151-172)
+ *   multifm_fm_demod_process         multifm/fm_demod.c:36-85      s = o[n] conj(o[n-1]), fast_atan2f, phi/pi*16384
+ *
+ * on float32 interleaved IQ (any scale) in fp32 arithmetic.  Parity target: oracle/f32_oracle.c (the same in fp64),
+ * 1e-5 relative (tests/test_f32_path.py).  PCM comes out as float and, truncated like fm_demod.c:72, as int16 laid
+ * out like the integer engine's ([channel][stride]) so that mfm_resampler_* / mfm_pocsag_* take it unchanged.
+ * All channels of an engine share one filter length (>= the decimation).
+ */
+struct mfm_f32_engine; /* opaque */
+
+#define MFM_F32_WANT_IQ 1u /* also keep the derotated filtered samples (signalDebugFile analogue) */
+
+struct mfm_f32_config {
+    uint32_t abi_version; /* MFM_ABI_VERSION */
+    int32_t device;
+    uint32_t sample_rate_hz;
+    uint32_t decimation;
+    uint32_t max_block_samples; /* most IQ samples one process call may carry */
+    uint32_t flags;             /* MFM_F32_* */
+};
+
+struct mfm_f32_block {
+    float *d_pcm_f32;     /* device, [channel][stride] */
+    int16_t *d_pcm_i16;   /* device, [channel][stride] */
+    float *d_iq_f32;      /* device, [channel][stride] (re, im) pairs, NULL without MFM_F32_WANT_IQ */
+    size_t stride;        /* elements between channels */
+    size_t nr_out;        /* outputs per channel of this call */
+    uint32_t nr_channels;
+    uint32_t reserved;
+};
+
+int mfm_f32_create(struct mfm_f32_engine **pe, const struct mfm_f32_config *cfg);
+/* same arguments as demod_thread_new's offset / taps / gain (multifm/demod.h:104-110); returns the channel index */
+int mfm_f32_add_channel(struct mfm_f32_engine *e, int32_t offset_hz, const double *lpf_taps, size_t nr_taps,
+                        double gain);
+int mfm_f32_commit(struct mfm_f32_engine *e);
+void mfm_f32_destroy(struct mfm_f32_engine **pe);
+size_t mfm_f32_max_out(const struct mfm_f32_engine *e);
+/* nr_samples float IQ pairs in device memory; work is queued on `stream`, the block's pointers are valid until the
+ * next call.  The stream position (unconsumed samples, output phase, discriminator history) carries over. */
+int mfm_f32_process_device(struct mfm_f32_engine *e, const float *d_iq, size_t nr_samples, void *stream,
+                           struct mfm_f32_block *out);
+/* Host convenience (tests): synchronous, any of the three outputs may be NULL; out_stride in elements. */
+int mfm_f32_process_host(struct mfm_f32_engine *e, const float *iq, size_t nr_samples, float *pcm_f32,
+                         int16_t *pcm_i16, float *iq_f32, size_t out_stride, size_t *nr_out);
+
+/*
  * Host twins of the kernel's scalar numerics (compiled from the same header the kernel uses).
  * They exist so the test-suite can check, on the CPU, that the device formulas reproduce the
  * reference's expressions bit for bit; they are not a compute path.

@@ -91,6 +91,15 @@ def lib():
         o.mfmo_pocsag_msgdec_free.restype = None
         o.mfmo_pocsag_msgdec_batch.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
                                                C.POINTER(C.c_size_t)]
+        f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        o.mfmo_f32_chan_new.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, f64p, C.c_size_t, C.c_double]
+        o.mfmo_f32_chan_new.restype = C.c_void_p
+        o.mfmo_f32_chan_free.argtypes = [C.c_void_p]
+        o.mfmo_f32_chan_free.restype = None
+        o.mfmo_f32_chan_taps.argtypes = [C.c_void_p, f64p, f64p]
+        o.mfmo_f32_chan_taps.restype = None
+        o.mfmo_f32_chan_push.argtypes = [C.c_void_p, f32p, C.c_size_t, f64p, f64p, C.c_size_t]
+        o.mfmo_f32_chan_push.restype = C.c_size_t
         _lib = o
     return _lib
 
@@ -344,3 +353,38 @@ def unpack_bytes(raw, fmt):
     out = np.zeros(a.size, np.int16)
     lib().mfmo_unpack_bytes(a.ctypes.data, a.size, fmt, p16(out))
     return out
+
+
+class F32Channel:
+    """oracle/f32_oracle.c: the fp64 restatement of the floating-point IQ path, one channel."""
+
+    def __init__(self, offset_hz, sample_rate, decimation, lpf_taps, gain=1.0):
+        t = np.ascontiguousarray(lpf_taps, dtype=np.float64)
+        self.nt, self.decim = t.size, decimation
+        self.h = lib().mfmo_f32_chan_new(int(offset_hz), sample_rate, decimation,
+                                         t.ctypes.data_as(C.POINTER(C.c_double)), t.size, float(gain))
+
+    def taps(self):
+        re, im = np.zeros(self.nt), np.zeros(self.nt)
+        lib().mfmo_f32_chan_taps(self.h, re.ctypes.data_as(C.POINTER(C.c_double)), im.ctypes.data_as(C.POINTER(C.c_double)))
+        return re, im
+
+    def push(self, iq):
+        """iq float32 [n][2] -> (pcm float64 [m], iq float64 [m][2])"""
+        a = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        cap = a.size // 2 // self.decim + 4
+        pcm, out = np.zeros(cap), np.zeros((cap, 2))
+        n = lib().mfmo_f32_chan_push(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size // 2,
+                                     pcm.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)), cap)
+        return pcm[:n].copy(), out[:n].copy()
+
+    def close(self):
+        if self.h:
+            lib().mfmo_f32_chan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

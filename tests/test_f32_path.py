@@ -1,0 +1,144 @@
+"""BASELINE.json configs[4] ("fp32 vs int16 IQ path") / SURVEY.md 8d config 5: the channel path on float32 IQ.
+
+The reference has no floating-point path, so the oracle is oracle/f32_oracle.c - the integer path's algorithm with
+the Q14 quantisation steps removed, in fp64 (parity unpinned: there is nothing in the reference to pin it to).
+Tolerances, from BASELINE.json north_star ("within 1 LSB (int16) / 1e-5 rel for the float FIR/atan2 stage"):
+
+  * derotated filtered IQ: |gpu - oracle| <= 1e-5 * (largest |oracle| over all channels of the run)
+  * float PCM (phi/pi*16384) of channels that carry a signal: circular difference <= 1e-5 * 16384 (0.16 LSB)
+  * float PCM of every channel (noise-only ones included): <= 1 LSB, except where |s| is so small that the angle is
+    ill-conditioned (|o[n]| |o[n-1]| below 1e-4 of the run's largest)
+"""
+import numpy as np
+import pytest
+
+
+def _circ(d):
+    return np.abs((d + 16384.0) % 32768.0 - 16384.0)
+
+
+def test_oracle_f32_taps_and_int16_path_agree(pkg, ora):
+    """The fp64 taps are the integer path's taps before truncation, and on a strong carrier the fp64 PCM and the
+    reference-exact integer PCM differ by quantisation only (a couple of LSB)."""
+    fs, decim = 2400000, 96
+    lpf = pkg.synth.design_lpf(128, 12500.0, fs)
+    off = -431250
+    ch = ora.F32Channel(off, fs, decim, lpf, 1.0)
+    re, im = ch.taps()
+    cre, cim = ora.make_taps(lpf, off, fs, 1.0)
+    assert np.array_equal(np.trunc(re * 16384.0).astype(np.int16), cre)
+    assert np.array_equal(np.trunc(im * 16384.0).astype(np.int16), cim)
+    iq = pkg.synth.synth_iq(1 << 16, fs, [off], seed=3)
+    pcm, _ = ch.push(iq.astype(np.float32))
+    ire, iim = ora.rot_incr(off, fs, decim)
+    pcm_i, _ = ora.run_channels(iq, cre[None, :], cim[None, :], np.array([[ire, iim]], np.int16), decim)
+    n = min(len(pcm), pcm_i.shape[1])
+    assert n == (len(iq) - 128) // decim + 1
+    # the first outputs differ by construction (the recursive Q14 rotator has not decayed yet / history 0)
+    d = _circ(pcm[8:n] - pcm_i[0, 8:n].astype(np.float64))
+    assert np.percentile(d, 99) < 6.0 and d.max() < 40.0
+    # chunking independence of the oracle itself
+    ch2 = ora.F32Channel(off, fs, decim, lpf, 1.0)
+    x = iq.astype(np.float32)
+    parts = [ch2.push(x[i:i + 5003])[0] for i in range(0, len(x), 5003)]
+    assert np.allclose(np.concatenate(parts), pcm, rtol=0, atol=1e-9)
+
+
+def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500.0, scale=1.0):
+    lpf = pkg.synth.design_lpf(ntaps, cutoff, fs)
+    offs = pkg.synth.channel_offsets(nch, fs)
+    rng = np.random.RandomState(seed)
+    gains = 0.5 + rng.rand(nch)
+    active = list(range(0, nch, max(1, nch // 6)))[:6]
+    iq = pkg.synth.synth_iq(nsamp, fs, [offs[a] for a in active], seed=seed).astype(np.float32) * np.float32(scale)
+    eng = pkg.F32Engine(fs, decim, max(chunks), device=0, want_iq=True)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), lpf, float(g))
+    eng.commit()
+    got_f, got_i, got_q = [], [], []
+    pos, k = 0, 0
+    while pos < nsamp:
+        n = min(chunks[k % len(chunks)], nsamp - pos)
+        pf, pi, q = eng.process_host(iq[pos:pos + n])
+        got_f.append(pf)
+        got_i.append(pi)
+        got_q.append(q)
+        pos += n
+        k += 1
+    eng.close()
+    gf, gi, gq = np.concatenate(got_f, 1), np.concatenate(got_i, 1), np.concatenate(got_q, 1)
+    nout = (nsamp - ntaps) // decim + 1 if nsamp >= ntaps else 0
+    assert gf.shape[1] == nout
+    ref_p, ref_q = np.zeros((nch, nout)), np.zeros((nch, nout, 2))
+    for c in range(nch):
+        ch = ora.F32Channel(int(offs[c]), fs, decim, lpf, float(gains[c]))
+        p, q = ch.push(iq)
+        ref_p[c], ref_q[c] = p, q
+        ch.close()
+    full = np.abs(ref_q).max()
+    # FIR + derotation
+    assert np.abs(gq - ref_q).max() <= 1e-5 * full
+    # discriminator
+    d = _circ(gf.astype(np.float64) - ref_p)
+    assert d[active].max() <= 1e-5 * 16384.0
+    mag = np.hypot(ref_q[:, :, 0], ref_q[:, :, 1])
+    cond = mag[:, 1:] * mag[:, :-1] > 1e-4 * full * full
+    assert d[:, 1:][cond].max() <= 1.0
+    # int16 PCM is the float PCM truncated (multifm/fm_demod.c:72)
+    assert np.array_equal(gi, np.trunc(gf).astype(np.int16))
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs,decim,ntaps,nch,chunks", [
+    (2400000, 96, 128, 64, [1 << 18]),                 # configs[1] shape
+    (2400000, 96, 128, 5, [4096, 100, 50000, 37, 1]),  # ragged blocks, blocks shorter than the filter
+    (10000000, 400, 512, 20, [1 << 17]),               # configs[4] shape (tap chunks of 128)
+    (1200000, 25, 127, 3, [30001]),                    # odd decimation, odd filter length
+    (1000000, 40, 40, 70, [65536]),                    # taps == decimation, two channel groups
+])
+def test_gpu_f32_path_matches_fp64_oracle(pkg, ora, fs, decim, ntaps, nch, chunks):
+    _run_case(pkg, ora, fs, decim, ntaps, nch, 300000, chunks, seed=11)
+
+
+@pytest.mark.gpu
+def test_gpu_f32_path_is_scale_invariant_and_restartable(pkg, ora):
+    """atan2 does not care about the input scale: normalised (+-1) float IQ gives the same PCM within tolerance;
+    a second engine restarts the stream from zero history."""
+    d1 = _run_case(pkg, ora, 2400000, 96, 128, 8, 200000, [65536], seed=5, scale=1.0)
+    d2 = _run_case(pkg, ora, 2400000, 96, 128, 8, 200000, [65536], seed=5, scale=1.0 / 32768.0)
+    assert d1.shape == d2.shape
+
+
+@pytest.mark.gpu
+def test_gpu_f32_pcm_feeds_the_integer_stages(pkg, ora):
+    """The int16 PCM of the float path has the integer engine's layout: the resampler takes it in place."""
+    import ctypes as C
+    fs, decim, nch = 1152000, 24, 4
+    lpf = pkg.synth.design_lpf(128, 12500.0, fs)
+    offs = pkg.synth.channel_offsets(nch, fs)
+    iq = pkg.synth.synth_iq(1 << 18, fs, offs[:2], seed=2).astype(np.float32)
+    eng = pkg.F32Engine(fs, decim, 1 << 18, device=0)
+    for o in offs:
+        eng.add_channel(int(o), lpf, 1.0)
+    eng.commit()
+    import torch
+    d_iq = torch.from_numpy(iq.reshape(-1)).cuda()
+    blk = eng.process_device(d_iq.data_ptr(), iq.shape[0])
+    rtaps = ora.quantize_taps(pkg.synth.design_lpf(81, 0.45 / 5, 1.0) * 4)
+    rs = pkg.Resampler(nch, rtaps, 4, 5, eng.max_out(), device=0)
+    yptr, ystride, ny = rs.process_device(blk.d_pcm_i16, blk.stride, blk.nr_out)
+    torch.cuda.synchronize()
+    pcm = np.zeros((nch, blk.stride), np.int16)
+    lib = pkg.load_library()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(pcm.ctypes.data, blk.d_pcm_i16, pcm.nbytes, 2) == 0
+    y = np.zeros((nch, ystride), np.int16)
+    assert hip.hipMemcpy(y.ctypes.data, yptr, y.nbytes, 2) == 0
+    for c in range(nch):
+        o = ora.Resampler(rtaps, 4, 5)
+        assert np.array_equal(o.feed(pcm[c, :blk.nr_out]), y[c, :ny])
+    rs.close()
+    eng.close()
+    del lib

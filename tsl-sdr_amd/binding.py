@@ -30,6 +30,8 @@ ABI_SYMBOLS = [
     "mfm_resampler_process_host", "mfm_resampler_process_host_to_device",
     "mfm_pocsag_create", "mfm_pocsag_destroy", "mfm_pocsag_process_device", "mfm_pocsag_process_host",
     "mfm_pocsag_fetch_events", "mfm_bch3121_decode_device", "mfm_bch3121_decode_host", "mfm_hosttwin_bch3121_decode",
+    "mfm_f32_create", "mfm_f32_add_channel", "mfm_f32_commit", "mfm_f32_destroy", "mfm_f32_max_out",
+    "mfm_f32_process_device", "mfm_f32_process_host",
 ]
 
 MFM_POCSAG_EV_SYNC_FOUND, MFM_POCSAG_EV_BATCH, MFM_POCSAG_EV_SYNC_LOST, MFM_POCSAG_EV_SYNC_KEPT = 1, 2, 3, 4
@@ -81,6 +83,18 @@ class ResamplerConfig(C.Structure):
                 ("interpolate", C.c_uint32), ("decimate", C.c_uint32), ("max_in_samples", C.c_uint32),
                 ("invert", C.c_uint32), ("dc_block", C.c_uint32), ("dc_pole", C.c_double)]
 
+
+class F32Config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("sample_rate_hz", C.c_uint32),
+                ("decimation", C.c_uint32), ("max_block_samples", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class F32Block(C.Structure):
+    _fields_ = [("d_pcm_f32", C.c_void_p), ("d_pcm_i16", C.c_void_p), ("d_iq_f32", C.c_void_p),
+                ("stride", C.c_size_t), ("nr_out", C.c_size_t), ("nr_channels", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+MFM_F32_WANT_IQ = 1
 
 _lib = None
 
@@ -151,6 +165,16 @@ def load_library():
     lib.mfm_resampler_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t, i16p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.mfm_resampler_process_host_to_device.argtypes = [vp, i16p, C.c_size_t, C.c_size_t, vp, C.POINTER(vp),
                                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    f32p = C.POINTER(C.c_float)
+    lib.mfm_f32_create.argtypes = [C.POINTER(vp), C.POINTER(F32Config)]
+    lib.mfm_f32_add_channel.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_size_t, C.c_double]
+    lib.mfm_f32_commit.argtypes = [vp]
+    lib.mfm_f32_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_f32_destroy.restype = None
+    lib.mfm_f32_max_out.argtypes = [vp]
+    lib.mfm_f32_max_out.restype = C.c_size_t
+    lib.mfm_f32_process_device.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(F32Block)]
+    lib.mfm_f32_process_host.argtypes = [vp, f32p, C.c_size_t, f32p, i16p, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = lib
     return lib
 
@@ -365,6 +389,73 @@ class Resampler:
         if rc < 0:
             raise MfmError(rc, "mfm_resampler_process_device", self.lib.mfm_strerror(rc).decode())
         return p.value, st.value, n.value
+
+
+class F32Engine:
+    """mfm_f32_*: the channel path on float32 IQ (FIR, derotation, discriminator in fp32)."""
+
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, want_iq=False):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = F32Config(MFM_ABI_VERSION, device, sample_rate_hz, decimation, max_block_samples,
+                        MFM_F32_WANT_IQ if want_iq else 0)
+        rc = self.lib.mfm_f32_create(C.byref(self.h), C.byref(cfg))
+        if rc < 0:
+            raise MfmError(rc, "mfm_f32_create", self.lib.mfm_strerror(rc).decode())
+        self.want_iq = want_iq
+        self.nr_channels = 0
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise MfmError(rc, what, self.lib.mfm_last_error().decode() or self.lib.mfm_strerror(rc).decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_f32_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_channel(self, offset_hz, lpf_taps, gain=1.0):
+        t = np.ascontiguousarray(lpf_taps, dtype=np.float64)
+        idx = self._chk(self.lib.mfm_f32_add_channel(self.h, int(offset_hz), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     t.size, float(gain)), "mfm_f32_add_channel")
+        self.nr_channels = idx + 1
+        return idx
+
+    def commit(self):
+        self._chk(self.lib.mfm_f32_commit(self.h), "mfm_f32_commit")
+
+    def max_out(self):
+        return self.lib.mfm_f32_max_out(self.h)
+
+    def process_host(self, iq):
+        """iq: float32 [n][2] (or flat interleaved) -> (pcm_f32 [C][m], pcm_i16 [C][m], iq_f32 [C][m][2] or None)"""
+        a = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        n_in = a.size // 2
+        cap = self.max_out()
+        Cn = self.nr_channels
+        pf = np.zeros((Cn, cap), np.float32)
+        pi = np.zeros((Cn, cap), np.int16)
+        qf = np.zeros((Cn, cap, 2), np.float32) if self.want_iq else None
+        n = C.c_size_t()
+        f32p = C.POINTER(C.c_float)
+        self._chk(self.lib.mfm_f32_process_host(self.h, a.ctypes.data_as(f32p), n_in, pf.ctypes.data_as(f32p), _i16p(pi),
+                                                qf.ctypes.data_as(f32p) if qf is not None else None, cap, C.byref(n)),
+                  "mfm_f32_process_host")
+        m = n.value
+        return pf[:, :m].copy(), pi[:, :m].copy(), (qf[:, :m].copy() if qf is not None else None)
+
+    def process_device(self, d_iq, nr_samples, stream=None):
+        b = F32Block()
+        self._chk(self.lib.mfm_f32_process_device(self.h, C.c_void_p(d_iq), nr_samples, C.c_void_p(stream or 0),
+                                                  C.byref(b)), "mfm_f32_process_device")
+        return b
 
 
 class Pocsag:

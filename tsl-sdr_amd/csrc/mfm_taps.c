@@ -25,6 +25,19 @@ void mfm_taps_rotate_q14(const double *lpf_taps, size_t nr_taps, int32_t offset_
     }
 }
 
+void mfm_taps_rotate_f64(const double *lpf_taps, size_t nr_taps, int32_t offset_hz, uint32_t sample_rate, double gain,
+                         double *coeff_re, double *coeff_im)
+{
+    /* the same expression without the int16 casts of multifm/demod.c:242-243: the floating-point path's taps */
+    const double f_offs = -2.0 * M_PI * (double)offset_hz / (double)sample_rate;
+
+    for (size_t i = 0; i < nr_taps; i++) {
+        const double complex tap = gain * cexp(CMPLX(0, f_offs * (double)i)) * lpf_taps[i];
+        coeff_re[i] = creal(tap);
+        coeff_im[i] = cimag(tap);
+    }
+}
+
 void mfm_taps_rot_increment(int32_t offset_hz, uint32_t sample_rate, uint32_t decimation, int16_t *incr_re,
                             int16_t *incr_im)
 {
