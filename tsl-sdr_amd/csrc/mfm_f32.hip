@@ -10,13 +10,13 @@
  *   discrim.  s = o[n]*conj(o[n-1]); phi = fast_atan2f(s)    multifm/fm_demod.c:55-72, fast_atan2f.c:101-174
  *             pcm = phi/pi*16384 (float), and truncated to int16 for the stages behind (resampler, pager)
  *
- * Kernel shape.  A workgroup = 4 waves, one tile = 64 output columns (lane = column; column 0 is the output before
+ * Kernel shape.  A workgroup = 8 waves, one tile = 64 output columns (lane = column; column 0 is the output before
  * the tile's first new one, recomputed, so that the discriminator's history is always the lane to the left) by 64
- * channels (wave w owns channels 16w..16w+15 of the group, one complex accumulator each, in registers).  The
+ * channels (wave w owns channels 8w..8w+7 of the group, one complex accumulator each, in registers).  The
  * input windows of the 64 columns are staged into LDS as 64 rows of KT = 128 taps' worth of samples with an odd
  * row pitch (a lane's ds_read_b64 walks its own row: consecutive lanes hit consecutive banks), tap chunk by tap
- * chunk.  The taps are wave-uniform: they are stored [tap][channel] and read with scalar loads, 16 channels per
- * s_load_dwordx16 pair, and feed v_pk_fma_f32 as SGPR operands - two packed FMAs per complex tap, no other VALU
+ * chunk.  The taps are wave-uniform: they are stored [tap][channel] and read with scalar loads (one
+ * s_load_dwordx16 per tap and wave, requested one pair of taps ahead), and feed v_pk_fma_f32 as SGPR operands - two packed FMAs per complex tap, no other VALU
  * work in the inner loop:
  *
  *     acc(re,im) += (cr, cr) * (xr, xi)            op_sel_hi:[0,1,1]
@@ -41,9 +41,11 @@ extern "C" void mfm_internal_set_error(const char *msg);
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr uint32_t F_NT = 256;  /* threads per workgroup */
-constexpr uint32_t F_CB = 16;   /* channels per wave */
+constexpr uint32_t F_NT = 512;  /* threads per workgroup */
+constexpr uint32_t F_CB = 8;    /* channels per wave */
 constexpr uint32_t F_CG = 64;   /* channels per workgroup */
 constexpr uint32_t F_COLS = 64; /* columns per tile, 63 of them new */
 constexpr uint32_t F_KT = 128;  /* taps per LDS chunk */
@@ -52,7 +54,7 @@ constexpr uint32_t F_PITCH = F_KT + 1; /* row pitch in samples (float2) */
 struct F32Launch {
     const float2 *tail;   /* [tail_len] unconsumed samples of earlier calls */
     const float2 *blk;    /* [nr_in] this call's samples */
-    const float2 *taps_t; /* [T + 1][cpad], the last row zero */
+    const float2 *taps_t; /* [T + 8][cpad], rows >= T zero */
     const float2 *wlane;  /* [cpad][64]: w^lane per channel */
     const float2 *lut;    /* [256] {T[i], T[i+1]-T[i]} */
     const uint32_t *step_mod; /* [cpad] (off*D) mod fs */
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t tile = blockIdx.x;
-    const uint32_t ch0 = (blockIdx.y * 4u + wave) * F_CB; /* < cpad */
+    const uint32_t ch0 = (blockIdx.y * (F_NT / 64u) + wave) * F_CB; /* < cpad */
     /* column 0 of the tile is output rel0 of this call (-1 for the first tile) */
     const int rel0 = (int)(tile * (F_COLS - 1u)) - 1;
 
@@ -122,9 +124,9 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
     for (uint32_t i0 = 0; i0 < L.nt; i0 += F_KT) {
         const uint32_t kt = L.nt - i0 < F_KT ? L.nt - i0 : F_KT;
         __syncthreads(); /* the previous chunk has been consumed */
-        /* taps go two at a time (their scalar loads are issued together, one wait per pair); an odd chunk length is
-         * rounded up - the taps array has a zero row behind the last tap, the extra column holds a real sample */
-        const uint32_t kte = (kt + 1u) & ~1u;
+        /* taps go in trips of eight; a chunk length that is not a multiple of 8 is rounded up - the taps array has
+         * zero rows behind the last tap, the extra columns hold real (finite) samples */
+        const uint32_t kte = (kt + 7u) & ~7u;
         for (uint32_t idx = tid; idx < F_COLS * kte; idx += F_NT) {
             const uint32_t row = kte == F_KT ? idx / F_KT : idx / kte, col = idx - row * kte;
             const int rel = rel0 + (int)row;
@@ -134,24 +136,35 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
         __syncthreads();
         const float2 *xrow = xs + lane * F_PITCH;
         const float2 *tp = L.taps_t + (size_t)i0 * L.cpad + ch0;
-        for (uint32_t i = 0; i < kte; i += 2) {
-            const float2 *t0 = tp + (size_t)i * L.cpad, *t1 = t0 + L.cpad;
-            v2f c[2][F_CB], x[2];
-#pragma unroll
-            for (uint32_t k = 0; k < F_CB; k++) {
-                const float2 a = t0[k], b = t1[k];
-                c[0][k] = v2f{ a.x, a.y };
-                c[1][k] = v2f{ b.x, b.y };
-            }
-            {
-                const float2 a = xrow[i], b = xrow[i + 1];
-                x[0] = v2f{ a.x, a.y };
-                x[1] = v2f{ b.x, b.y };
-            }
+        /* Software pipeline, by hand: the taps of one pair are two s_load_dwordx16 (8 channels x (re, im) per tap),
+         * issued from inline asm one pair ahead of the FMAs that use them, because the compiler would only wait for
+         * them right where they are issued (scalar loads return out of order: its only wait is lgkmcnt(0) at the first
+         * use).  What is in flight is invisible to the compiler, so every stage is settled explicitly: "settle" is an
+         * s_waitcnt lgkmcnt(0) that the stage's registers (taps and the two LDS samples) are threaded through, which
+         * orders it before their uses; the compiler's own LDS waits in between can under-wait (they do not count the
+         * scalar loads) but are always followed by this one.  Four pairs per trip, two register stages; nothing scalar
+         * is carried around the loop. */
+        v16i c[2][2];
+        v2f x[2][2];
+        auto fetch = [&](uint32_t i, int st) {
+            const float2 *t0 = tp + (size_t)i * L.cpad;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0"
+                         : "=&s"(c[st][0]), "=&s"(c[st][1])
+                         : "s"(t0), "s"(t0 + L.cpad));
+            const float2 a = xrow[i], b = xrow[i + 1];
+            x[st][0] = v2f{ a.x, a.y };
+            x[st][1] = v2f{ b.x, b.y };
+        };
+        auto settle = [&](int st) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c[st][0]), "+s"(c[st][1]), "+v"(x[st][0]), "+v"(x[st][1]));
+        };
+        auto mac = [&](int st) {
 #pragma unroll
             for (uint32_t u = 0; u < 2; u++) {
 #pragma unroll
                 for (uint32_t k = 0; k < F_CB; k += 2) {
+                    const v2i ca = { c[st][u][2 * k], c[st][u][2 * k + 1] };
+                    const v2i cb = { c[st][u][2 * k + 2], c[st][u][2 * k + 3] };
                     /* a VOP3P result needs one wait state before it is read again: the two channels of a block are
                      * interleaved, so dependent instructions are never adjacent - also across blocks */
                     asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[0,1,1]\n\t"
@@ -159,8 +172,20 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
                         "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
                         "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
                         : "+v"(acc[k]), "+v"(acc[k + 1])
-                        : "s"(c[u][k]), "s"(c[u][k + 1]), "v"(x[u]));
+                        : "s"(ca), "s"(cb), "v"(x[st][u]));
                 }
+            }
+        };
+        for (uint32_t i = 0; i < kte; i += 8) {
+            fetch(i, 0);
+#pragma unroll
+            for (uint32_t sp = 0; sp < 4; sp++) {
+                const int st = (int)(sp & 1u);
+                settle(st);
+                if (sp < 3) {
+                    fetch(i + 2u * (sp + 1u), st ^ 1);
+                }
+                mac(st);
             }
         }
     }
@@ -326,7 +351,7 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
     if ((uint64_t)e->out_cap * D >= (1ull << 31) || (uint64_t)e->cfg.max_block_samples + e->tail_cap >= (1ull << 31)) {
         return MFM_E_INVAL;
     }
-    std::vector<float2> taps((size_t)(T + 1u) * e->cpad, make_float2(0.0f, 0.0f)); /* + a zero row (odd lengths) */
+    std::vector<float2> taps((size_t)(T + 8u) * e->cpad, make_float2(0.0f, 0.0f)); /* + zero rows: trips of 8 taps */
     std::vector<float2> wlane((size_t)e->cpad * 64, make_float2(1.0f, 0.0f));
     std::vector<uint32_t> step(e->cpad, 0);
     std::vector<double> re(T), im(T);
