@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_DOT2_PEAK = 256 * 4 * 32 * 2.4e9  # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 (v_dot2 measured at half of it)
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8/fp8 MFMA, MI355X_MICROARCH.md (measured 4.1-4.4 POPS)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # packed FP32 on the vector ALUs: 256 CU x 256 flop/clk x 2.4 GHz
 
 
 def parse():
@@ -43,6 +44,7 @@ def parse():
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the float32-IQ comparison line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
@@ -80,6 +82,38 @@ def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
     return {"value": passes * n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
             "sample": f"{passes} passes over {n} IQ samples x {nch} channels, oracle/liboracle.so "
                       f"(-O2 -march=x86-64-v3), {threads} threads thread-per-channel, {dt:.1f} s"}
+
+
+def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=24, iters=30):
+    """Kernel time of the floating-point IQ path (mfm_f32_*) on 2^24-sample blocks resident in HBM, HIP events on
+    the launch stream; the integer kernel's time is scaled to the same block length for the ratio."""
+    blk = 1 << block_log2
+    base = pkg.synth.synth_iq(1 << 20, fs, offs[:: max(1, len(offs) // 8)][:8], seed=7).astype(np.float32)
+    d_f = torch.from_numpy(np.tile(base, (blk // base.shape[0], 1)).reshape(-1)).cuda()
+    eng = pkg.F32Engine(fs, decim, blk, device=torch.cuda.current_device())
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        b = eng.process_device(d_f.data_ptr(), blk, stream=st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b = eng.process_device(d_f.data_ptr(), blk, stream=st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    C, T = len(offs), len(taps)
+    flops = 8.0 * C * T * b.nr_out
+    eng.close()
+    return {"kernel": "mfm_f32_channel_kernel", "block_samples": blk, "ms_per_block": ms,
+            "value": blk * C / ms / 1e3, "unit": "MSamp/s x channels", "dtype": "f32",
+            "achieved_tflops": flops / ms / 1e9, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+            "frac": flops / ms / 1e9 / FP32_VECTOR_PEAK_TFLOPS,
+            "time_vs_int16_path": ms / (int16_kernel_ms * blk / int16_block),
+            "tolerance": "1e-5 rel vs fp64 restatement (tests/test_f32_path.py)"}
 
 
 def main():
@@ -217,6 +251,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pkg, fs, decim, taps, offs, gains, args.cpu_seconds)
 
     eng.close()
+    if rank == 0 and world == 1 and not args.no_fp32:
+        # BASELINE configs[4] "fp32 vs int16 IQ path": the same channels on float32 IQ, outside the timed region,
+        # reported next to the headline (never part of `value`)
+        line["fp32_iq_path"] = fp32_path(pkg, torch, fs, decim, taps, offs, gains, line["roofline"]["kernel_ms"],
+                                         block)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

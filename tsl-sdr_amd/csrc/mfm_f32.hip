@@ -10,25 +10,24 @@
  *   discrim.  s = o[n]*conj(o[n-1]); phi = fast_atan2f(s)    multifm/fm_demod.c:55-72, fast_atan2f.c:101-174
  *             pcm = phi/pi*16384 (float), and truncated to int16 for the stages behind (resampler, pager)
  *
- * Kernel shape.  A workgroup = 8 waves, one tile = 64 output columns (lane = column; column 0 is the output before
- * the tile's first new one, recomputed, so that the discriminator's history is always the lane to the left) by 64
- * channels (wave w owns channels 8w..8w+7 of the group, one complex accumulator each, in registers).  The
- * input windows of the 64 columns are staged into LDS as 64 rows of KT = 128 taps' worth of samples with an odd
- * row pitch (a lane's ds_read_b64 walks its own row: consecutive lanes hit consecutive banks), tap chunk by tap
- * chunk.  The taps are wave-uniform: they are stored [tap][channel] and read with scalar loads (one
- * s_load_dwordx16 per tap and wave, requested one pair of taps ahead), and feed v_pk_fma_f32 as SGPR operands - two packed FMAs per complex tap, no other VALU
- * work in the inner loop:
- *
- *     acc(re,im) += (cr, cr) * (xr, xi)            op_sel_hi:[0,1,1]
- *     acc(re,im) += (-ci, ci) * (xi, xr)           op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]
- *
- * Bound: packed FP32 issue (2*T v_pk_fma_f32 per channel and output, 4 clk each): 64 channels, 128 taps, D = 96,
- * 2^26-sample block = 11.5 G lane-ops -> 0.34 ms at 2.05 GHz; HBM moves 8 B per input sample + 6*C/D per sample out.
+ * Kernel shape.  A workgroup = 8 waves, one tile = 64 output columns (column 0 is the output before the tile's first
+ * new one, recomputed, so that the discriminator's history is always the column to the left) by 64 channels (wave w
+ * owns channels 8w..8w+7 of the group).  The input windows of the 64 columns are staged into LDS as 64 rows of
+ * KT = 128 taps' worth of samples, tap chunk by tap chunk.  Two multiply variants (template parameter):
+ *   MFMA  - v_mfma_f32_16x16x4_f32 on the wave's 16 rows (re, im of 8 channels) x 16 columns, exact fp32; a lane's
+ *           four B values of four consecutive MFMAs are one ds_read_b128 of its column's row, the A fragments are
+ *           laid out on the host to match and live in registers for a chunk.  Default.
+ *   VALU  - lane = column, taps [tap][channel] read with scalar loads and fed to v_pk_fma_f32 as SGPR operands, two
+ *           packed FMAs per complex tap (MFM_F32_VALU=1; kept for A/B):
+ *               acc(re,im) += (cr, cr) * (xr, xi)            op_sel_hi:[0,1,1]
+ *               acc(re,im) += (-ci, ci) * (xi, xr)           op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]
+ * Measured: DESIGN.md 3.5 (71-90 TFLOP/s of the 157 TFLOP/s fp32 peak).
  */
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -41,6 +40,7 @@ extern "C" void mfm_internal_set_error(const char *msg);
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -49,12 +49,13 @@ constexpr uint32_t F_CB = 8;    /* channels per wave */
 constexpr uint32_t F_CG = 64;   /* channels per workgroup */
 constexpr uint32_t F_COLS = 64; /* columns per tile, 63 of them new */
 constexpr uint32_t F_KT = 128;  /* taps per LDS chunk */
-constexpr uint32_t F_PITCH = F_KT + 1; /* row pitch in samples (float2) */
+constexpr uint32_t F_PITCH = F_KT + 2; /* row pitch in samples (float2): 1040 B, an odd multiple of 16 B */
 
 struct F32Launch {
     const float2 *tail;   /* [tail_len] unconsumed samples of earlier calls */
     const float2 *blk;    /* [nr_in] this call's samples */
     const float2 *taps_t; /* [T + 8][cpad], rows >= T zero */
+    const float4 *afrag;  /* matrix-core variant: [cpad / 8][chunks][16 quads][64 lanes] A fragments */
     const float2 *wlane;  /* [cpad][64]: w^lane per channel */
     const float2 *lut;    /* [256] {T[i], T[i+1]-T[i]} */
     const uint32_t *step_mod; /* [cpad] (off*D) mod fs */
@@ -75,7 +76,9 @@ static __device__ __forceinline__ float2 f_sample(const F32Launch &L, uint32_t v
 {
     /* clamped: samples past the end feed only columns that are not stored */
     v = v < L.total ? v : L.total - 1u;
-    return v < L.tail_len ? L.tail[v] : L.blk[v - L.tail_len];
+    /* one load through a selected pointer (no branch: the loads of a staging pass can be issued back to back) */
+    const float2 *p = v < L.tail_len ? L.tail + v : L.blk + (v - L.tail_len);
+    return *p;
 }
 
 /* multifm/fast_atan2f.c:101-174 on floats; lut[i] = {T[i], T[i+1]-T[i]} */
@@ -104,7 +107,8 @@ static __device__ __forceinline__ float f_fast_atan2f(float y, float x, const fl
     return (y < 0.0f) ? -ang : ang;
 }
 
-__global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launch L)
+template <bool MFMA>
+__global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel(const F32Launch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t f_smem[];
     float2 *xs = reinterpret_cast<float2 *>(f_smem); /* [64][F_PITCH] */
@@ -120,6 +124,11 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
     for (uint32_t k = 0; k < F_CB; k++) {
         acc[k] = v2f{ 0.0f, 0.0f };
     }
+    v4f macc[4]; /* matrix-core variant: four 16-column groups of the wave's 16 rows */
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+        macc[g] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+    }
 
     for (uint32_t i0 = 0; i0 < L.nt; i0 += F_KT) {
         const uint32_t kt = L.nt - i0 < F_KT ? L.nt - i0 : F_KT;
@@ -127,13 +136,60 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
         /* taps go in trips of eight; a chunk length that is not a multiple of 8 is rounded up - the taps array has
          * zero rows behind the last tap, the extra columns hold real (finite) samples */
         const uint32_t kte = (kt + 7u) & ~7u;
-        for (uint32_t idx = tid; idx < F_COLS * kte; idx += F_NT) {
-            const uint32_t row = kte == F_KT ? idx / F_KT : idx / kte, col = idx - row * kte;
-            const int rel = rel0 + (int)row;
-            const uint32_t v = rel < 0 ? 0u : (uint32_t)rel * L.decim + i0 + col;
-            xs[row * F_PITCH + col] = f_sample(L, v);
+        if (kte == F_KT) {
+            /* full chunk: all 16 loads of a thread are in flight together (as a plain loop every iteration waited
+             * for its own round trip: 16 of them per tile) */
+            float2 r[F_COLS * F_KT / F_NT];
+#pragma unroll
+            for (uint32_t j = 0; j < F_COLS * F_KT / F_NT; j++) {
+                const uint32_t idx = tid + j * F_NT, row = idx / F_KT, col = idx % F_KT;
+                const int rel = rel0 + (int)row;
+                r[j] = f_sample(L, rel < 0 ? 0u : (uint32_t)rel * L.decim + i0 + col);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < F_COLS * F_KT / F_NT; j++) {
+                const uint32_t idx = tid + j * F_NT, row = idx / F_KT, col = idx % F_KT;
+                xs[row * F_PITCH + col] = r[j];
+            }
+        } else {
+            for (uint32_t idx = tid; idx < F_COLS * kte; idx += F_NT) {
+                const uint32_t row = idx / kte, col = idx - row * kte;
+                const int rel = rel0 + (int)row;
+                const uint32_t v = rel < 0 ? 0u : (uint32_t)rel * L.decim + i0 + col;
+                xs[row * F_PITCH + col] = f_sample(L, v);
+            }
         }
         __syncthreads();
+        if (MFMA) {
+            /* ---- matrix cores: acc[row][col] += sum_k W[row][k] * e[col][k], rows = (re, im) of the wave's 8 channels,
+             * k = the 2 * kte floats of a column's window chunk.  v_mfma_f32_16x16x4_f32 takes one float of A and one
+             * of B per lane (k = lane / 16); the k order inside a group of 16 is permuted so that a lane's four B
+             * values of four consecutive MFMAs are one ds_read_b128 of its column's row (the A fragments are laid
+             * out to match on the host).  Exact fp32 (an FMA chain per output). */
+            const uint32_t nq = kte / 8u; /* quads of 16 floats */
+            const uint32_t kg = lane >> 4, n = lane & 15u;
+            const float4 *ap = L.afrag + ((size_t)(ch0 / 8u) * ((L.nt + F_KT - 1u) / F_KT) + i0 / F_KT) * 16u * 64u + lane;
+            float4 a[16];
+#pragma unroll
+            for (uint32_t q = 0; q < 16; q++) {
+                a[q] = ap[q * 64u]; /* quads past nq hold zeros and are not used */
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                const float4 *brow = reinterpret_cast<const float4 *>(xs + (16u * g + n) * F_PITCH) + kg;
+#pragma unroll
+                for (uint32_t q = 0; q < 16; q++) {
+                    if (q < nq) {
+                        const float4 b = brow[q * 4u];
+                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b.x, macc[g], 0, 0, 0);
+                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b.y, macc[g], 0, 0, 0);
+                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b.z, macc[g], 0, 0, 0);
+                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b.w, macc[g], 0, 0, 0);
+                    }
+                }
+            }
+            continue;
+        }
         const float2 *xrow = xs + lane * F_PITCH;
         const float2 *tp = L.taps_t + (size_t)i0 * L.cpad + ch0;
         /* Software pipeline, by hand: the taps of one pair are two s_load_dwordx16 (8 channels x (re, im) per tap),
@@ -192,6 +248,24 @@ __global__ __launch_bounds__(F_NT, 2) void mfm_f32_channel_kernel(const F32Launc
 #pragma unroll
     for (uint32_t k = 0; k < F_CB; k++) {
         asm volatile("s_nop 0" : "+v"(acc[k])); /* the wait state for whoever reads the accumulators next */
+    }
+    if (MFMA) {
+        /* C/D layout (lane (kg, n): rows 4kg..4kg+3 of column n) -> the epilogue's (lane = column, 8 channels in
+         * registers), through the LDS tile, which nobody reads any more after the barrier */
+        __syncthreads();
+        float2 *os = xs + (size_t)wave * F_CB * 64u; /* [8 channels][64 columns] of this wave */
+        const uint32_t kg = lane >> 4, n = lane & 15u;
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            os[(2u * kg) * 64u + 16u * g + n] = make_float2(macc[g][0], macc[g][1]);
+            os[(2u * kg + 1u) * 64u + 16u * g + n] = make_float2(macc[g][2], macc[g][3]);
+        }
+        /* written and read by the same wave: LDS operations of a wave complete in order */
+#pragma unroll
+        for (uint32_t k = 0; k < F_CB; k++) {
+            const float2 v = os[k * 64u + lane];
+            acc[k] = v2f{ v.x, v.y };
+        }
     }
 
     /* ---- epilogue: derotation, discriminator, stores ---- */
@@ -267,6 +341,8 @@ struct mfm_f32_engine {
     bool committed = false;
     uint32_t nt = 0, cpad = 0, out_cap = 0, tail_cap = 0;
     float2 *d_taps = nullptr, *d_wlane = nullptr, *d_lut = nullptr;
+    float4 *d_afrag = nullptr;
+    bool use_mfma = true;
     float2 *d_prev[2] = { nullptr, nullptr };
     int prev_cur = 0;
     uint32_t *d_step = nullptr;
@@ -372,6 +448,35 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
             wlane[(size_t)c * 64 + l] = make_float2((float)cos(ang), (float)sin(ang));
         }
     }
+    /* A fragments of the matrix-core variant.  Rows of a wave: 2c = real part, 2c + 1 = imaginary part of its channel
+     * c; k = 2 * tap + part of the sample: W[2c] = (cr, -ci, ...), W[2c+1] = (ci, cr, ...) (filter/complex.h:40-46).
+     * Lane (kg, r) of quad q, MFMA m holds W[r][16 q + 4 kg + m] of the chunk. */
+    const uint32_t nchunks = (T + F_KT - 1) / F_KT;
+    std::vector<float4> afrag((size_t)(e->cpad / 8) * nchunks * 16 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t grp = 0; grp < e->cpad / 8; grp++) {
+        for (uint32_t ck = 0; ck < nchunks; ck++) {
+            for (uint32_t q = 0; q < 16; q++) {
+                for (uint32_t ln = 0; ln < 64; ln++) {
+                    const uint32_t r = ln & 15u, kg = ln >> 4, c = grp * 8 + r / 2, part = r & 1u;
+                    float v[4];
+                    for (uint32_t m = 0; m < 4; m++) {
+                        const uint32_t kk = 16 * q + 4 * kg + m, tap = ck * F_KT + kk / 2, comp = kk & 1u;
+                        float val = 0.0f;
+                        if (tap < T && c < C) {
+                            const float2 t = taps[(size_t)tap * e->cpad + c];
+                            val = part == 0 ? (comp == 0 ? t.x : -t.y) : (comp == 0 ? t.y : t.x);
+                        }
+                        v[m] = val;
+                    }
+                    afrag[(((size_t)grp * nchunks + ck) * 16 + q) * 64 + ln] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    {
+        const char *env = getenv("MFM_F32_VALU"); /* A/B: the packed-FMA variant */
+        e->use_mfma = !(env && env[0] == '1');
+    }
     float tbl[257];
     mfm_hosttwin_atan_table(tbl);
     if (!mfm_hosttwin_atan_table_ok()) {
@@ -385,6 +490,8 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
     F_TRY(hipSetDevice(e->cfg.device));
     F_TRY(hipMalloc(&e->d_taps, taps.size() * sizeof(float2)));
     F_TRY(hipMemcpy(e->d_taps, taps.data(), taps.size() * sizeof(float2), hipMemcpyHostToDevice));
+    F_TRY(hipMalloc(&e->d_afrag, afrag.size() * sizeof(float4)));
+    F_TRY(hipMemcpy(e->d_afrag, afrag.data(), afrag.size() * sizeof(float4), hipMemcpyHostToDevice));
     F_TRY(hipMalloc(&e->d_wlane, wlane.size() * sizeof(float2)));
     F_TRY(hipMemcpy(e->d_wlane, wlane.data(), wlane.size() * sizeof(float2), hipMemcpyHostToDevice));
     F_TRY(hipMalloc(&e->d_lut, lut.size() * sizeof(float2)));
@@ -402,7 +509,9 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
     if (e->cfg.flags & MFM_F32_WANT_IQ) {
         F_TRY(hipMalloc(&e->d_iq, (size_t)C * e->out_cap * sizeof(float2)));
     }
-    F_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_f32_channel_kernel),
+    F_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_f32_channel_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F_COLS * F_PITCH * sizeof(float2))));
+    F_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_f32_channel_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F_COLS * F_PITCH * sizeof(float2))));
     F_TRY(hipDeviceSynchronize());
     e->committed = true;
@@ -419,6 +528,7 @@ void mfm_f32_destroy(struct mfm_f32_engine **pe)
     (void)hipDeviceSynchronize();
     (void)hipFree(e->d_taps);
     (void)hipFree(e->d_wlane);
+    (void)hipFree(e->d_afrag);
     (void)hipFree(e->d_lut);
     (void)hipFree(e->d_step);
     (void)hipFree(e->d_prev[0]);
@@ -462,6 +572,7 @@ int mfm_f32_process_device(struct mfm_f32_engine *e, const float *d_iq, size_t n
     L.tail = e->d_tail[e->cur];
     L.blk = reinterpret_cast<const float2 *>(d_iq);
     L.taps_t = e->d_taps;
+    L.afrag = e->d_afrag;
     L.wlane = e->d_wlane;
     L.lut = e->d_lut;
     L.step_mod = e->d_step;
@@ -486,7 +597,11 @@ int mfm_f32_process_device(struct mfm_f32_engine *e, const float *d_iq, size_t n
     L.new_tail = new_tail;
     if (n_new) {
         const dim3 grid((n_new + F_COLS - 2u) / (F_COLS - 1u), e->cpad / F_CG);
-        hipLaunchKernelGGL(mfm_f32_channel_kernel, grid, dim3(F_NT), F_COLS * F_PITCH * sizeof(float2), s, L);
+        if (e->use_mfma) {
+            hipLaunchKernelGGL(mfm_f32_channel_kernel<true>, grid, dim3(F_NT), F_COLS * F_PITCH * sizeof(float2), s, L);
+        } else {
+            hipLaunchKernelGGL(mfm_f32_channel_kernel<false>, grid, dim3(F_NT), F_COLS * F_PITCH * sizeof(float2), s, L);
+        }
         F_TRY(hipGetLastError());
         e->prev_cur ^= 1;
     }
