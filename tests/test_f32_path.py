@@ -102,6 +102,14 @@ def test_gpu_f32_path_matches_fp64_oracle(pkg, ora, fs, decim, ntaps, nch, chunk
 
 
 @pytest.mark.gpu
+def test_gpu_f32_packed_fma_variant_matches_too(pkg, ora, monkeypatch):
+    """MFM_F32_VALU=1 selects the v_pk_fma_f32 form of the multiply (kept for A/B runs): same tolerances."""
+    monkeypatch.setenv("MFM_F32_VALU", "1")
+    _run_case(pkg, ora, 2400000, 96, 128, 20, 300000, [70000, 4099], seed=4)
+    _run_case(pkg, ora, 10000000, 400, 512, 9, 300000, [1 << 17], seed=6)
+
+
+@pytest.mark.gpu
 def test_gpu_f32_path_is_scale_invariant_and_restartable(pkg, ora):
     """atan2 does not care about the input scale: normalised (+-1) float IQ gives the same PCM within tolerance;
     a second engine restarts the stream from zero history."""
