@@ -292,6 +292,39 @@ int mfm_pocsag_process_host(struct mfm_pocsag *p, const int16_t *pcm, size_t in_
 int mfm_pocsag_fetch_events(struct mfm_pocsag *p, struct mfm_pocsag_event *out, size_t max_events,
                             size_t *nr_events);
 
+/*
+ * ---- Mueller-Muller clock recovery (BASELINE.json configs[3]: "mueller_muller slicer") -------------------------
+ *   mm_init      pager/mueller_muller.c:10-33
+ *   mm_process   pager/mueller_muller.c:41-115
+ * for all channels of a PCM block at once, one loop state per channel, same float operations in the same order
+ * (decisions are bit-identical to a build of the reference without FP contraction).  The reference's live decoder
+ * does not call it (pager_pocsag.c has its own eye detectors); its consumer is pager/test/test_mueller_muller.c:
+ * decisions[i] > 0 ? 0 : 1 shifted into a 32-bit register and compared with the POCSAG sync word.
+ * As in the reference (:66-67) the index of a decision can reach nr_in: when in_stride > nr_in that sample is read
+ * (the next block's first one, if the caller slices a longer buffer as the reference's test does), otherwise the
+ * last sample stands in for it.
+ */
+struct mfm_mm; /* opaque */
+
+struct mfm_mm_config {
+    uint32_t abi_version; /* MFM_ABI_VERSION */
+    int32_t device;
+    uint32_t nr_channels;
+    uint32_t max_in_samples;
+    float kw, km, samples_per_bit, error_min, error_max; /* mm_init's arguments */
+};
+
+int mfm_mm_create(struct mfm_mm **pm, const struct mfm_mm_config *cfg);
+void mfm_mm_destroy(struct mfm_mm **pm);
+size_t mfm_mm_max_decisions(const struct mfm_mm *m);
+/* decisions: [channel][*dec_stride] int16 (the samples picked, :71), counts: [channel] decisions of this call;
+ * both in device memory, valid until the next call; queued on `stream`. */
+int mfm_mm_process_device(struct mfm_mm *m, const int16_t *d_pcm, size_t in_stride, size_t nr_in, void *stream,
+                          int16_t **d_decisions, size_t *dec_stride, uint32_t **d_counts);
+/* Host convenience: synchronous; MFM_E_NOMEM if a channel produced more than dec_stride decisions. */
+int mfm_mm_process_host(struct mfm_mm *m, const int16_t *pcm, size_t in_stride, size_t nr_in, int16_t *decisions,
+                        size_t dec_stride, uint32_t *counts);
+
 /* bch_code_decode (pager/bch_code.c:307-398) on n words in place; rc[i] = its return value (0 or 1). */
 int mfm_bch3121_decode_device(uint32_t *d_words, uint8_t *d_rc, size_t n, int device, void *stream);
 int mfm_bch3121_decode_host(uint32_t *words, uint8_t *rc, size_t n, int device);

@@ -7,6 +7,7 @@
 #include "pocsag_oracle.h"
 
 #include <ctype.h>
+#include <math.h>
 #include <pthread.h>
 #include <stdbool.h>
 #include <stdlib.h>
@@ -566,4 +567,51 @@ int mfmo_pocsag_on_pcm(struct mfmo_pocsag *p, const int16_t *pcm, size_t nr_samp
         }
     }
     return 0;
+}
+
+/* ---- Mueller-Muller clock recovery: pager/mueller_muller.c ---- */
+
+void mfmo_mm_init(struct mfmo_mm *mm, float kw, float km, float samples_per_bit, float error_min, float error_max)
+{
+    /* mueller_muller.c:17-26 */
+    memset(mm, 0, sizeof(*mm));
+    mm->next_offset = 0.0f;
+    mm->m = mm->w = mm->ideal_step_size = samples_per_bit;
+    mm->kw = kw;
+    mm->km = km;
+    mm->error_min = error_min;
+    mm->error_max = error_max;
+    mm->samples_per_bit = samples_per_bit;
+}
+
+static float mm_sign(float v)
+{
+    return (float)(v > 0) - (float)(v < 0); /* :36-39 */
+}
+
+size_t mfmo_mm_process(struct mfmo_mm *mm, const int16_t *samples, size_t nr_samples, int16_t *decisions,
+                       size_t max_decisions)
+{
+    float cur_sample = mm->next_offset, nr_samples_f = (float)nr_samples, w = mm->w, m = mm->m; /* :57-60 */
+    size_t cur = 0;
+    while (cur_sample < nr_samples_f && cur < max_decisions) { /* :66 */
+        const float sample = samples[(size_t)(cur_sample + 0.5f)]; /* :67 */
+        decisions[cur++] = (int16_t)sample;                         /* :71 */
+        /* :77 */
+        const float w_error = mm_sign(mm->last_sample) * sample - mm_sign(sample) * mm->last_sample;
+        w += w_error * mm->kw; /* :80 */
+        if (mm->error_min > w) { /* :87-91 */
+            w = mm->error_min;
+        } else if (mm->error_max < w) {
+            w = mm->error_max;
+        }
+        m += w + mm->km * sample;   /* :93 */
+        cur_sample += floorf(m);     /* :96 */
+        m -= floorf(m);              /* :98 */
+        mm->last_sample = sample;    /* :101 */
+    }
+    mm->next_offset = cur_sample - nr_samples_f; /* :109-111 */
+    mm->w = w;
+    mm->m = m;
+    return cur;
 }

@@ -87,6 +87,24 @@ void mfmo_pocsag_msgdec_free(struct mfmo_pocsag_msgdec *d);
 int mfmo_pocsag_msgdec_batch(struct mfmo_pocsag_msgdec *d, const uint32_t *words, int flush, uint32_t baud,
                              uint64_t sample, struct mfmo_pocsag_msg *msgs, size_t max_msgs, size_t *nr_msgs);
 
+/*
+ * ---- Mueller-Muller clock recovery (pager/mueller_muller.c:10-115), BASELINE configs[3]'s "mueller_muller slicer" ----
+ * The live decoder path does not use it (pager_pocsag.c has its own eye detectors); the
+ * reference exercises it only from pager/test/test_mueller_muller.c on a capture file that is not in the tree.
+ * PARITY UNPINNED (mueller_muller.c includes <tsl/...> headers the image lacks; its test holds no vectors).
+ * Restated without floating-point contraction (the reference's default build has no -O flag).  As in the
+ * reference (:66) the sample index can reach nr_samples: the caller provides one more readable sample (the
+ * reference's test slices one long buffer, so that sample is the next slice's first).
+ */
+struct mfmo_mm {
+    float samples_per_bit, kw, km, error_min, error_max;
+    float w, m, next_offset, last_sample, ideal_step_size;
+};
+void mfmo_mm_init(struct mfmo_mm *mm, float kw, float km, float samples_per_bit, float error_min, float error_max);
+/* returns the number of decisions written (never more than max_decisions; the reference aborts instead) */
+size_t mfmo_mm_process(struct mfmo_mm *mm, const int16_t *samples, size_t nr_samples, int16_t *decisions,
+                       size_t max_decisions);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,10 @@ def lib():
         o.mfmo_pocsag_msgdec_free.restype = None
         o.mfmo_pocsag_msgdec_batch.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
                                                C.POINTER(C.c_size_t)]
+        o.mfmo_mm_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+        o.mfmo_mm_init.restype = None
+        o.mfmo_mm_process.argtypes = [C.c_void_p, _i16p, C.c_size_t, _i16p, C.c_size_t]
+        o.mfmo_mm_process.restype = C.c_size_t
         f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
         o.mfmo_f32_chan_new.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, f64p, C.c_size_t, C.c_double]
         o.mfmo_f32_chan_new.restype = C.c_void_p
@@ -388,3 +392,21 @@ class F32Channel:
             self.close()
         except Exception:
             pass
+
+
+class MuellerMuller:
+    """oracle/pocsag_oracle.c: mm_init / mm_process (pager/mueller_muller.c), one channel."""
+
+    def __init__(self, kw, km, samples_per_bit, error_min, error_max):
+        self.st = (C.c_float * 10)()
+        lib().mfmo_mm_init(self.st, kw, km, samples_per_bit, error_min, error_max)
+
+    def process(self, buf, offset, nr_samples):
+        """decisions of samples[offset : offset + nr_samples] of `buf` (the sample behind the slice is read when the
+        loop asks for it, as in the reference's test)"""
+        a = np.ascontiguousarray(buf, dtype=np.int16)
+        cap = nr_samples + 16
+        dec = np.zeros(cap, np.int16)
+        ptr = C.cast(a.ctypes.data + 2 * offset, C.POINTER(C.c_int16))
+        n = lib().mfmo_mm_process(self.st, ptr, nr_samples, p16(dec), cap)
+        return dec[:n].copy()

@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "mfm_pocsag_fetch_events", "mfm_bch3121_decode_device", "mfm_bch3121_decode_host", "mfm_hosttwin_bch3121_decode",
     "mfm_f32_create", "mfm_f32_add_channel", "mfm_f32_commit", "mfm_f32_destroy", "mfm_f32_max_out",
     "mfm_f32_process_device", "mfm_f32_process_host",
+    "mfm_mm_create", "mfm_mm_destroy", "mfm_mm_max_decisions", "mfm_mm_process_device", "mfm_mm_process_host",
 ]
 
 MFM_POCSAG_EV_SYNC_FOUND, MFM_POCSAG_EV_BATCH, MFM_POCSAG_EV_SYNC_LOST, MFM_POCSAG_EV_SYNC_KEPT = 1, 2, 3, 4
@@ -95,6 +96,12 @@ class F32Block(C.Structure):
 
 
 MFM_F32_WANT_IQ = 1
+
+
+class MmConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("nr_channels", C.c_uint32),
+                ("max_in_samples", C.c_uint32), ("kw", C.c_float), ("km", C.c_float), ("samples_per_bit", C.c_float),
+                ("error_min", C.c_float), ("error_max", C.c_float)]
 
 _lib = None
 
@@ -175,6 +182,14 @@ def load_library():
     lib.mfm_f32_max_out.restype = C.c_size_t
     lib.mfm_f32_process_device.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(F32Block)]
     lib.mfm_f32_process_host.argtypes = [vp, f32p, C.c_size_t, f32p, i16p, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.mfm_mm_create.argtypes = [C.POINTER(vp), C.POINTER(MmConfig)]
+    lib.mfm_mm_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_mm_destroy.restype = None
+    lib.mfm_mm_max_decisions.argtypes = [vp]
+    lib.mfm_mm_max_decisions.restype = C.c_size_t
+    lib.mfm_mm_process_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                          C.POINTER(vp)]
+    lib.mfm_mm_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t, i16p, C.c_size_t, u32p]
     _lib = lib
     return lib
 
@@ -456,6 +471,44 @@ class F32Engine:
         self._chk(self.lib.mfm_f32_process_device(self.h, C.c_void_p(d_iq), nr_samples, C.c_void_p(stream or 0),
                                                   C.byref(b)), "mfm_f32_process_device")
         return b
+
+
+class MuellerMuller:
+    """mfm_mm_*: Mueller-Muller clock recovery (pager/mueller_muller.c) for all channels of a PCM block."""
+
+    def __init__(self, nr_channels, kw, km, samples_per_bit, error_min, error_max, max_in_samples, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = MmConfig(MFM_ABI_VERSION, device, nr_channels, max_in_samples, kw, km, samples_per_bit, error_min,
+                       error_max)
+        rc = self.lib.mfm_mm_create(C.byref(self.h), C.byref(cfg))
+        if rc < 0:
+            raise MfmError(rc, "mfm_mm_create", self.lib.mfm_strerror(rc).decode())
+        self.nr_channels = nr_channels
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_mm_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_host(self, pcm, nr_in):
+        """pcm: int16 [C][stride] with stride > nr_in when the look-ahead sample is there -> list of per-channel
+        decision arrays"""
+        a = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.nr_channels, -1)
+        cap = self.lib.mfm_mm_max_decisions(self.h)
+        dec = np.zeros((self.nr_channels, cap), np.int16)
+        cnt = np.zeros(self.nr_channels, np.uint32)
+        rc = self.lib.mfm_mm_process_host(self.h, _i16p(a), a.shape[1], nr_in, _i16p(dec), cap,
+                                          cnt.ctypes.data_as(C.POINTER(C.c_uint32)))
+        if rc < 0:
+            raise MfmError(rc, "mfm_mm_process_host", self.lib.mfm_strerror(rc).decode())
+        return [dec[c, :cnt[c]].copy() for c in range(self.nr_channels)]
 
 
 class Pocsag:
