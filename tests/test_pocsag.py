@@ -436,3 +436,68 @@ def test_decoder_amd_json_matches_oracle(tmp_path, ora, pkg, opts):
         _, pages = ora.Pocsag().feed(res.feed(xin))
         assert len(pages) >= 3
         assert (tmp_path / f"pages.json.{c}").read_text() == _json_lines(pages), f"channel {c}"
+
+
+@pytest.mark.gpu
+def test_pocsag_rtlsdr_chain_through_both_binaries(tmp_path, ora, pkg):
+    """BASELINE configs[3] end to end at the reference's process boundary: a cu8 capture (what an RTL-SDR records)
+    -> multifm_amd with etc/pocsag_rtlsdr.json's values (fs 1.2 MS/s, D 25, channels at -320 kHz with dBGain 4.0 and
+    -492 kHz with the file's "dbGain" typo, i.e. gain 1) -> one PCM sink per channel (the FIFOs) -> decoder_amd
+    (4/5 -> 38 400 Hz -> POCSAG) -> JSON lines.  Must equal the oracle chain run on the same bytes: file_if's cu8
+    widening, channel path, resampler, pager, decoder.c's output format."""
+    import json
+    import subprocess
+    sy = pkg.synth
+    fs, decim, taps, offs, gains = sy.plan("pocsag_rtlsdr")
+    center = 929612500 + 320000
+    msgs = _messages(sy)
+    bits = sy.pocsag_bits(sy.pocsag_batches(msgs[:2]))
+    n = 4096 * 700 + 1001  # 2.4 s; a partial, odd-sized last read
+    acc = np.zeros((n, 2), np.float64)
+    for o, baud, seed in zip(offs, (1200, 2400), (1, 2)):
+        burst = sy.pocsag_fm_iq(bits, baud, fs, float(o), lead=50000, trail=0, amplitude=40.0, noise=1.5, seed=seed)
+        m = min(n, burst.shape[0])
+        acc[:m] += burst[:m]
+        if m < n:
+            t = np.arange(m, n)
+            ph = 2 * np.pi * float(o) * t / fs
+            acc[m:, 0] += 40.0 * np.cos(ph)
+            acc[m:, 1] += 40.0 * np.sin(ph)
+    raw = np.clip(np.round(acc + 127.0), 0, 255).astype(np.uint8)  # 8-bit offset binary, as the dongle delivers
+    cap = tmp_path / "capture.cu8"
+    cap.write_bytes(raw.tobytes())
+    taps_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "etc", "lpf_25khz_1200k_128.json")
+    lpf = np.array(json.load(open(taps_file))["lpfTaps"])
+    cfg = {"device": {"type": "file", "filename": str(cap), "fileFormat": "cu8"}, "sampleRateHz": fs,
+           "centerFreqHz": center, "nrSampBufs": 32, "decimationFactor": decim,
+           "channels": [{"outFifo": str(tmp_path / "ch0.pcm"), "chanCenterFreq": int(center + offs[0]), "dBGain": 4.0},
+                        {"outFifo": str(tmp_path / "ch1.pcm"), "chanCenterFreq": int(center + offs[1]), "dbGain": 4.0}]}
+    for c in range(2):
+        (tmp_path / f"ch{c}.pcm").write_bytes(b"")
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    host_dir = os.path.dirname(HOST_SO)
+    r = subprocess.run([os.path.join(host_dir, "multifm_amd"), str(tmp_path / "cfg.json"), taps_file],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rt = sy.design_lpf(81, 0.45 / 5, 1.0) * 4
+    (tmp_path / "filter.json").write_text(json.dumps({"lpfCoeffs": [float(t) for t in rt]}))
+    env = dict(os.environ, MFM_DECODER_FIXED_TIME="1")
+    r = subprocess.run([os.path.join(host_dir, "decoder_amd"), "-I", "4", "-D", "5", "-S", "48000", "-F",
+                        str(tmp_path / "filter.json"), "-f", str(center), "-m", "POCSAG", "-c", "-o",
+                        str(tmp_path / "pages.json"), str(tmp_path / "ch0.pcm"), str(tmp_path / "ch1.pcm")],
+                       capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # the oracle chain on the same bytes
+    iq = np.concatenate([ora.unpack_bytes(raw[i:i + 4096], 2) for i in range(0, n, 4096)]).reshape(-1, 2)
+    g = [10.0 ** (4.0 / 10.0), 1.0]  # multifm/receiver.c:218-220 reads "dBGain" only
+    cre = np.stack([ora.make_taps(lpf, int(o), fs, gg)[0] for o, gg in zip(offs, g)])
+    cim = np.stack([ora.make_taps(lpf, int(o), fs, gg)[1] for o, gg in zip(offs, g)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    pcm, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    rtaps = ora.quantize_taps(rt)
+    for c in range(2):
+        got_pcm = np.frombuffer((tmp_path / f"ch{c}.pcm").read_bytes(), dtype=np.int16)
+        assert np.array_equal(got_pcm, pcm[c]), f"channel {c}: PCM sink differs"
+        _, pages = ora.Pocsag().feed(ora.Resampler(rtaps, 4, 5).feed(pcm[c]))
+        assert len(pages) >= 2, f"channel {c}: the synthetic pages did not decode"
+        assert (tmp_path / f"pages.json.{c}").read_text() == _json_lines(pages), f"channel {c}: JSON lines differ"
