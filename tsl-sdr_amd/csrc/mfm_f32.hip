@@ -13,7 +13,7 @@
  * Kernel shape.  A workgroup = 8 waves, one tile = 64 output columns (column 0 is the output before the tile's first
  * new one, recomputed, so that the discriminator's history is always the column to the left) by 64 channels (wave w
  * owns channels 8w..8w+7 of the group).  The input windows of the 64 columns are staged into LDS as 64 rows of
- * KT = 128 taps' worth of samples, tap chunk by tap chunk.  Two multiply variants (template parameter):
+ * KT = 64 taps' worth of samples, tap chunk by tap chunk.  Two multiply variants (template parameter):
  *   MFMA  - v_mfma_f32_16x16x4_f32 on the wave's 16 rows (re, im of 8 channels) x 16 columns, exact fp32; a lane's
  *           four B values of four consecutive MFMAs are one ds_read_b128 of its column's row, the A fragments are
  *           laid out on the host to match and live in registers for a chunk.  Default.
@@ -48,8 +48,12 @@ constexpr uint32_t F_NT = 512;  /* threads per workgroup */
 constexpr uint32_t F_CB = 8;    /* channels per wave */
 constexpr uint32_t F_CG = 64;   /* channels per workgroup */
 constexpr uint32_t F_COLS = 64; /* columns per tile, 63 of them new */
-constexpr uint32_t F_KT = 128;  /* taps per LDS chunk */
-constexpr uint32_t F_PITCH = F_KT + 2; /* row pitch in samples (float2): 1040 B, an odd multiple of 16 B */
+constexpr uint32_t F_KT = 64;   /* taps per LDS chunk: 33 KB tiles, three workgroups per CU (128: 0.162 ms, 64: 0.153, 32: 0.156) */
+constexpr uint32_t F_NQ = F_KT / 8; /* quads of 16 floats per chunk */
+constexpr uint32_t F_PITCH = F_KT + 2; /* row pitch in samples (float2): an odd multiple of 16 B */
+/* the tile, or the accumulators of 64 channels x 64 columns on their way to the epilogue, whichever is larger */
+constexpr uint32_t F_LDS = F_COLS * F_PITCH * 8u > 64u * 64u * 8u ? F_COLS * F_PITCH * 8u : 64u * 64u * 8u;
+static_assert(true, ""); /* row pitch in samples (float2): 1040 B, an odd multiple of 16 B */
 
 struct F32Launch {
     const float2 *tail;   /* [tail_len] unconsumed samples of earlier calls */
@@ -108,7 +112,7 @@ static __device__ __forceinline__ float f_fast_atan2f(float y, float x, const fl
 }
 
 template <bool MFMA>
-__global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel(const F32Launch L)
+__global__ __launch_bounds__(F_NT, 6) void mfm_f32_channel_kernel(const F32Launch L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t f_smem[];
     float2 *xs = reinterpret_cast<float2 *>(f_smem); /* [64][F_PITCH] */
@@ -168,17 +172,17 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel(const F32Launc
              * out to match on the host).  Exact fp32 (an FMA chain per output). */
             const uint32_t nq = kte / 8u; /* quads of 16 floats */
             const uint32_t kg = lane >> 4, n = lane & 15u;
-            const float4 *ap = L.afrag + ((size_t)(ch0 / 8u) * ((L.nt + F_KT - 1u) / F_KT) + i0 / F_KT) * 16u * 64u + lane;
-            float4 a[16];
+            const float4 *ap = L.afrag + ((size_t)(ch0 / 8u) * ((L.nt + F_KT - 1u) / F_KT) + i0 / F_KT) * F_NQ * 64u + lane;
+            float4 a[F_NQ];
 #pragma unroll
-            for (uint32_t q = 0; q < 16; q++) {
+            for (uint32_t q = 0; q < F_NQ; q++) {
                 a[q] = ap[q * 64u]; /* quads past nq hold zeros and are not used */
             }
 #pragma unroll
             for (uint32_t g = 0; g < 4; g++) {
                 const float4 *brow = reinterpret_cast<const float4 *>(xs + (16u * g + n) * F_PITCH) + kg;
 #pragma unroll
-                for (uint32_t q = 0; q < 16; q++) {
+                for (uint32_t q = 0; q < F_NQ; q++) {
                     if (q < nq) {
                         const float4 b = brow[q * 4u];
                         macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b.x, macc[g], 0, 0, 0);
@@ -452,10 +456,10 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
      * c; k = 2 * tap + part of the sample: W[2c] = (cr, -ci, ...), W[2c+1] = (ci, cr, ...) (filter/complex.h:40-46).
      * Lane (kg, r) of quad q, MFMA m holds W[r][16 q + 4 kg + m] of the chunk. */
     const uint32_t nchunks = (T + F_KT - 1) / F_KT;
-    std::vector<float4> afrag((size_t)(e->cpad / 8) * nchunks * 16 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> afrag((size_t)(e->cpad / 8) * nchunks * F_NQ * 64, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t grp = 0; grp < e->cpad / 8; grp++) {
         for (uint32_t ck = 0; ck < nchunks; ck++) {
-            for (uint32_t q = 0; q < 16; q++) {
+            for (uint32_t q = 0; q < F_NQ; q++) {
                 for (uint32_t ln = 0; ln < 64; ln++) {
                     const uint32_t r = ln & 15u, kg = ln >> 4, c = grp * 8 + r / 2, part = r & 1u;
                     float v[4];
@@ -468,7 +472,7 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
                         }
                         v[m] = val;
                     }
-                    afrag[(((size_t)grp * nchunks + ck) * 16 + q) * 64 + ln] = make_float4(v[0], v[1], v[2], v[3]);
+                    afrag[(((size_t)grp * nchunks + ck) * F_NQ + q) * 64 + ln] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -510,9 +514,9 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
         F_TRY(hipMalloc(&e->d_iq, (size_t)C * e->out_cap * sizeof(float2)));
     }
     F_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_f32_channel_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F_COLS * F_PITCH * sizeof(float2))));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F_LDS)));
     F_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_f32_channel_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F_COLS * F_PITCH * sizeof(float2))));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F_LDS)));
     F_TRY(hipDeviceSynchronize());
     e->committed = true;
     return MFM_OK;
@@ -598,9 +602,9 @@ int mfm_f32_process_device(struct mfm_f32_engine *e, const float *d_iq, size_t n
     if (n_new) {
         const dim3 grid((n_new + F_COLS - 2u) / (F_COLS - 1u), e->cpad / F_CG);
         if (e->use_mfma) {
-            hipLaunchKernelGGL(mfm_f32_channel_kernel<true>, grid, dim3(F_NT), F_COLS * F_PITCH * sizeof(float2), s, L);
+            hipLaunchKernelGGL(mfm_f32_channel_kernel<true>, grid, dim3(F_NT), F_LDS, s, L);
         } else {
-            hipLaunchKernelGGL(mfm_f32_channel_kernel<false>, grid, dim3(F_NT), F_COLS * F_PITCH * sizeof(float2), s, L);
+            hipLaunchKernelGGL(mfm_f32_channel_kernel<false>, grid, dim3(F_NT), F_LDS, s, L);
         }
         F_TRY(hipGetLastError());
         e->prev_cur ^= 1;
