@@ -494,11 +494,28 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     #pragma unroll
                     for (int kq = 0; kq < KQ; kq++) {
                         const int cb = kq & 1, nb = cb ^ 1;
+#if defined(MFM_EXPERIMENT) && MFM_EXPERIMENT == 1
+                        /* sensitivity run (wrong results): every second k-step reuses the previous B fragments */
+                        if (kq + 1 < KQ) {
+                            if ((kq & 1) == 1) {
+                                bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
+                                bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
+                            } else {
+                                bh[nb] = bh[cb];
+                                bl[nb] = bl[cb];
+                            }
+                        }
+#else
                         if (kq + 1 < KQ) {
                             bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
                             bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
                         }
+#endif
+#if defined(MFM_EXPERIMENT) && MFM_EXPERIMENT == 3
+                        if (false) { /* sensitivity run (wrong results): no high-plane products at all */
+#else
                         if ((ah_mask >> kq) & 1u) { /* uniform: skipped where the high-byte tap plane is all zero */
+#endif
                             hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
                             md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
                         }
@@ -549,7 +566,13 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 for (int gq = 0; gq < 2; gq++) {
                     mfm_conj_mul(q[gq][c], pp[gq], &s_re[gq], &s_im[gq]);
                 }
+#if defined(MFM_EXPERIMENT) && MFM_EXPERIMENT == 2
+                /* sensitivity run (wrong results): no discriminator arithmetic */
+                out[0] = s_re[0] ^ s_im[0];
+                out[1] = s_re[1] ^ s_im[1];
+#else
                 mfm_discriminate2(s_re, s_im, lut_t, lut_d, out);
+#endif
                 pcm[0][c] = out[0];
                 pcm[1][c] = out[1];
             }
