@@ -104,3 +104,22 @@ def test_gpu_mueller_muller_long_block_and_missing_lookahead(pkg, ora):
     mm = ora.MuellerMuller(KW, KM, float(SPB), float(SPB - MARGIN), float(SPB + MARGIN))
     assert np.array_equal(mm.process(buf, 0, n), d)
     assert _count_syncs(d) == nb
+
+
+@pytest.mark.gpu
+def test_gpu_mueller_muller_more_channels_than_a_wave(pkg, ora):
+    """70 channels (two workgroups, the second one partly empty), each a shifted copy of three transmissions."""
+    base = [_transmission(pkg, s, lead=2000 + 500 * s, nbatches_msgs=1 + s % 3)[0] for s in range(3)]
+    nch, n = 70, 60000
+    buf = np.zeros((nch, n + 1), np.int16)
+    rng = np.random.RandomState(3)
+    for c in range(nch):
+        p = np.roll(np.resize(base[c % 3], n), 137 * c) + rng.randint(-300, 300, n)
+        buf[c, :n] = np.clip(p, -32768, 32767)
+    buf[:, n] = buf[:, n - 1]
+    gpu = pkg.MuellerMuller(nch, KW, KM, float(SPB), float(SPB - MARGIN), float(SPB + MARGIN), n, device=0)
+    got = gpu.process_host(buf, n)
+    gpu.close()
+    for c in range(nch):
+        mm = ora.MuellerMuller(KW, KM, float(SPB), float(SPB - MARGIN), float(SPB + MARGIN))
+        assert np.array_equal(mm.process(buf[c], 0, n), got[c]), f"channel {c}"
