@@ -170,13 +170,19 @@ def main():
             b.copy_(torch.from_numpy(host))
     torch.cuda.synchronize()
 
+    # the exchange step: RCCL broadcast by default; MFM_EXCHANGE=scatter_allgather | auto selects the large-message
+    # form (tsl-sdr_amd/dist.py) - written for point-to-point xGMI, gloo-tested, not yet run on a multi-GPU node
+    exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "broadcast")) if use_dist else None
+
     def step():
         ptr, cap = eng.acquire_input()
         if use_dist:
             which = 0 if ptr < bufs[0].data_ptr() + in_bytes and ptr >= bufs[0].data_ptr() else 1
             off = (ptr - bufs[which].data_ptr()) // 2
             view = bufs[which][off: off + 2 * block]
-            pkg.dist.broadcast_block(view, src=0)
+            if exchange.algo == "auto":
+                exchange.choose(view, sync=torch.cuda.synchronize)
+            exchange.run(view)
         # the RCCL broadcast runs on torch's stream; without it (N = 1) the block is already in place
         eng.submit(block, producer_stream=torch.cuda.current_stream().cuda_stream, wait_producer=use_dist)
 
@@ -238,7 +244,8 @@ def main():
                                    f"decimation {decim}, fs {fs} Hz-shaped int16 IQ, block 2^{args.block_log2} samples",
                        "channels_per_gpu": cpg, "channels_total": total_ch, "block_samples": block,
                        "input_msamp_per_s": msamp,
-                       "parallelism": "1 GPU" if world == 1 else f"channel shards x{world} + RCCL broadcast of IQ"},
+                       "parallelism": "1 GPU" if world == 1 else
+                                      f"channel shards x{world} + RCCL {exchange.algo} of the IQ block"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "mfm_channel_kernel_mfma" if mfma else "mfm_channel_kernel", "kernel_ms": k_ms,

@@ -61,7 +61,17 @@ def _worker(rank, world, port, out_dir):
                 view.copy_(torch.from_numpy(iq.reshape(-1)))
             else:
                 view.fill_(-1)
-            pkg.dist.broadcast_block(view, src=0)
+            if b == 0:
+                pkg.dist.broadcast_block(view, src=0)
+            elif b == 1:
+                pkg.dist.BlockExchange(src=0, algo="scatter_allgather").run(view)
+            else:
+                ex = pkg.dist.BlockExchange(src=0, algo="auto")
+                assert ex.choose(view, sync=lambda: None, iters=1) in pkg.dist.BlockExchange.ALGOS
+                assert set(ex.timings) == set(pkg.dist.BlockExchange.ALGOS)
+                if rank != 0:
+                    view.fill_(-1)  # choose() already delivered the block: make sure run() does so again
+                ex.run(view)
             got = view.numpy().reshape(-1, 2)
             for k, ch in enumerate(chans):
                 outs[k].append(ch.feed(got)[0])

@@ -25,6 +25,82 @@ def broadcast_block(view, src=0, group=None, async_op=False):
     return dist.broadcast(view.view(torch.uint8), src=src, group=group, async_op=async_op)
 
 
+class BlockExchange:
+    """The exchange step of the channel-sharded engine: the ingest rank's wideband block reaches every rank, in place.
+
+    Two ways to do it, same bytes in the same places afterwards:
+      * "broadcast"          one RCCL broadcast (rings of single xGMI links);
+      * "scatter_allgather"  the ingest rank sends rank r the r-th 1/N of the block (N - 1 different links at once),
+                             then an all-gather fills in the rest (every link of the node busy): the classic
+                             large-message broadcast, worth it where links are point to point.
+    "auto" times both on the real buffer once (choose()) and keeps the faster; the decision is taken on max-reduced
+    times, so every rank takes the same one."""
+
+    ALGOS = ("broadcast", "scatter_allgather")
+
+    def __init__(self, src=0, algo="auto", group=None):
+        import torch.distributed as dist
+        self.src, self.group = src, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.algo = algo if self.world > 1 else "broadcast"
+        self.timings = None
+
+    def _scatter_allgather(self, u8):
+        import torch.distributed as dist
+        n = u8.numel()
+        if n % self.world:
+            return dist.broadcast(u8, src=self.src, group=self.group)
+        chunks = list(u8.chunk(self.world))
+        if self.rank == self.src:
+            ops = [dist.P2POp(dist.isend, chunks[r], r, self.group) for r in range(self.world) if r != self.src]
+        else:
+            ops = [dist.P2POp(dist.irecv, chunks[self.rank], self.src, self.group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if dist.get_backend(self.group) == "gloo":
+            # gloo gathers into a list of tensors; the chunks are views of the block, so this is in place as well
+            got = [c.clone() for c in chunks]
+            dist.all_gather(got, chunks[self.rank].clone(), group=self.group)
+            for c, g in zip(chunks, got):
+                c.copy_(g)
+        else:
+            dist.all_gather_into_tensor(u8, chunks[self.rank], group=self.group)
+        return None
+
+    def run(self, view, algo=None):
+        import torch
+        import torch.distributed as dist
+        u8 = view.view(torch.uint8)  # neither RCCL nor gloo has a 16-bit integer type; the exchange only moves bytes
+        algo = algo or self.algo
+        if algo == "auto":
+            algo = "broadcast"  # until choose() has run
+        if algo == "scatter_allgather":
+            return self._scatter_allgather(u8)
+        return dist.broadcast(u8, src=self.src, group=self.group)
+
+    def choose(self, view, sync, iters=3):
+        """Time both algorithms on `view` (sync() must drain the device) and keep the faster one."""
+        import time
+        import torch.distributed as dist
+        if self.world == 1 or self.algo != "auto":
+            return self.algo
+        dev = view.device
+        res = {}
+        for algo in self.ALGOS:
+            self.run(view, algo)
+            sync()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                self.run(view, algo)
+            sync()
+            res[algo] = max_over_ranks((time.perf_counter() - t0) / iters, device=dev)
+        self.timings = res
+        self.algo = min(res, key=res.get)
+        return self.algo
+
+
 def max_over_ranks(seconds, device="cpu"):
     """Step time of the job = slowest rank."""
     import torch
