@@ -119,6 +119,40 @@ def test_gpu_f32_path_is_scale_invariant_and_restartable(pkg, ora):
 
 
 @pytest.mark.gpu
+def test_gpu_f32_full_size_block_is_chunking_independent(pkg):
+    """2^24 samples x 64 channels (the bench's float block) in one call and in ragged pieces: the stream position,
+    the carried discriminator history and the derotation phase must line up, so the two runs agree to rounding
+    (a tile boundary moves with the chunking, and with it the split of w^n into w^(tile start) * w^lane)."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=64)
+    n = 1 << 24
+    base = pkg.synth.synth_iq(1 << 20, fs, offs[::8][:8], seed=7).astype(np.float32)
+    iq = np.tile(base, (n // base.shape[0], 1))
+    outs = []
+    for chunks in ([n], [5000001, 77, 3000000, n]):
+        eng = pkg.F32Engine(fs, decim, n, device=0, want_iq=True)
+        for o, g in zip(offs, gains):
+            eng.add_channel(int(o), taps, float(g))
+        eng.commit()
+        pf, pq, pos, k = [], [], 0, 0
+        while pos < n:
+            m = min(chunks[k], n - pos)
+            f, _, q = eng.process_host(iq[pos:pos + m])
+            pf.append(f)
+            pq.append(q)
+            pos += m
+            k += 1
+        eng.close()
+        outs.append((np.concatenate(pf, 1), np.concatenate(pq, 1)))
+    (f0, q0), (f1, q1) = outs
+    assert f0.shape == f1.shape == (64, (n - len(taps)) // decim + 1)
+    full = np.abs(q0).max()
+    assert np.abs(q0 - q1).max() <= 2e-6 * full
+    mag = np.hypot(q0[:, :, 0], q0[:, :, 1])
+    ok = mag[:, 1:] * mag[:, :-1] > 1e-4 * full * full
+    assert _circ(f0.astype(np.float64) - f1)[:, 1:][ok].max() <= 0.05
+
+
+@pytest.mark.gpu
 def test_gpu_f32_pcm_feeds_the_integer_stages(pkg, ora):
     """The int16 PCM of the float path has the integer engine's layout: the resampler takes it in place."""
     import ctypes as C
