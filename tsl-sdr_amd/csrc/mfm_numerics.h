@@ -210,12 +210,29 @@ static __device__ __forceinline__ void mfm_discriminate2(const int32_t s_re[2], 
 
     const mfm_v2f alpha = z * 255.0f;
     mfm_v2f frac, t0, dt;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int idx = (int)alpha[i];
-        frac[i] = __builtin_amdgcn_fractf(alpha[i]);
-        t0[i] = t_lut[idx];
-        dt[i] = d_lut[idx];
+    {
+        /* The four look-ups as four ds_read_b32 straight into the halves of the two register pairs.  Left to the
+         * compiler, T[idx] and dT[idx] (256 floats apart) become one ds_read2st64_b32 per pair - which lands (T, dT) of
+         * pair 0 in one register pair and needs three moves to regroup into (T0, T1) and (dT0, dT1).  d_lut must be
+         * t_lut + 256 (1024 bytes); nothing else of this wave is in flight in LDS here, and the block drains itself. */
+        const int i0 = (int)alpha[0], i1 = (int)alpha[1];
+        frac[0] = __builtin_amdgcn_fractf(alpha[0]);
+        frac[1] = __builtin_amdgcn_fractf(alpha[1]);
+        const uint32_t a0 = (uint32_t)(uintptr_t)(t_lut + i0), a1 = (uint32_t)(uintptr_t)(t_lut + i1);
+        float ta, tb, da, db;
+        asm volatile("ds_read_b32 %0, %4\n\t"
+                     "ds_read_b32 %1, %5\n\t"
+                     "ds_read_b32 %2, %4 offset:1024\n\t"
+                     "ds_read_b32 %3, %5 offset:1024\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(ta), "=&v"(tb), "=&v"(da), "=&v"(db)
+                     : "v"(a0), "v"(a1)
+                     : "memory");
+        t0[0] = ta;
+        t0[1] = tb;
+        dt[0] = da;
+        dt[1] = db;
+        (void)d_lut;
     }
     const mfm_v2f prod = dt * frac;
     const mfm_v2f interp = t0 + prod;
