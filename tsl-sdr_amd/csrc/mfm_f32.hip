@@ -53,7 +53,6 @@ constexpr uint32_t F_NQ = F_KT / 8; /* quads of 16 floats per chunk */
 constexpr uint32_t F_PITCH = F_KT + 2; /* row pitch in samples (float2): an odd multiple of 16 B */
 /* the tile, or the accumulators of 64 channels x 64 columns on their way to the epilogue, whichever is larger */
 constexpr uint32_t F_LDS = F_COLS * F_PITCH * 8u > 64u * 64u * 8u ? F_COLS * F_PITCH * 8u : 64u * 64u * 8u;
-static_assert(true, ""); /* row pitch in samples (float2): 1040 B, an odd multiple of 16 B */
 
 struct F32Launch {
     const float2 *tail;   /* [tail_len] unconsumed samples of earlier calls */
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(F_NT, 6) void mfm_f32_channel_kernel(const F32Launc
         __syncthreads(); /* the previous chunk has been consumed */
         /* taps go in trips of eight; a chunk length that is not a multiple of 8 is rounded up - the taps array has
          * zero rows behind the last tap, the extra columns hold real (finite) samples */
-        const uint32_t kte = (kt + 7u) & ~7u;
+        const uint32_t kte = MFMA ? F_KT : (kt + 7u) & ~7u;
         if (kte == F_KT) {
             /* full chunk: all 16 loads of a thread are in flight together (as a plain loop every iteration waited
              * for its own round trip: 16 of them per tile) */
@@ -170,7 +169,6 @@ __global__ __launch_bounds__(F_NT, 6) void mfm_f32_channel_kernel(const F32Launc
              * of B per lane (k = lane / 16); the k order inside a group of 16 is permuted so that a lane's four B
              * values of four consecutive MFMAs are one ds_read_b128 of its column's row (the A fragments are laid
              * out to match on the host).  Exact fp32 (an FMA chain per output). */
-            const uint32_t nq = kte / 8u; /* quads of 16 floats */
             const uint32_t kg = lane >> 4, n = lane & 15u;
             const float4 *ap = L.afrag + ((size_t)(ch0 / 8u) * ((L.nt + F_KT - 1u) / F_KT) + i0 / F_KT) * F_NQ * 64u + lane;
             float4 a[F_NQ];
@@ -178,18 +176,26 @@ __global__ __launch_bounds__(F_NT, 6) void mfm_f32_channel_kernel(const F32Launc
             for (uint32_t q = 0; q < F_NQ; q++) {
                 a[q] = ap[q * 64u]; /* quads past nq hold zeros and are not used */
             }
+            const float4 *bbase = reinterpret_cast<const float4 *>(xs + n * F_PITCH) + kg;
+            /* one straight run over the 4 x F_NQ (group, quad) steps with the next step's B fragment already requested
+             * (as nested loops with a guard per quad, every ds_read_b128 was waited for right where it was issued).
+             * A chunk is always staged whole in this variant: taps past the filter are zero in the A fragments, the
+             * columns they meet hold real samples */
+            {
+                float4 b = bbase[0];
 #pragma unroll
-            for (uint32_t g = 0; g < 4; g++) {
-                const float4 *brow = reinterpret_cast<const float4 *>(xs + (16u * g + n) * F_PITCH) + kg;
-#pragma unroll
-                for (uint32_t q = 0; q < F_NQ; q++) {
-                    if (q < nq) {
-                        const float4 b = brow[q * 4u];
-                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b.x, macc[g], 0, 0, 0);
-                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b.y, macc[g], 0, 0, 0);
-                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b.z, macc[g], 0, 0, 0);
-                        macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b.w, macc[g], 0, 0, 0);
+                for (uint32_t st = 0; st < 4u * F_NQ; st++) {
+                    const uint32_t g = st / F_NQ, q = st % F_NQ;
+                    float4 bn = b;
+                    if (st + 1u < 4u * F_NQ) {
+                        const uint32_t g1 = (st + 1u) / F_NQ, q1 = (st + 1u) % F_NQ;
+                        bn = bbase[g1 * 16u * (F_PITCH / 2u) + q1 * 4u];
                     }
+                    macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b.x, macc[g], 0, 0, 0);
+                    macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b.y, macc[g], 0, 0, 0);
+                    macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b.z, macc[g], 0, 0, 0);
+                    macc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b.w, macc[g], 0, 0, 0);
+                    b = bn;
                 }
             }
             continue;
