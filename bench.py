@@ -40,7 +40,14 @@ def parse():
     # of GPU time.
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=150)
-    ap.add_argument("--channels-per-gpu", type=int, default=64)
+    # The settle phase makes the line independent of --warmup/--steps: back-to-back launches for at least this much
+    # wall time (untimed, before the warm-up), so that a short run (--warmup 5 --steps 20) times the same sustained
+    # state as the defaults.
+    ap.add_argument("--settle-seconds", type=float, default=0.75)
+    ap.add_argument("--channels-per-gpu", type=int, default=None,
+                    help="default 64 at N = 1 (BASELINE configs[1]), 128 at N > 1 (configs[2]: 1024 channels on 8 GPUs)")
+    ap.add_argument("--kernel", choices=["auto", "dot2"], default="auto",
+                    help="dot2 = the v_dot2 kernel through MFM_F_FORCE_DOT2 (A/B timing)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,8 +134,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the multifm engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -142,7 +149,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    cpg = args.channels_per_gpu
+    cpg = args.channels_per_gpu or (64 if world == 1 else 128)
     total_ch = cpg * world
     fs, decim, taps, all_offs, all_gains = pkg.synth.plan(args.config, nr_channels=total_ch)
     lo, hi = pkg.dist.shard_range(total_ch, rank, world)
@@ -155,7 +162,8 @@ def main():
     in_bytes = lib.mfm_engine_input_bytes(block, T)
     bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
     eng = pkg.Engine(fs, decim, block, device=local_rank,
-                     flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING,
+                     flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
+                     (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))
@@ -193,6 +201,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # settle: the board's power management takes ~100 launches to reach the sustained clock (profiles/README.md);
+    # every rank runs the same number of steps (rank 0 decides), so the exchange stays in lock-step
+    settle_steps = 0
+    if args.settle_seconds > 0:
+        fence()
+        t_s = time.perf_counter()
+        for _ in range(8):
+            step()
+        fence()
+        per = max((time.perf_counter() - t_s) / 8, 1e-6)
+        settle_steps = int(min(20000, max(0, args.settle_seconds / per)))
+        if use_dist:
+            t = torch.tensor([settle_steps], device="cuda")
+            dist.broadcast(t, src=0)
+            settle_steps = int(t.item())
+        for _ in range(settle_steps):
+            step()
+        fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -208,6 +234,7 @@ def main():
 
     launches = st1["launches"] - st0["launches"]
     k_ms = (st1["kernel_ms"] - st0["kernel_ms"]) / max(1, launches)
+    per_launch = np.sort(eng.launch_ms(min(int(launches), 4096)).astype(np.float64))
     outs = (st1["outputs"] - st0["outputs"]) / max(1, launches)
     bytes_per_launch = block * 4 + len(offs) * outs * 2        # 4 + 2*C_g/D bytes per input sample
     dot2_per_launch = 2.0 * len(offs) * T * outs               # two v_dot2 lane-ops per complex tap per output
@@ -249,7 +276,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "mfm_channel_kernel_mfma" if mfma else "mfm_channel_kernel", "kernel_ms": k_ms,
-                         "bytes_per_launch": bytes_per_launch},
+                         "kernel_ms_min": float(per_launch[0]) if len(per_launch) else None,
+                         "kernel_ms_median": float(np.median(per_launch)) if len(per_launch) else None,
+                         "kernel_ms_p95": float(np.percentile(per_launch, 95)) if len(per_launch) else None,
+                         "bytes_per_launch": bytes_per_launch,
+                         # what holds the kernel below the HBM roof (SQ counters in profiles/)
+                         "binding": "simd_issue" if mfma else "valu_dot2"},
+            "protocol": {"settle_seconds": args.settle_seconds, "settle_steps": settle_steps + 8,
+                         "warmup_steps": args.warmup, "timed_steps": args.steps},
             "compute_roofline": compute_roof,
             "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],
                          "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"]},

@@ -58,6 +58,8 @@ extern "C" {
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
 #define MFM_F_TIMING 0x2u      /* bracket every kernel launch with HIP events */
+#define MFM_F_FORCE_DOT2 0x4u  /* run the v_dot2 (packed int16 VALU) kernel even where the matrix-core kernel applies:
+                                  both produce the same bits; parity tests and A/B timing select it here */
 
 struct mfm_engine_config {
     uint32_t abi_version;       /* MFM_ABI_VERSION */
@@ -169,6 +171,10 @@ int mfm_engine_sync(struct mfm_engine *e);
 int mfm_engine_reset(struct mfm_engine *e);
 
 int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st);
+
+/* MFM_F_TIMING: durations (ms, HIP events on the compute stream) of the most recent launches, oldest first; at most
+ * `cap` and at most the last 4096.  Returns how many were written. */
+size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap);
 
 /* The engine's compute stream (hipStream_t) for callers that order their own work after it. */
 void *mfm_engine_stream(struct mfm_engine *e);
@@ -346,6 +352,7 @@ int mfm_bch3121_decode_host(uint32_t *words, uint8_t *rc, size_t n, int device);
 struct mfm_f32_engine; /* opaque */
 
 #define MFM_F32_WANT_IQ 1u /* also keep the derotated filtered samples (signalDebugFile analogue) */
+#define MFM_F32_PACKED_FMA 2u /* multiply with v_pk_fma_f32 instead of the fp32 matrix instructions (A/B timing) */
 
 struct mfm_f32_config {
     uint32_t abi_version; /* MFM_ABI_VERSION */

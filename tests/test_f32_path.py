@@ -44,14 +44,14 @@ def test_oracle_f32_taps_and_int16_path_agree(pkg, ora):
     assert np.allclose(np.concatenate(parts), pcm, rtol=0, atol=1e-9)
 
 
-def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500.0, scale=1.0):
+def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500.0, scale=1.0, packed_fma=False):
     lpf = pkg.synth.design_lpf(ntaps, cutoff, fs)
     offs = pkg.synth.channel_offsets(nch, fs)
     rng = np.random.RandomState(seed)
     gains = 0.5 + rng.rand(nch)
     active = list(range(0, nch, max(1, nch // 6)))[:6]
     iq = pkg.synth.synth_iq(nsamp, fs, [offs[a] for a in active], seed=seed).astype(np.float32) * np.float32(scale)
-    eng = pkg.F32Engine(fs, decim, max(chunks), device=0, want_iq=True)
+    eng = pkg.F32Engine(fs, decim, max(chunks), device=0, want_iq=True, packed_fma=packed_fma)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), lpf, float(g))
     eng.commit()
@@ -102,11 +102,10 @@ def test_gpu_f32_path_matches_fp64_oracle(pkg, ora, fs, decim, ntaps, nch, chunk
 
 
 @pytest.mark.gpu
-def test_gpu_f32_packed_fma_variant_matches_too(pkg, ora, monkeypatch):
-    """MFM_F32_VALU=1 selects the v_pk_fma_f32 form of the multiply (kept for A/B runs): same tolerances."""
-    monkeypatch.setenv("MFM_F32_VALU", "1")
-    _run_case(pkg, ora, 2400000, 96, 128, 20, 300000, [70000, 4099], seed=4)
-    _run_case(pkg, ora, 10000000, 400, 512, 9, 300000, [1 << 17], seed=6)
+def test_gpu_f32_packed_fma_variant_matches_too(pkg, ora):
+    """MFM_F32_PACKED_FMA selects the v_pk_fma_f32 form of the multiply (kept for A/B runs): same tolerances."""
+    _run_case(pkg, ora, 2400000, 96, 128, 20, 300000, [70000, 4099], seed=4, packed_fma=True)
+    _run_case(pkg, ora, 10000000, 400, 512, 9, 300000, [1 << 17], seed=6, packed_fma=True)
 
 
 @pytest.mark.gpu

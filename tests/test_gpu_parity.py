@@ -13,16 +13,13 @@ KERNELS = ["auto", "dot2"]  # "auto" = int8-MFMA kernel where it applies, "dot2"
 
 
 def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_iq=False, flags=0, kernel="auto"):
+    if kernel == "dot2":
+        flags |= pkg.binding.MFM_F_FORCE_DOT2
     eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
     gains = gains if gains is not None else [1.0] * len(offs)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
-    if kernel == "dot2":
-        os.environ["MFM_FORCE_DOT2"] = "1"
-    try:
-        eng.commit()
-    finally:
-        os.environ.pop("MFM_FORCE_DOT2", None)
+    eng.commit()
     variant = eng.stats()["kernel_variant"]
     if kernel == "dot2":
         assert variant == 0
@@ -97,6 +94,31 @@ def test_cfg3_shard_of_1024_channels(pkg, ora, kernel):
     shard = offs[3 * 128:4 * 128]
     iq = pkg.synth.synth_iq(1 << 18, fs, shard[::16], seed=23)
     _check(pkg, ora, fs, decim, taps, shard, iq, 1 << 17, want_iq=False, kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("nch", [257, 512, 1024])
+def test_many_channels_on_one_gpu(pkg, ora, nch, kernel):
+    """north_star's target shape: >= 1024 channels on ONE GPU (the reference builds one demod_thread per channels[]
+    entry without limit, multifm/receiver.c:195-244).  More than 256 channels = more than four 64-channel slices per
+    tile and per-channel constants that no longer fit one LDS table; several blocks so that the carried sample and
+    the rotator index of every channel cross a launch boundary; irregular block length."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg3_1024ch", nr_channels=nch)
+    iq = pkg.synth.synth_iq(3 * 50000 + 777, fs, offs[:: max(1, nch // 5)][:5], seed=nch)
+    pcm = _check(pkg, ora, fs, decim, taps, offs, iq, 50000, gains=gains, want_iq=(nch == 257), threads=16,
+                 kernel=kernel)
+    assert pcm.shape[0] == nch
+
+
+def test_2048_channels_at_the_airspy_geometry(pkg, ora):
+    """BASELINE configs[4] whole channel set on one GPU: 2048 channels, fs 10 MS/s, D = 400, 512 taps (streamed taps,
+    single-iteration tiles, 32 slices per tile)."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=2048)
+    iq = pkg.synth.synth_iq(2 * 60000 + 1234, fs, offs[::400][:5], seed=2048)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=60000, want_iq=False)
+    assert eng.stats()["kernel_variant"] == 1
+    eng.close()
+    _check(pkg, ora, fs, decim, taps, offs, iq, 60000, gains=gains, want_iq=False, threads=16)
 
 
 @pytest.mark.parametrize("ntaps,want_iq", [(512, False), (512, True), (256, False), (160, False)])

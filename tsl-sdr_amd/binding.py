@@ -16,6 +16,7 @@ MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_D
 MFM_ABI_VERSION = 1
 MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
+MFM_F_FORCE_DOT2 = 0x4
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
@@ -24,7 +25,7 @@ ABI_SYMBOLS = [
     "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
     "mfm_engine_submit", "mfm_engine_push", "mfm_engine_push_bytes", "mfm_engine_fetch", "mfm_engine_release",
     "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
-    "mfm_engine_stream", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
+    "mfm_engine_stream", "mfm_engine_get_launch_ms", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
     "mfm_resampler_create", "mfm_resampler_destroy", "mfm_resampler_max_out", "mfm_resampler_process_device",
     "mfm_resampler_process_host", "mfm_resampler_process_host_to_device",
@@ -96,6 +97,7 @@ class F32Block(C.Structure):
 
 
 MFM_F32_WANT_IQ = 1
+MFM_F32_PACKED_FMA = 2
 
 
 class MmConfig(C.Structure):
@@ -137,6 +139,8 @@ def load_library():
     lib.mfm_engine_reset.argtypes = [vp]
     lib.mfm_engine_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.mfm_engine_stream.argtypes = [vp]
+    lib.mfm_engine_get_launch_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
+    lib.mfm_engine_get_launch_ms.restype = C.c_size_t
     lib.mfm_engine_stream.restype = vp
     lib.mfm_strerror.argtypes = [C.c_int]
     lib.mfm_strerror.restype = C.c_char_p
@@ -352,6 +356,12 @@ class Engine:
         self._chk(self.lib.mfm_engine_get_stats(self.h, C.byref(st)), "mfm_engine_get_stats")
         return {k: getattr(st, k) for k, _ in Stats._fields_}
 
+    def launch_ms(self, last=4096):
+        """MFM_F_TIMING: durations (ms) of the most recent `last` launches, oldest first."""
+        buf = np.zeros(last, np.float32)
+        n = self.lib.mfm_engine_get_launch_ms(self.h, buf.ctypes.data_as(C.POINTER(C.c_float)), last)
+        return buf[:n].copy()
+
     @property
     def stream(self):
         return self.lib.mfm_engine_stream(self.h)
@@ -409,11 +419,11 @@ class Resampler:
 class F32Engine:
     """mfm_f32_*: the channel path on float32 IQ (FIR, derotation, discriminator in fp32)."""
 
-    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, want_iq=False):
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, want_iq=False, packed_fma=False):
         self.lib = load_library()
         self.h = C.c_void_p()
         cfg = F32Config(MFM_ABI_VERSION, device, sample_rate_hz, decimation, max_block_samples,
-                        MFM_F32_WANT_IQ if want_iq else 0)
+                        (MFM_F32_WANT_IQ if want_iq else 0) | (MFM_F32_PACKED_FMA if packed_fma else 0))
         rc = self.lib.mfm_f32_create(C.byref(self.h), C.byref(cfg))
         if rc < 0:
             raise MfmError(rc, "mfm_f32_create", self.lib.mfm_strerror(rc).decode())

@@ -66,6 +66,7 @@ constexpr uint64_t MFM_ATAN_TABLE_FNV1A = 0x674d1aab1787b44bull;
 
 constexpr int kOutSlots = 4;      /* output ring depth (2 in device-only mode) */
 constexpr int kTimingPairs = 256; /* event pairs kept before the oldest is folded into the total */
+constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine_get_launch_ms() */
 constexpr uint32_t kMaxOutputsPerTile = 128;
 constexpr uint64_t kMaxRotEntries = 1ull << 26; /* per distinct increment: 512 MiB of table */
 
@@ -200,9 +201,12 @@ struct mfm_engine {
     std::mutex mu;
 
     /* timing */
-    hipEvent_t t0[kTimingPairs], t1[kTimingPairs];
+    hipEvent_t t0[kTimingPairs] = {}, t1[kTimingPairs] = {};
+    bool timing_events = false;
     uint64_t t_head = 0, t_tail = 0;
     double kernel_ms = 0.0;
+    std::vector<float> launch_ms; /* ring of the last kLaunchRing launch durations */
+    uint64_t launch_ms_n = 0;     /* durations folded so far */
 };
 
 namespace {
@@ -215,6 +219,11 @@ int fold_timing(mfm_engine *e, bool all)
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e->t0[i], e->t1[i]));
         e->kernel_ms += ms;
+        if (e->launch_ms.size() < kLaunchRing) {
+            e->launch_ms.resize(kLaunchRing);
+        }
+        e->launch_ms[e->launch_ms_n % kLaunchRing] = ms;
+        e->launch_ms_n++;
         e->t_tail++;
     }
     return MFM_OK;
@@ -263,10 +272,14 @@ void free_device(mfm_engine *e)
             (void)hipEventDestroy(s.ready);
         }
     }
-    if (e->cfg.flags & MFM_F_TIMING) {
+    if (e->timing_events) {
         for (int i = 0; i < kTimingPairs; i++) {
-            (void)hipEventDestroy(e->t0[i]);
-            (void)hipEventDestroy(e->t1[i]);
+            if (e->t0[i]) {
+                (void)hipEventDestroy(e->t0[i]);
+            }
+            if (e->t1[i]) {
+                (void)hipEventDestroy(e->t1[i]);
+            }
         }
     }
     if (e->in_ready) {
@@ -284,6 +297,24 @@ void free_device(mfm_engine *e)
     if (e->s_out) {
         (void)hipStreamDestroy(e->s_out);
     }
+    e->d_coef = e->d_tapoff = e->d_afrag = nullptr;
+    e->d_krow = nullptr;
+    e->d_info = nullptr;
+    e->d_rot = nullptr;
+    e->d_lut = nullptr;
+    for (int i = 0; i < 2; i++) {
+        e->d_state[i] = nullptr;
+        e->d_in[i] = nullptr;
+        e->d_raw[i] = nullptr;
+        e->h_in[i] = nullptr;
+        e->in_free[i] = e->in_free_wait[i] = nullptr;
+    }
+    for (int i = 0; i < kOutSlots; i++) {
+        e->slots[i] = OutSlot();
+    }
+    e->in_ready = e->kernel_done = nullptr;
+    e->s_in = e->s_compute = e->s_out = nullptr;
+    e->timing_events = false;
     e->committed = false;
 }
 
@@ -503,6 +534,8 @@ int mfm_engine_get_channel(struct mfm_engine *e, uint32_t chan, int16_t *coeff_r
     return MFM_OK;
 }
 
+static int commit_locked(struct mfm_engine *e);
+
 int mfm_engine_commit(struct mfm_engine *e)
 {
     if (!e) {
@@ -511,6 +544,25 @@ int mfm_engine_commit(struct mfm_engine *e)
     if (e->committed) {
         return fail(MFM_E_STATE, "already committed");
     }
+    for (int i = 0; i < 2; i++) {
+        if (e->cfg.ext_input[i] && (reinterpret_cast<uintptr_t>(e->cfg.ext_input[i]) & 15u)) {
+            return fail(MFM_E_INVAL, "ext_input buffers must be 16-byte aligned");
+        }
+    }
+    const int rc = commit_locked(e);
+    if (rc != MFM_OK && e->committed) {
+        /* a failure half-way through the device allocations: release what exists and leave the engine
+         * uncommitted (the data-path entry points check `committed`), keeping the failure's message */
+        char keep[sizeof(g_last_error)];
+        memcpy(keep, g_last_error, sizeof(keep));
+        free_device(e);
+        memcpy(g_last_error, keep, sizeof(keep));
+    }
+    return rc;
+}
+
+static int commit_locked(struct mfm_engine *e)
+{
     if (e->chans.empty()) {
         return fail(MFM_E_INVAL, "no channels");
     }
@@ -536,9 +588,8 @@ int mfm_engine_commit(struct mfm_engine *e)
     };
     uint32_t rs2 = 0;
     int opl = 2;
-    const char *force = getenv("MFM_OPL");
     uint64_t dw = tile_dwords(2, &rs2);
-    if ((force && atoi(force) == 1) || (dw + 512) * 4 > 53 * 1024) {
+    if ((dw + 512) * 4 > 53 * 1024) {
         opl = 1;
         dw = tile_dwords(1, &rs2);
     }
@@ -552,11 +603,7 @@ int mfm_engine_commit(struct mfm_engine *e)
     e->lds_bytes = (e->lut_off + 512) * 4;
     e->nchunks = (T + MFM_TG - 1) / MFM_TG;
     e->ngroups = (C + MFM_CG - 1) / MFM_CG;
-    e->gpw = MFM_NW;
-    if (const char *g = getenv("MFM_GPW")) {
-        e->gpw = std::max(1, atoi(g));
-    }
-    e->gpw = std::min(e->gpw, e->ngroups);
+    e->gpw = std::min<uint32_t>(MFM_NW, e->ngroups);
     e->nslices = (e->ngroups + e->gpw - 1) / e->gpw;
     e->cap_in = input_capacity(e->cfg.max_block_samples, T);
     e->out_stride = ((e->cap_in - T) / D + 1 + 1) & ~1u;
@@ -595,7 +642,7 @@ int mfm_engine_commit(struct mfm_engine *e)
      *      in registers and every tap splits into two signed bytes ---- */
     std::vector<uint32_t> afrag;
     std::vector<int32_t> krow;
-    e->use_mfma = (D % 8 == 0) && T <= 32u * MFM_MFMA_KQ_STREAM_MAX && !getenv("MFM_FORCE_DOT2");
+    e->use_mfma = (D % 8 == 0) && T <= 32u * MFM_MFMA_KQ_STREAM_MAX && !(e->cfg.flags & MFM_F_FORCE_DOT2);
     for (const Channel &ch : e->chans) {
         for (uint32_t i = 0; i < T && e->use_mfma; i++) {
             if (ch.cre[i] > 32639 || ch.cim[i] > 32639 || ch.cim[i] < -32639) {
@@ -618,14 +665,7 @@ int mfm_engine_commit(struct mfm_engine *e)
         }
         uint32_t ot = 0, plane = 0, lds = 0;
         const uint32_t want[] = { 2u * 31u, 31u }; /* new outputs per tile: two 31-output iterations, or one for large decimations */
-        uint32_t forced_ot = 0;
-        if (const char *f = getenv("MFM_OT")) {
-            forced_ot = (uint32_t)atoi(f);
-        }
         for (uint32_t cand : want) {
-            if (forced_ot && cand != forced_ot) {
-                continue;
-            }
             const uint32_t nst = ((cand * D + 32u * kq) + 3u) & ~3u;
             const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
             const uint32_t pb = rows * rs_m;
@@ -671,9 +711,6 @@ int mfm_engine_commit(struct mfm_engine *e)
             e->m_nrb = (2u * C + 15u) / 16u;
             e->m_nslices = (e->m_nrb + MFM_MFMA_NW - 1u) / MFM_MFMA_NW;
             e->m_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
-            if (const char *w = getenv("MFM_WG_PER_CU")) {
-                e->m_wg_per_cu = std::max(1, atoi(w));
-            }
 
             /* W[2c] = (cr0,-ci0,cr1,-ci1..), W[2c+1] = (ci0,cr0,ci1,cr1..) (filter/complex.h:40-46) */
             const uint32_t K = 64u * kq;
@@ -802,11 +839,6 @@ int mfm_engine_commit(struct mfm_engine *e)
         HIP_TRY(hipMemcpy(e->d_afrag, afrag.data(), afrag.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&e->d_krow, krow.size() * 4));
         HIP_TRY(hipMemcpy(e->d_krow, krow.data(), krow.size() * 4, hipMemcpyHostToDevice));
-        for (int i = 0; i < 2; i++) {
-            if (e->cfg.ext_input[i] && (reinterpret_cast<uintptr_t>(e->cfg.ext_input[i]) & 15u)) {
-                return fail(MFM_E_INVAL, "ext_input buffers must be 16-byte aligned");
-            }
-        }
     }
     HIP_TRY(hipMalloc(&e->d_info, info.size() * sizeof(mfm_chan_info)));
     HIP_TRY(hipMemcpy(e->d_info, info.data(), info.size() * sizeof(mfm_chan_info), hipMemcpyHostToDevice));
@@ -854,6 +886,7 @@ int mfm_engine_commit(struct mfm_engine *e)
         HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
     }
     if (e->cfg.flags & MFM_F_TIMING) {
+        e->timing_events = true;
         for (int i = 0; i < kTimingPairs; i++) {
             HIP_TRY(hipEventCreate(&e->t0[i]));
             HIP_TRY(hipEventCreate(&e->t1[i]));
@@ -989,11 +1022,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
             M.nchan = C;
             M.out_stride = e->out_stride;
-            M.ah_mask = getenv("MFM_ALL_PLANES") ? 0xffffu : e->m_ah_mask;
-            M.skew = 0; /* measured: no gain on MI355X (tools/ab.sh MFM_SKEW=..); kept as a knob */
-            if (const char *sk = getenv("MFM_SKEW")) {
-                M.skew = (uint32_t)atoi(sk);
-            }
+            M.ah_mask = e->m_ah_mask;
             M.tail_src = n_new * D;
             M.tail_n = n_avail - n_new * D;
             M.tail_dst = e->d_in[cur ^ 1];
@@ -1304,6 +1333,22 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->tail_samples = e->tail;
     st->rot_table_entries = e->rot_entries;
     return MFM_OK;
+}
+
+size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap)
+{
+    if (!e || !e->committed || !(e->cfg.flags & MFM_F_TIMING)) {
+        return 0;
+    }
+    if (hipSetDevice(e->cfg.device) != hipSuccess || fold_timing(e, true) != MFM_OK) {
+        return 0;
+    }
+    const size_t have = (size_t)std::min<uint64_t>(e->launch_ms_n, kLaunchRing);
+    const size_t n = std::min(have, cap);
+    for (size_t i = 0; i < n && dst; i++) {
+        dst[i] = e->launch_ms[(e->launch_ms_n - n + i) % kLaunchRing];
+    }
+    return n;
 }
 
 void *mfm_engine_stream(struct mfm_engine *e)

@@ -18,7 +18,7 @@
  *           four B values of four consecutive MFMAs are one ds_read_b128 of its column's row, the A fragments are
  *           laid out on the host to match and live in registers for a chunk.  Default.
  *   VALU  - lane = column, taps [tap][channel] read with scalar loads and fed to v_pk_fma_f32 as SGPR operands, two
- *           packed FMAs per complex tap (MFM_F32_VALU=1; kept for A/B):
+ *           packed FMAs per complex tap (MFM_F32_PACKED_FMA; kept for A/B):
  *               acc(re,im) += (cr, cr) * (xr, xi)            op_sel_hi:[0,1,1]
  *               acc(re,im) += (-ci, ci) * (xi, xr)           op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]
  * Measured: DESIGN.md 3.5 (71-90 TFLOP/s of the 157 TFLOP/s fp32 peak).
@@ -483,10 +483,7 @@ int mfm_f32_commit(struct mfm_f32_engine *e)
             }
         }
     }
-    {
-        const char *env = getenv("MFM_F32_VALU"); /* A/B: the packed-FMA variant */
-        e->use_mfma = !(env && env[0] == '1');
-    }
+    e->use_mfma = !(e->cfg.flags & MFM_F32_PACKED_FMA); /* A/B: the packed-FMA variant */
     float tbl[257];
     mfm_hosttwin_atan_table(tbl);
     if (!mfm_hosttwin_atan_table_ok()) {
