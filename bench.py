@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--settle-seconds", type=float, default=0.75)
     ap.add_argument("--channels-per-gpu", type=int, default=None,
                     help="default 64 at N = 1 (BASELINE configs[1]), 128 at N > 1 (configs[2]: 1024 channels on 8 GPUs)")
-    ap.add_argument("--kernel", choices=["auto", "dot2"], default="auto",
-                    help="dot2 = the v_dot2 kernel through MFM_F_FORCE_DOT2 (A/B timing)")
+    ap.add_argument("--kernel", choices=["auto", "mfma1", "dot2"], default="auto",
+                    help="mfma1 / dot2 = the first-generation matrix kernel / the v_dot2 kernel through the "
+                         "MFM_F_FORCE_* flags (A/B timing)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +164,8 @@ def main():
     bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
     eng = pkg.Engine(fs, decim, block, device=local_rank,
                      flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
-                     (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0),
+                     (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
+                     (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))
@@ -239,7 +241,8 @@ def main():
     bytes_per_launch = block * 4 + len(offs) * outs * 2        # 4 + 2*C_g/D bytes per input sample
     dot2_per_launch = 2.0 * len(offs) * T * outs               # two v_dot2 lane-ops per complex tap per output
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-    mfma = st1["kernel_variant"] == 1
+    mfma = st1["kernel_variant"] >= 1
+    kname = {0: "mfm_channel_kernel", 1: "mfm_channel_kernel_mfma", 2: "mfm_channel_kernel_v3"}[st1["kernel_variant"]]
     if mfma:
         # exact int16 MACs done as four int8 products on the matrix cores: 2 ops x 4 x (4 real MACs per complex tap)
         ops = 2.0 * 4.0 * 4.0 * len(offs) * T * outs
@@ -275,7 +278,7 @@ def main():
                                       f"channel shards x{world} + RCCL {exchange.algo} of the IQ block"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "mfm_channel_kernel_mfma" if mfma else "mfm_channel_kernel", "kernel_ms": k_ms,
+                         "kernel": kname, "kernel_ms": k_ms,
                          "kernel_ms_min": float(per_launch[0]) if len(per_launch) else None,
                          "kernel_ms_median": float(np.median(per_launch)) if len(per_launch) else None,
                          "kernel_ms_p95": float(np.percentile(per_launch, 95)) if len(per_launch) else None,

@@ -60,6 +60,8 @@ extern "C" {
 #define MFM_F_TIMING 0x2u      /* bracket every kernel launch with HIP events */
 #define MFM_F_FORCE_DOT2 0x4u  /* run the v_dot2 (packed int16 VALU) kernel even where the matrix-core kernel applies:
                                   both produce the same bits; parity tests and A/B timing select it here */
+#define MFM_F_FORCE_MFMA_V1 0x8u /* where both matrix-core kernels apply, run the first-generation one (31-output column
+                                  blocks, 2-byte PCM stores) instead of the second (64-output tiles, 8-byte stores) */
 
 struct mfm_engine_config {
     uint32_t abi_version;       /* MFM_ABI_VERSION */
@@ -96,7 +98,7 @@ struct mfm_stats {
     uint32_t grid_last;        /* workgroups of the last launch */
     uint32_t tail_samples;     /* unconsumed samples carried to the next block */
     uint64_t rot_table_entries;
-    uint32_t kernel_variant;   /* 0 = v_dot2 kernel, 1 = int8-MFMA (FIR-as-GEMM) kernel */
+    uint32_t kernel_variant;   /* 0 = v_dot2 kernel, 1 = int8-MFMA (FIR-as-GEMM) kernel, 2 = its second generation */
     uint32_t pending_blocks;   /* finished or in-flight blocks not yet fetched + released */
 };
 

@@ -9,12 +9,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-KERNELS = ["auto", "dot2"]  # "auto" = int8-MFMA kernel where it applies, "dot2" = forced v_dot2 kernel
+# "auto" = the matrix-core kernels where they apply (second generation when decimation % 32 == 0 and <= 128 taps, else
+# the first), "mfma1" = first-generation matrix kernel forced, "dot2" = forced v_dot2 kernel.  All three give the same bits.
+KERNELS = ["auto", "mfma1", "dot2"]
 
 
 def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_iq=False, flags=0, kernel="auto"):
     if kernel == "dot2":
         flags |= pkg.binding.MFM_F_FORCE_DOT2
+    if kernel == "mfma1":
+        flags |= pkg.binding.MFM_F_FORCE_MFMA_V1
     eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
     gains = gains if gains is not None else [1.0] * len(offs)
     for o, g in zip(offs, gains):
@@ -24,7 +28,12 @@ def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_i
     if kernel == "dot2":
         assert variant == 0
     elif decim % 8 == 0 and len(taps) <= 128 and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
-        assert variant == 1, "the matrix-core kernel should have been selected"
+        if kernel == "mfma1":
+            assert variant == 1, "the first-generation matrix-core kernel should have been selected"
+        else:
+            assert variant in (1, 2), "a matrix-core kernel should have been selected"
+            if decim in (32, 64, 96):
+                assert variant == 2, "decimation % 32 == 0, <= 128 taps: the second-generation kernel applies"
     return eng
 
 
@@ -130,7 +139,7 @@ def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntap
     taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
     iq = pkg.synth.synth_iq(96 * 2500 + ntaps, fs, offs[:3], seed=ntaps)
     eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 16, want_iq=want_iq)
-    assert eng.stats()["kernel_variant"] == 1, "long filters should run on the matrix cores too"
+    assert eng.stats()["kernel_variant"] == 1, "long filters should run on the (first-generation) matrix kernel too"
     eng.close()
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
 

@@ -1,0 +1,642 @@
+/*
+ * mfm_kernel_v3.hip - the multifm channel kernel on the matrix cores, second generation.
+ *
+ * Arithmetic: exactly that of mfm_kernel_mfma.hip - the bank of complex-tap decimating FIRs
+ * (filter/direct_fir.c:328-417, filter/complex.h:40-46) as four int8 byte-plane products per k-step on
+ * v_mfma_i32_16x16x64_i8 with wrapping int32 accumulators, then Q14 round, derotation by the tabulated
+ * rotator, Q14 round (filter/direct_fir.c:151-172,406-413), s = q * conj(prev), fast_atan2f, PCM
+ * (multifm/fm_demod.c:53-79, multifm/fast_atan2f.c:101-174).  Bit for bit the oracle's results.
+ *
+ * What is different is the assignment of outputs to lanes and of tiles to workgroups (mfm_kernel.h has the
+ * summary).  Measured on MI355X (profiles/r02_*): the first generation was held at ~105 us per 2^26-sample
+ * block by its 2-byte PCM stores alone (one 64-lane store instruction moves 128 bytes and takes as long as one
+ * that moves 1 KB), matrix instructions and other VALU instructions of one SIMD do not overlap (only two
+ * instructions between two MFMAs of a wave issue in the MFMA's shadow), and most VALU instructions other than
+ * 32-bit add / logic / shift-right / fp32 mul-add-fma take two issue slots.  Hence:
+ *   - 8-byte PCM stores (4 consecutive outputs per lane), 16-byte rotator loads;
+ *   - chunks of consecutive tiles per workgroup: history and table position stay in registers, no per-tile
+ *     index arithmetic, no recomputed column;
+ *   - workgroups stage 64 + 4 + (window overhang) rows per tile; the 4 rows in front are only read by the
+ *     first tile of a chunk (its column group 3 shifted one sub-plane row down yields output -1).
+ *
+ * Geometry: workgroup = 8 waves, wave w = GEMM rows 16w..16w+15 = channels 8w..8w+7 of the 64-channel slice,
+ * taps in registers.  Lane (kg = lane >> 4, n = lane & 15) holds, after column group g, re/im of channels
+ * 2kg, 2kg+1 (of the wave's eight) for output 64*tile + 4n + g.
+ */
+#include <hip/hip_runtime.h>
+
+#include "../../tsl-sdr_amd/csrc/mfm_kernel.h"
+#include "../../tsl-sdr_amd/csrc/mfm_numerics.h"
+
+typedef int mfm_v4i __attribute__((ext_vector_type(4)));
+__device__ unsigned long long g_trace[16 * 8 * 40 * 8];
+extern "C" int mfm_v3_trace_read(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), sizeof(g_trace)) == hipSuccess ? 0 : -1;
+}
+
+#define MFM3_NT 512u
+#define MFM3_SCHED_ALL_BUT_VMEM 0x38F
+
+/* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 */
+static __device__ __forceinline__ uint32_t mfm3_combine(int hh, int md, int ll)
+{
+    uint32_t t, a;
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(hh), "v"(md));
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a) : "v"(t), "v"(ll));
+    return a;
+}
+
+/* bits 29:14 of re_b and im_b (biased sums) as (re | im << 16), for two pairs: four SDWA shifts (see
+ * mfm_kernel_mfma.hip for the hazard notes: one wait state between a dst_sel write and the PRESERVE read) */
+static __device__ __forceinline__ void mfm3_round_pack2(const uint32_t re_b[2], const uint32_t im_b[2], uint32_t p[2])
+{
+    uint32_t p0, p1;
+    asm("v_lshrrev_b32_sdwa %0, 14, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, 14, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %0, 14, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, 14, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(p0), "=&v"(p1)
+        : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]));
+    p[0] = p0;
+    p[1] = p1;
+}
+
+/* o = f * r + 8192: two VOP3P v_dot2_i32_i16 (3 wait states before the results are read) */
+static __device__ __forceinline__ void mfm3_rotate_biased(uint32_t f, uint32_t rx, uint32_t ry, uint32_t *o_re,
+                                                          uint32_t *o_im)
+{
+    asm("v_dot2_i32_i16 %0, %2, %3, %5\n\tv_dot2_i32_i16 %1, %2, %4, %5\n\ts_nop 2"
+        : "=&v"(*o_re), "=&v"(*o_im)
+        : "v"(f), "v"(rx), "v"(ry), "s"(8192));
+}
+
+/* s = q * conj(p), wrapping int32 (multifm/fm_demod.c:55-64) */
+static __device__ __forceinline__ void mfm3_conj_mul(uint32_t q, uint32_t p, int *s_re, int *s_im)
+{
+    int u, t;
+    asm("v_dot2_i32_i16 %0, %3, %4, 0\n\t"
+        "v_mad_i32_i16 %1, %3, %4, 0 op_sel:[1,0,0,0]\n\t"
+        "v_mad_i32_i16 %2, %3, %4, 0 op_sel:[0,1,0,0]\n\t"
+        "s_nop 0"
+        : "=&v"(*s_re), "=&v"(u), "=&v"(t)
+        : "v"(q), "v"(p));
+    *s_im = (int)((uint32_t)u - (uint32_t)t);
+}
+
+/* derotation + second rounding of two packed samples (filter/direct_fir.c:406-413) */
+static __device__ __forceinline__ void derotate2(const uint32_t fin[2], const uint32_t rx[2], const uint32_t ry[2], uint32_t qout[2])
+{
+    uint32_t o_re[2], o_im[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        mfm3_rotate_biased(fin[c], rx[c], ry[c], &o_re[c], &o_im[c]);
+    }
+    mfm3_round_pack2(o_re, o_im, qout);
+}
+
+static __device__ __forceinline__ uint32_t mfm3_opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+/* rotator-table position of output index (kb + d) of a channel: pre-period as is, then folded into the period */
+static __device__ __forceinline__ uint32_t mfm3_fold(uint32_t kb, uint32_t d, uint32_t mu, uint32_t lam, uint32_t lam_magic)
+{
+    uint32_t k = kb + d;
+    if (k >= mu) {
+        const uint32_t x = k - mu;
+        uint32_t m = x - __umulhi(x, lam_magic) * lam;
+        m = (m >= lam) ? m - lam : m;
+        k = mu + m;
+    }
+    return k;
+}
+
+/*
+ * Four discriminators (multifm/fm_demod.c:68-72 on fast_atan2f.c:101-174), same operations in the same order as
+ * mfm_discriminate() in mfm_numerics.h (the form the host twin proves against the oracle), written for the issue
+ * costs measured on gfx950 (profiles/r02_ubench_ops.txt): fp32 mul / add / fma and 32-bit add / and / xor / shift-right
+ * take one issue slot, conversions, min / max, compares, selects, v_fract, SDWA / DPP and packed forms two, v_rcp_f32
+ * four.  So the division is scalar FMAs (no packed math: nothing to gain, registers to lose), and the table index comes
+ * out of the float adder: floor(alpha) + 2^21 has 4 * floor(alpha) in its low mantissa bits - the byte offset of
+ * T[floor(alpha)] - which saves the conversion and the shift.
+ * lut_addr: LDS byte address of T[0]; dT[0] sits 1024 bytes behind it.
+ */
+static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], const int s_im[4], uint32_t lut_addr, int pcm[4])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(off)
+    float x[4], y[4], mx[4], mn[4], z[4], fr[4], t0[4], dt[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        x[i] = (float)s_re[i];
+        y[i] = (float)s_im[i];
+        asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx[i]) : "v"(x[i]), "v"(y[i]));
+        asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn[i]) : "v"(x[i]), "v"(y[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        /* mfm_div_unit: correctly rounded mn / mx */
+        const float r0 = __builtin_amdgcn_rcpf(mx[i]);
+        const float e0 = __builtin_fmaf(-mx[i], r0, 1.0f);
+        const float r1 = __builtin_fmaf(e0, r0, r0);
+        const float q0 = mn[i] * r1;
+        const float e1 = __builtin_fmaf(-mx[i], q0, mn[i]);
+        const float q1 = __builtin_fmaf(e1, r1, q0);
+        const float e2 = __builtin_fmaf(-mx[i], q1, mn[i]);
+        z[i] = __builtin_fmaf(e2, r1, q1);
+    }
+    typedef const __attribute__((address_space(3))) float *lds_fp;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
+        fr[i] = __builtin_amdgcn_fractf(alpha);        /* :127 (alpha - floor(alpha), exact) */
+        const float fl = alpha - fr[i];                /* floor(alpha), 0..255 (NaN for (0, 0)) */
+        const float m = fl + 2097152.0f;               /* bits 0x4A000000 + 4 * floor(alpha) */
+        /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
+        const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x4A000000u);
+        lds_fp p = (lds_fp)(uintptr_t)addr;
+        t0[i] = p[0];
+        dt[i] = p[256];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float prod = dt[i] * fr[i];
+        const float interp = t0[i] + prod;             /* :130-131, unfused */
+        const float base = (z[i] < MFM_TAN_MAP_RES_F) ? z[i] : interp;
+        /* :134-163: sign(y) * (K + u), K in {0, pi, pi/2}, u = +-base */
+        const bool x_nonneg = s_re[i] >= 0, wide = __builtin_fabsf(x[i]) > __builtin_fabsf(y[i]);
+        const float k = wide ? (x_nonneg ? 0.0f : MFM_PI_F) : MFM_HALF_PI_F;
+        const float u = (x_nonneg == wide) ? base : -base;
+        const float mag = k + u;
+        const float lo = mag * MFM_Q14_OVER_PI_LO;
+        const float sc = __builtin_fmaf(mag, MFM_Q14_OVER_PI_HI, lo);
+        int signed_sc;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(signed_sc) : "s"(0x7fffffff), "v"(sc), "v"(s_im[i]));
+        pcm[i] = (int)__int_as_float(signed_sc);       /* NaN (from (0, 0)) converts to 0 = fast_atan2f.c:111-112 */
+    }
+#else
+    (void)s_re, (void)s_im, (void)lut_addr, (void)pcm;
+#endif
+}
+
+/* one work item = (chunk of consecutive tiles, 64-channel slice); XCD-aware: the slices of a chunk run back to back
+ * on one XCD, so the chunk's input is fetched from HBM once and re-read from that XCD's L2 */
+static __device__ __forceinline__ bool mfm3_decode_item(const mfm_launch_v3 &L, uint32_t item, uint32_t *chunk, uint32_t *slice)
+{
+    const uint32_t xcd = item & 7u, seq = item >> 3;
+    *chunk = (seq / L.nslices) * 8u + xcd;
+    *slice = seq % L.nslices;
+    return item < L.nitems && *chunk < L.nchunks;
+}
+
+template <int KQ, bool DBG_IQ, int NCH, int AHM>
+__global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_launch_v3 L)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t kg = lane >> 4, n = lane & 15u;
+    const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
+    const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
+    const uint32_t lut_addr = (uint32_t)(uintptr_t)(smem + L.lut_off);
+
+    /* atan LUT, once per workgroup: {T[i], T[i+1]-T[i]} pairs split into T[256] followed by dT[256] */
+    {
+        uint32_t *lut_s = reinterpret_cast<uint32_t *>(smem + L.lut_off);
+        const uint32_t *lut_g = reinterpret_cast<const uint32_t *>(L.lut);
+        for (uint32_t i = tid; i < 512; i += MFM3_NT) {
+            lut_s[(i >> 1) + ((i & 1u) << 8)] = lut_g[i];
+        }
+    }
+
+    /* staging: this thread owns the 16-byte chunks q = tid + j * 512 of every tile (4 samples = 8 bytes per byte
+     * plane); where they go in the image never changes: row = 8q / row_bytes, sub-plane row & 3, slot row >> 2 */
+    uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const uint32_t p8 = (tid + (uint32_t)j * MFM3_NT) * 8u;
+        const uint32_t row = p8 / row_bytes, colb = p8 % row_bytes;
+        sta_s[j * MFM3_NT + tid] = (row & 3u) * L.sp_pitch + (row >> 2) * rs + colb;
+    }
+
+    /* B fragments: lane part of the address; the (column group, k-step) part is wave uniform:
+     * row = LEAD + 4n + g + cross -> sub-plane (g + cross) & 3, slot 1 + n + ((g + cross) >> 2) */
+    uint32_t ofs[4][KQ], ofs_w[KQ];
+#pragma unroll
+    for (int kq = 0; kq < KQ; kq++) {
+        const uint32_t c = L.cross[kq], w = L.within[kq];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            ofs[g][kq] = ((g + c) & 3u) * L.sp_pitch + (1u + ((g + c) >> 2)) * rs + w;
+        }
+        ofs_w[kq] = ((3u + c) & 3u) * L.sp_pitch + ((3u + c) >> 2) * rs + w; /* column group 3, four rows earlier */
+    }
+    const uint32_t lb0 = n * rs + 16u * kg;
+
+    auto stage_load = [&](uint32_t tile, int j) -> uint4 {
+        /* 4 samples of the image of `tile`, which starts LEAD rows in front of the tile's first output.  Only a
+         * readable address is needed: samples before the stream start feed nothing but the recomputed output of
+         * tile 0 (replaced by the carried sample), samples past n_avail only outputs >= n_new (never stored) or
+         * zero-padded taps.  Chunks past the image all read the tile's first line (one cache line per wave). */
+        const uint32_t q = tid + (uint32_t)j * MFM3_NT;
+        int gs = (int)(tile * MFM_V3_OT * D) - (int)(MFM_V3_LEAD * D) + 4 * (int)(q < L.nstage4 ? q : 0u);
+        gs = gs < 0 ? 0 : gs;
+        gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
+        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
+    };
+    auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
+        if (tid + (uint32_t)j * MFM3_NT < L.nstage4) {
+            uint2 hi, lo;
+            hi.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+            hi.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+            lo.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) ^ 0x80808080u;
+            lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) ^ 0x80808080u;
+            uint8_t *base = smem + buf * L.buf_pitch + sta_s[j * MFM3_NT + tid];
+            *reinterpret_cast<uint2 *>(base) = hi;
+            *reinterpret_cast<uint2 *>(base + L.plane_pitch) = lo;
+        }
+    };
+
+    /* the unconsumed samples at the end of this block are the head of the next one */
+    if (blockIdx.x == 0) {
+        for (uint32_t i = tid; i < L.tail_n; i += MFM3_NT) {
+            L.tail_dst[i] = L.x[L.tail_src + i];
+        }
+    }
+
+    uint32_t item = blockIdx.x, chunk, slice;
+    if (!mfm3_decode_item(L, item, &chunk, &slice)) {
+        return;
+    }
+    uint32_t tile = chunk * L.cl;
+    uint32_t tend = min(tile + L.cl, L.ntiles);
+    {
+        uint4 v[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            v[j] = stage_load(tile, j);
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            stage_store(0, j, v[j]);
+        }
+    }
+    __syncthreads();
+
+    mfm_v4i a_h[KQ], a_l[KQ];
+    /* 128 * sum(W) + 8192 of the wave's 16 rows: 64 bytes of LDS per wave (read back as the initial value of the low
+     * accumulator of every column group; four registers that need not be live through the epilogue) */
+    mfm_v4i *krow_s = reinterpret_cast<mfm_v4i *>(smem + L.sta_off + NCH * MFM3_NT * 4u) + wave * 4u + kg;
+    /* behind them, per (wave, kg, channel of the lane): {byte offset of table position mu + lam, 8 * lam} */
+    uint2 *fold_s = reinterpret_cast<uint2 *>(smem + L.sta_off + NCH * MFM3_NT * 4u + 512u) + (wave * 4u + kg) * 2u;
+    uint32_t slice_loaded = 0xffffffffu;
+    uint32_t cur = 0;
+    bool first_of_chunk = true;
+    unsigned long long *trc = g_trace;
+    uint32_t trn = 0;
+#define STAMP(id) do { if (trc && blockIdx.x < 16 && lane == 0 && trn < 40) { trc[((blockIdx.x * 8 + wave) * 40 + trn) * 8 + (id)] = __builtin_readcyclecounter(); } } while (0)
+
+    /* per-lane state of the chunk: two channels */
+    uint32_t kb8[2] = { 0, 0 };   /* byte offset into the rotator table of the entry of (this tile's first output + 4n) */
+    uint32_t voff[2] = { 0, 0 };  /* byte offset into pcm of (channel, this tile's first output + 4n) */
+    uint32_t hist[2] = { 0, 0 };  /* lanes n = 0: filtered sample of the output in front of this tile */
+    bool ch_ok[2] = { false, false };
+
+    while (true) {
+        /* what follows this tile in the workgroup's stream: the next tile of the chunk, or the first tile of the
+         * workgroup's next item; its image is requested now and written to the other buffer at the end */
+        uint32_t n_item = item, n_chunk = chunk, n_slice = slice, n_tile = tile + 1u, n_tend = tend;
+        bool n_first = false, n_valid = true;
+        if (n_tile >= tend) {
+            n_item = item + gridDim.x;
+            n_valid = mfm3_decode_item(L, n_item, &n_chunk, &n_slice);
+            n_tile = n_chunk * L.cl;
+            n_tend = min(n_tile + L.cl, L.ntiles);
+            n_first = true;
+        }
+        STAMP(0);
+        uint4 pre[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            pre[j] = stage_load(n_valid ? n_tile : tile, j);
+        }
+        __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
+
+        const uint32_t rb = slice * 8u + wave;
+        const bool rb_valid = rb < L.nrb; /* wave uniform */
+        const uint32_t lb = lb0 + cur * L.buf_pitch;
+        const uint8_t *img = smem;
+        const uint32_t first_out = tile * MFM_V3_OT;
+
+        uint32_t f[4][2];
+        uint4 rva[2][2];
+        if (rb_valid) {
+            const uint32_t ch0 = rb * 8u + 2u * kg;
+            if (slice != slice_loaded) {
+                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rb * KQ * 2 * 64 + mfm3_opaque(lane);
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    a_h[kq] = ap[(kq * 2 + 0) * 64];
+                    a_l[kq] = ap[(kq * 2 + 1) * 64];
+                }
+                const mfm_v4i krow = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rb * 16 + 4 * mfm3_opaque(kg));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (n == 0) {
+                    *krow_s = krow; /* only this wave reads it */
+                }
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    asm volatile("" : "+v"(a_h[kq]), "+v"(a_l[kq]));
+                }
+                slice_loaded = slice;
+            }
+
+            /* one column group: 16 rows x 16 columns x 64*KQ elements, four byte-plane products, then
+             * recombination and the first Q14 rounding -> packed filtered samples of the lane's two channels */
+            auto column_group = [&](const uint32_t (&o)[KQ], uint32_t fout[2]) {
+                mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = *krow_s;
+                mfm_v4i bh[2], bl[2];
+                bh[0] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[0]);
+                bl[0] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[0] + L.plane_pitch);
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    const int cb = kq & 1, nb = cb ^ 1;
+                    if (kq + 1 < KQ) {
+                        bh[nb] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[kq + 1]);
+                        bl[nb] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[kq + 1] + L.plane_pitch);
+                    }
+                    if ((ah_mask >> kq) & 1u) {
+                        hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
+                        md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
+                    }
+                    ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
+                    md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
+                }
+                /* MFMA -> VALU read hazard: 16 wait states cover a 16x16x64 MFMA (hipcc has been seen to leave it
+                 * unpadded across the loop-carried edge) */
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t a_re[2], a_im[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    a_re[c] = mfm3_combine(hh[2 * c], md[2 * c], ll[2 * c]);
+                    a_im[c] = mfm3_combine(hh[2 * c + 1], md[2 * c + 1], ll[2 * c + 1]);
+                }
+                mfm3_round_pack2(a_re, a_im, fout);
+            };
+
+            if (first_of_chunk) {
+                /* ---- chunk set-up: where the lane's two channels stand in their rotator tables and in the output,
+                 *      and the filtered sample in front of the chunk ---- */
+                uint32_t wrx[2], wry[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t chn = ch0 + c;
+                    ch_ok[c] = chn < L.nchan;
+                    const uint32_t chs = ch_ok[c] ? chn : 0u;
+                    const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chs * 8;
+                    const uint4 inf = *reinterpret_cast<const uint4 *>(ip);
+                    const uint32_t lam_magic = ip[4];
+                    const uint32_t kb = L.st_in[chs].kb;
+                    const uint32_t mu = inf.z, lam = inf.w;
+                    const uint32_t k0 = mfm3_fold(kb, first_out, mu, lam, lam_magic);
+                    kb8[c] = (inf.x + k0 + 4u * n) * 8u;
+                    if (n == 0) {
+                        fold_s[c] = make_uint2((inf.x + mu + lam) * 8u, lam * 8u); /* only this wave reads it */
+                    }
+                    voff[c] = (chs * L.out_stride + first_out + 4u * n) * 2u;
+                    if (first_out == 0) {
+                        hist[c] = L.st_in[chs].carry_q; /* multifm/fm_demod.c:16-17: last sample of the previous pass */
+                        wrx[c] = wry[c] = 0;
+                    } else {
+                        /* rotator entry of output first_out - 1 (folded on its own: the entry in front of a period is
+                         * not the period's last one) */
+                        const uint32_t kw = mfm3_fold(kb, first_out - 1u, mu, lam, lam_magic);
+                        const uint2 e = L.rot[inf.x + kw];
+                        wrx[c] = e.x;
+                        wry[c] = e.y;
+                    }
+                }
+                if (first_out != 0) {
+                    /* column group 3 one sub-plane row down: lane n computes output first_out - 4 + 4n + 3; n = 0 is
+                     * the output in front of the chunk */
+                    uint32_t fw[2], qw[2];
+                    uint32_t ow[KQ];
+#pragma unroll
+                    for (int kq = 0; kq < KQ; kq++) {
+                        ow[kq] = ofs_w[kq];
+                    }
+                    column_group(ow, fw);
+                    derotate2(fw, wrx, wry, qw);
+                    hist[0] = qw[0];
+                    hist[1] = qw[1];
+                }
+            }
+
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t og[KQ];
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    og[kq] = ofs[g][kq];
+                }
+                column_group(og, f[g]);
+                if (g == 1) {
+                    /* rotator entries of this tile, four consecutive ones per channel: requested half-way through
+                     * the matrix phase (16 registers that need not be live before), needed behind it */
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
+                        rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
+                        rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+        STAMP(1);
+        if (rb_valid) {
+            const uint32_t ch0 = rb * 8u + 2u * kg;
+            /* ---- one channel after the other (register pressure): derotation, discriminator, stores ---- */
+            const uint32_t n_left = L.n_new - first_out; /* >= 1 */
+            uint32_t q[4][2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                /* derotation + second rounding, two column groups per call */
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint4 e = rva[c][h];
+                    const uint32_t fin[2] = { f[2 * h][c], f[2 * h + 1][c] };
+                    const uint32_t rx[2] = { e.x, e.z }, ry[2] = { e.y, e.w };
+                    uint32_t qo[2];
+                    derotate2(fin, rx, ry, qo);
+                    q[2 * h][c] = qo[0];
+                    q[2 * h + 1][c] = qo[1];
+                }
+                /* discriminator: previous output = previous column group; for group 0 the neighbouring lane's group 3,
+                 * and for lane n = 0 the last output of the previous tile */
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp((int)hist[c], (int)q[3][c], 0x111 /* row_shr:1 */,
+                                                                          0xf, 0xf, false);
+                const uint32_t pp[4] = { p0, q[0][c], q[1][c], q[2][c] };
+                int s_re[4], s_im[4], pcm[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    mfm3_conj_mul(q[g][c], pp[g], &s_re[g], &s_im[g]);
+                }
+                mfm3_discriminate4(s_re, s_im, lut_addr, pcm);
+                /* lane 0 of each row of 16 lanes gets lane 15's last sample: the next tile's history */
+                hist[c] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[3][c], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
+                if (n_left >= MFM_V3_OT) {
+                    if (ch_ok[c]) {
+                        uint2 w;
+                        w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
+                        w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
+                        *reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]) = w;
+                        if (DBG_IQ) {
+                            *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + 2u * (size_t)voff[c]) =
+                                make_uint4(q[0][c], q[1][c], q[2][c], q[3][c]);
+                        }
+                    }
+                } else {
+                    /* the last tile of the pass, partly filled */
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        if (ch_ok[c] && 4u * n + (uint32_t)g < n_left) {
+                            *reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c] + 2u * g) = (int16_t)pcm[g];
+                            if (DBG_IQ) {
+                                *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + 2u * (size_t)voff[c] + 4u * g) = q[g][c];
+                            }
+                        }
+                    }
+                }
+                if (c == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (n_left <= MFM_V3_OT) {
+                /* this tile holds output n_new - 1: the sample the next pass starts from */
+                const uint32_t last = n_left - 1u;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        if (ch_ok[c] && 4u * n + (uint32_t)g == last) {
+                            L.st_out[ch0 + c].carry_q = q[g][c];
+                        }
+                    }
+                }
+            }
+            if (first_out == 0 && n == 0) {
+                /* rotator position of the next pass's first output, one lane per channel pair */
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (ch_ok[c]) {
+                        const uint32_t chn = ch0 + c;
+                        const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chn * 8;
+                        L.st_out[chn].kb = mfm3_fold(L.st_in[chn].kb, L.n_new, ip[2], ip[3], ip[4]);
+                    }
+                }
+            }
+            /* next tile of the chunk: 64 outputs on */
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint2 fo = fold_s[c]; /* at or past table position mu + lam the position folds back by lam */
+                kb8[c] += MFM_V3_OT * 8u;
+                kb8[c] = kb8[c] >= fo.x + 32u * n ? kb8[c] - fo.y : kb8[c];
+                voff[c] += MFM_V3_OT * 2u;
+            }
+        }
+
+        /* The next image goes to the other buffer at the very end of the tile: its loads have had the whole tile to
+         * arrive (written before the epilogue, the wait for them - HBM latency with every workgroup asking at once -
+         * cost 12 % of the launch).  After the barrier nobody reads the current buffer any more. */
+        STAMP(2);
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            stage_store(cur ^ 1u, j, pre[j]);
+        }
+        STAMP(3);
+        __syncthreads();
+        STAMP(4);
+        trn++;
+
+        if (!n_valid) {
+            break;
+        }
+        cur ^= 1u;
+        item = n_item;
+        chunk = n_chunk;
+        slice = n_slice;
+        tile = n_tile;
+        tend = n_tend;
+        first_of_chunk = n_first;
+    }
+}
+
+extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, uint32_t lds_bytes, uint32_t grid,
+                                                   hipStream_t stream)
+{
+    if (L->ntiles == 0) {
+        return hipSuccess;
+    }
+    const uint32_t nch = (L->nstage4 + MFM3_NT - 1) / MFM3_NT;
+    if (nch < 1 || nch > MFM_V3_CH_MAX) {
+        return hipErrorInvalidValue;
+    }
+#define MFM3_LAUNCH(KQ_, DBG_, NCH_, AHM_)                                                                   \
+    do {                                                                                                     \
+        auto kfn = mfm_channel_kernel_v3<KQ_, DBG_, NCH_, AHM_>;                                             \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        if (e_ != hipSuccess) {                                                                              \
+            return e_;                                                                                       \
+        }                                                                                                    \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM3_NT), lds_bytes, stream, *L);                           \
+    } while (0)
+#define MFM3_LAUNCH_N(KQ_, DBG_, AHM_)                                                                       \
+    do {                                                                                                     \
+        switch (nch) {                                                                                       \
+        case 1: MFM3_LAUNCH(KQ_, DBG_, 1, AHM_); break;                                                      \
+        case 2: MFM3_LAUNCH(KQ_, DBG_, 2, AHM_); break;                                                      \
+        case 3: MFM3_LAUNCH(KQ_, DBG_, 3, AHM_); break;                                                      \
+        case 4: MFM3_LAUNCH(KQ_, DBG_, 4, AHM_); break;                                                      \
+        case 5: MFM3_LAUNCH(KQ_, DBG_, 5, AHM_); break;                                                      \
+        case 6: MFM3_LAUNCH(KQ_, DBG_, 6, AHM_); break;                                                      \
+        case 7: MFM3_LAUNCH(KQ_, DBG_, 7, AHM_); break;                                                      \
+        default: MFM3_LAUNCH(KQ_, DBG_, 8, AHM_); break;                                                     \
+        }                                                                                                    \
+    } while (0)
+#define MFM3_LAUNCH_D(KQ_, AHM_)                                                                             \
+    do {                                                                                                     \
+        if (dbg_iq) {                                                                                        \
+            MFM3_LAUNCH_N(KQ_, true, -1);                                                                    \
+        } else {                                                                                             \
+            MFM3_LAUNCH_N(KQ_, false, AHM_);                                                                 \
+        }                                                                                                    \
+    } while (0)
+    switch (L->kq) {
+    case 1: MFM3_LAUNCH_D(1, -1); break;
+    case 2: MFM3_LAUNCH_D(2, -1); break;
+    case 4:
+        if (L->ah_mask == 0x6u) {
+            MFM3_LAUNCH_D(4, 0x6);
+        } else {
+            MFM3_LAUNCH_D(4, -1);
+        }
+        break;
+    default: return hipErrorInvalidValue;
+    }
+#undef MFM3_LAUNCH_D
+#undef MFM3_LAUNCH_N
+#undef MFM3_LAUNCH
+    return hipGetLastError();
+}

@@ -17,6 +17,7 @@ MFM_ABI_VERSION = 1
 MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
 MFM_F_FORCE_DOT2 = 0x4
+MFM_F_FORCE_MFMA_V1 = 0x8
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)

@@ -30,6 +30,8 @@ extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, in
                                                 hipStream_t stream);
 extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, uint32_t lds_bytes,
                                                      uint32_t grid, hipStream_t stream);
+extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, uint32_t lds_bytes, uint32_t grid,
+                                                   hipStream_t stream);
 
 #if defined(MFM_TRACE)
 static unsigned long long *g_trace_dev = nullptr;
@@ -158,6 +160,10 @@ struct mfm_engine {
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
     bool m_fixed_planes = false;
     uint32_t m_ah_mask = 0; /* k-steps whose high-byte tap plane is not all zero */
+    /* second-generation matrix kernel (mfm_kernel_v3.hip): same tap fragments, its own LDS image */
+    bool use_v3 = false;
+    uint32_t v_rs = 0, v_sp_pitch = 0, v_nstage4 = 0, v_lds_bytes = 0, v_wg_per_cu = 1, v_cross[4] = { 0, 0, 0, 0 },
+             v_within[4] = { 0, 0, 0, 0 };
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
 
@@ -606,7 +612,8 @@ static int commit_locked(struct mfm_engine *e)
     e->gpw = std::min<uint32_t>(MFM_NW, e->ngroups);
     e->nslices = (e->ngroups + e->gpw - 1) / e->gpw;
     e->cap_in = input_capacity(e->cfg.max_block_samples, T);
-    e->out_stride = ((e->cap_in - T) / D + 1 + 1) & ~1u;
+    /* a multiple of 8 outputs: channel rows of the PCM buffer start 16-byte aligned (8-byte PCM / 16-byte IQ stores) */
+    e->out_stride = ((e->cap_in - T) / D + 1 + 7) & ~7u;
     e->any_iq = false;
     for (const Channel &c : e->chans) {
         e->any_iq |= c.want_iq;
@@ -753,6 +760,36 @@ static int commit_locked(struct mfm_engine *e)
                      * bias of the first round_q30_q15 (filter/complex.h:30-34), added here once */
                     krow[(size_t)rb * 16 + i] = (int32_t)(128u * sum + 8192u);
                 }
+            }
+        }
+    }
+
+    /* ---- second-generation matrix kernel: 64-output tiles, four sub-planes per byte plane (mfm_kernel.h) ---- */
+    e->use_v3 = false;
+    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && e->m_ks <= 4u && (2u * D) % 64u == 0u) {
+        const uint32_t kq = e->m_ks, row_bytes = 2u * D;
+        uint32_t rs_v = (row_bytes + 31u) / 32u * 32u;
+        if (((rs_v / 32u) & 1u) == 0u) {
+            rs_v += 32u; /* odd multiple of 32 bytes: the B-fragment read pattern runs at the full ds_read_b128 rate */
+        }
+        const uint32_t extra = (64u * kq - 1u) / row_bytes; /* rows the last output's window reaches past the tile */
+        const uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + extra;
+        const uint32_t sr = (rows + 3u) / 4u;
+        uint32_t sp = sr * rs_v;
+        sp = sp <= 4096u ? 4096u : (sp + 63u) & ~63u;
+        const uint32_t nstage4 = rows * D / 4u; /* D % 16 == 0 here */
+        const uint32_t nch = (nstage4 + 511u) / 512u;
+        const uint32_t lds = 16u * sp + 2048u + nch * 512u * 4u + 1024u; /* image, atan table, staging offsets, row constants + fold constants */
+        if (nch <= MFM_V3_CH_MAX && lds <= 160u * 1024u) {
+            e->use_v3 = true;
+            e->v_rs = rs_v;
+            e->v_sp_pitch = sp;
+            e->v_nstage4 = nstage4;
+            e->v_lds_bytes = lds;
+            e->v_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
+            for (uint32_t k = 0; k < 4; k++) {
+                e->v_cross[k] = k < kq ? (64u * k) / row_bytes : 0u;
+                e->v_within[k] = k < kq ? (64u * k) % row_bytes : 0u;
             }
         }
     }
@@ -999,7 +1036,61 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             ti = (int)(e->t_head % kTimingPairs);
             HIP_TRY(hipEventRecord(e->t0[ti], e->s_compute));
         }
-        if (e->use_mfma) {
+        if (e->use_v3) {
+            mfm_launch_v3 V{};
+            V.x = e->d_in[cur];
+            V.n_avail = n_avail;
+            V.n_new = n_new;
+            V.decim = D;
+            V.x_last4 = (e->cap_in - 4u) & ~3u;
+            V.kq = e->m_ks;
+            V.rs = e->v_rs;
+            V.sp_pitch = e->v_sp_pitch;
+            V.plane_pitch = 4u * e->v_sp_pitch;
+            V.buf_pitch = 8u * e->v_sp_pitch;
+            V.nstage4 = e->v_nstage4;
+            V.lut_off = 16u * e->v_sp_pitch;
+            V.sta_off = V.lut_off + 2048u;
+            for (int k = 0; k < 4; k++) {
+                V.cross[k] = e->v_cross[k];
+                V.within[k] = e->v_within[k];
+            }
+            V.nslices = e->m_nslices;
+            V.nrb = e->m_nrb;
+            V.ntiles = (n_new + MFM_V3_OT - 1u) / MFM_V3_OT;
+            /* chunks of consecutive tiles, `rounds` per workgroup slot and slice, lengths equal to within one tile
+             * (a chunk pays one extra column group) */
+            const uint32_t slots = 256u * e->v_wg_per_cu;
+            const uint32_t per_slice = std::max(1u, slots / V.nslices);
+#ifndef MFM_V3_CHUNK_TILES
+#define MFM_V3_CHUNK_TILES 1000000u
+#endif
+            const uint32_t per_slot = (V.ntiles + per_slice - 1u) / per_slice; /* tiles per slot */
+            const uint32_t rounds = std::max(1u, per_slot / (uint32_t)MFM_V3_CHUNK_TILES);
+            V.nchunks = std::min(V.ntiles, per_slice * rounds);
+            V.cl = (V.ntiles + V.nchunks - 1u) / V.nchunks;
+            V.nitems = ((V.nchunks + 7u) / 8u) * 8u * V.nslices;
+            V.nchan = C;
+            V.out_stride = e->out_stride;
+            V.ah_mask = e->m_ah_mask;
+            V.tail_src = n_new * D;
+            V.tail_n = n_avail - n_new * D;
+            V.tail_dst = e->d_in[cur ^ 1];
+            tail_in_kernel = true;
+            V.afrag = e->d_afrag;
+            V.krow = e->d_krow;
+            V.info = e->d_info;
+            V.rot = e->d_rot;
+            V.st_in = L.st_in;
+            V.st_out = L.st_out;
+            V.lut = e->d_lut;
+            V.pcm = slot->d_pcm;
+            V.iq_dbg = L.iq_dbg;
+            const uint32_t grid = std::min(V.nitems, slots);
+            HIP_TRY(mfm_launch_channel_kernel_v3(&V, e->any_iq ? 1 : 0, e->v_lds_bytes, grid, e->s_compute));
+            L.ntiles = grid; /* for grid_last below */
+            L.nslices = 1;
+        } else if (e->use_mfma) {
             mfm_launch_mfma M{};
             M.x = e->d_in[cur];
             M.n_avail = n_avail;
@@ -1322,9 +1413,9 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->kernel_ms = e->kernel_ms;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
-    st->outputs_per_tile = e->use_mfma ? e->m_ot : 64u * e->opl;
-    st->lds_bytes = e->use_mfma ? e->m_lds_bytes : e->lds_bytes;
-    st->kernel_variant = e->use_mfma ? 1u : 0u;
+    st->outputs_per_tile = e->use_v3 ? MFM_V3_OT : e->use_mfma ? e->m_ot : 64u * e->opl;
+    st->lds_bytes = e->use_v3 ? e->v_lds_bytes : e->use_mfma ? e->m_lds_bytes : e->lds_bytes;
+    st->kernel_variant = e->use_v3 ? 2u : e->use_mfma ? 1u : 0u;
     {
         std::lock_guard<std::mutex> guard(e->mu);
         st->pending_blocks = (uint32_t)(e->submit_seq - e->fetch_seq);

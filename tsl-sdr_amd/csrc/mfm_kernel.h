@@ -109,3 +109,55 @@ struct mfm_launch_mfma {
     uint32_t *iq_dbg;
     unsigned long long *trace; /* NULL unless the library was built with -DMFM_TRACE */
 };
+
+/* ---------------------------------------------------------------------------------------------
+ * FIR-as-GEMM, second generation (mfm_kernel_v3.hip).  Same arithmetic and the same tap fragments as
+ * mfm_kernel_mfma.hip; what changed is who owns which output:
+ *   - a tile is 64 consecutive outputs, column n of column group g (g = 0..3) is output 64*tile + 4*n + g, so a
+ *     lane ends up with FOUR CONSECUTIVE outputs of its two channels: the PCM leaves as one 8-byte store per
+ *     channel and tile (the 2-byte stores of the first generation bound that kernel at ~105 us per 2^26-sample
+ *     block all by themselves, profiles/r02_knockout.txt), and the rotator entries arrive as 16-byte loads;
+ *   - a workgroup walks a CHUNK of consecutive tiles of one 64-channel slice, so the discriminator's one-sample
+ *     history and the rotator-table position are carried in registers from tile to tile; only the first tile
+ *     of a chunk recomputes the output in front of it (one extra column group per chunk instead of one
+ *     recomputed column per 31);
+ *   - the LDS image of a tile keeps the rows (one row = the D samples between two outputs) of equal index mod 4
+ *     in four sub-planes, which makes "lane n reads row 4n + g" the same conflict-free stride pattern as
+ *     "lane n reads row n" was.
+ * Used when decimation % 32 == 0 (a 64-byte k-step never straddles a row), taps <= 128 and the image fits LDS.
+ * ------------------------------------------------------------------------------------------- */
+#define MFM_V3_OT 64u          /* outputs per tile */
+#define MFM_V3_LEAD 4u         /* rows staged in front of a tile (the first tile of a chunk recomputes output -1) */
+#define MFM_V3_CH_MAX 8u       /* 16-byte staging chunks per thread and tile, at most */
+
+struct mfm_launch_v3 {
+    const uint32_t *x;
+    uint32_t n_avail, n_new, decim;
+    uint32_t x_last4;
+    uint32_t kq;          /* k-steps of 64 elements (1, 2 or 4) */
+    uint32_t rs;          /* LDS row stride in bytes, an odd multiple of 32 */
+    uint32_t sp_pitch;    /* bytes between the four sub-planes (rows = 0,1,2,3 mod 4) of a byte plane */
+    uint32_t plane_pitch; /* bytes between the high-byte and the low-byte plane = 4 * sp_pitch */
+    uint32_t buf_pitch;   /* bytes between the two staging buffers = 2 * plane_pitch */
+    uint32_t nstage4;     /* 16-byte chunks (4 samples) staged per tile: (LEAD + 64 + extra rows) * D / 4 */
+    uint32_t lut_off, sta_off;
+    uint32_t cross[4];    /* per k-step: rows between an output's first sample and the k-step's first element */
+    uint32_t within[4];   /* per k-step: byte offset of that element inside its row (for kg = 0) */
+    uint32_t nslices, nrb;
+    uint32_t ntiles;      /* ceil(n_new / 64) */
+    uint32_t cl;          /* tiles per chunk */
+    uint32_t nchunks;     /* ceil(ntiles / cl) */
+    uint32_t nitems;      /* chunks rounded up to a multiple of 8, times slices */
+    uint32_t nchan, out_stride, ah_mask;
+    uint32_t tail_src, tail_n;
+    uint32_t *tail_dst;
+    const uint32_t *afrag;
+    const int32_t *krow;
+    const struct mfm_chan_info *info;
+    const uint2 *rot;
+    const struct mfm_chan_state *st_in;
+    struct mfm_chan_state *st_out;
+    const float2 *lut;
+    int16_t *pcm;
+    uint32_t *iq_dbg;
+};
