@@ -25,17 +25,15 @@
  */
 #include <hip/hip_runtime.h>
 
-#include "mfm_kernel.h"
-#include "mfm_numerics.h"
+#include "../../tsl-sdr_amd/csrc/mfm_kernel.h"
+#include "../../tsl-sdr_amd/csrc/mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 
 #define MFM3_NT 512u
 #define MFM3_SCHED_ALL_BUT_VMEM 0x38F
 
-/* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 (left to itself the compiler makes it two shifts and a three-operand
- * add).  The accumulators come straight from MFMAs and the compiler does not pad the MFMA -> VALU read hazard for what it
- * cannot see inside inline asm: callers put 16 wait states between the last MFMA and this. */
+/* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 */
 static __device__ __forceinline__ uint32_t mfm3_combine(int hh, int md, int ll)
 {
     uint32_t t, a;
@@ -300,11 +298,20 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     }
     __syncthreads();
 
-    /* The second half of a workgroup loses the arbitration for the SIMD to the first (older) half on every phase and
-     * reaches each barrier ~1300 cycles later (s_memtime stamps, profiles/r02_v3_phases.txt): static priority for it. */
-    if (wave >= 4) {
-        __builtin_amdgcn_s_setprio(1);
+#ifdef MFM3_STAGGER
+    {
+        /* de-synchronise the workgroups: the two of a CU half a tile apart, CUs spread over a tile */
+        const uint32_t units = (((blockIdx.x >> 8) & 1u) * 4u + ((blockIdx.x >> 3) & 3u)) * MFM3_STAGGER;
+        for (uint32_t z = 0; z < units; z++) {
+            __builtin_amdgcn_s_sleep(64); /* 64 x 64 clocks */
+        }
     }
+#endif
+#ifdef MFM3_PRIO
+    if (wave >= 4) {
+        __builtin_amdgcn_s_setprio(MFM3_PRIO);
+    }
+#endif
     mfm_v4i a_h[KQ], a_l[KQ];
     /* 128 * sum(W) + 8192 of the wave's 16 rows: 64 bytes of LDS per wave (read back as the initial value of the low
      * accumulator of every column group; four registers that need not be live through the epilogue) */
@@ -369,8 +376,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 slice_loaded = slice;
             }
 
-            /* one column group: 16 rows x 16 columns x 64*KQ elements, four byte-plane products (acc = hh, md, ll) */
-            auto mfma_chain = [&](const uint32_t (&o)[KQ], mfm_v4i (&acc)[3]) {
+            /* one column group: 16 rows x 16 columns x 64*KQ elements, four byte-plane products, then
+             * recombination and the first Q14 rounding -> packed filtered samples of the lane's two channels */
+            auto column_group = [&](const uint32_t (&o)[KQ], uint32_t fout[2]) {
                 mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = *krow_s;
                 mfm_v4i bh[2], bl[2];
                 bh[0] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[0]);
@@ -389,31 +397,18 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
                     md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
                 }
-                acc[0] = hh;
-                acc[1] = md;
-                acc[2] = ll;
-            };
-            /* recombination and the first Q14 rounding -> packed filtered samples of the lane's two channels */
-            auto finish = [&](const mfm_v4i (&acc)[3], uint32_t fout[2]) {
-                uint32_t a_re[2], a_im[2];
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    a_re[c] = mfm3_combine(acc[0][2 * c], acc[1][2 * c], acc[2][2 * c]);
-                    a_im[c] = mfm3_combine(acc[0][2 * c + 1], acc[1][2 * c + 1], acc[2][2 * c + 1]);
-                }
-                mfm3_round_pack2(a_re, a_im, fout);
-            };
-            /* MFMA -> VALU read hazard: 16 wait states cover a 16x16x64 MFMA (hipcc has been seen to leave it unpadded) */
-            auto settle = [&]() {
+                /* MFMA -> VALU read hazard: 16 wait states cover a 16x16x64 MFMA (hipcc has been seen to leave it
+                 * unpadded across the loop-carried edge) */
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            auto column_group = [&](const uint32_t (&o)[KQ], uint32_t fout[2]) {
-                mfm_v4i acc[3];
-                mfma_chain(o, acc);
-                settle();
-                finish(acc, fout);
+                uint32_t a_re[2], a_im[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    a_re[c] = mfm3_combine(hh[2 * c], md[2 * c], ll[2 * c]);
+                    a_im[c] = mfm3_combine(hh[2 * c + 1], md[2 * c + 1], ll[2 * c + 1]);
+                }
+                mfm3_round_pack2(a_re, a_im, fout);
             };
 
             if (first_of_chunk) {
@@ -464,9 +459,6 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 }
             }
 
-            /* The four column groups.  (Software pipelining them by one - the recombination of group g - 1 issued between
-             * the MFMAs of group g - was tried: the scheduler does not move inline asm between MFMAs, and written in
-             * plain C the recombination costs a third instruction per sum; it needs a hand-scheduled asm block.) */
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 uint32_t og[KQ];
@@ -490,14 +482,13 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             }
         }
 
-        /* The next image goes to the other buffer between the matrix phase and the epilogue; after the barrier nobody
-         * reads the current buffer any more.  (Measured against storing it at the very end of the tile, which gives the
-         * loads a whole tile to arrive: this order is 4 % faster.) */
+#ifdef MFM3_STAGE_EARLY
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
             stage_store(cur ^ 1u, j, pre[j]);
         }
         __syncthreads();
+#endif
         if (rb_valid) {
             const uint32_t ch0 = rb * 8u + 2u * kg;
             /* ---- one channel after the other (register pressure): derotation, discriminator, stores ---- */
@@ -589,6 +580,17 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 voff[c] += MFM_V3_OT * 2u;
             }
         }
+
+        /* The next image goes to the other buffer at the very end of the tile: its loads have had the whole tile to
+         * arrive (written before the epilogue, the wait for them - HBM latency with every workgroup asking at once -
+         * cost 12 % of the launch).  After the barrier nobody reads the current buffer any more. */
+#ifndef MFM3_STAGE_EARLY
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            stage_store(cur ^ 1u, j, pre[j]);
+        }
+        __syncthreads();
+#endif
 
         if (!n_valid) {
             break;

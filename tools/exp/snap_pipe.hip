@@ -25,17 +25,15 @@
  */
 #include <hip/hip_runtime.h>
 
-#include "mfm_kernel.h"
-#include "mfm_numerics.h"
+#include "../../tsl-sdr_amd/csrc/mfm_kernel.h"
+#include "../../tsl-sdr_amd/csrc/mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 
 #define MFM3_NT 512u
 #define MFM3_SCHED_ALL_BUT_VMEM 0x38F
 
-/* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 (left to itself the compiler makes it two shifts and a three-operand
- * add).  The accumulators come straight from MFMAs and the compiler does not pad the MFMA -> VALU read hazard for what it
- * cannot see inside inline asm: callers put 16 wait states between the last MFMA and this. */
+/* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 */
 static __device__ __forceinline__ uint32_t mfm3_combine(int hh, int md, int ll)
 {
     uint32_t t, a;
@@ -300,11 +298,20 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     }
     __syncthreads();
 
-    /* The second half of a workgroup loses the arbitration for the SIMD to the first (older) half on every phase and
-     * reaches each barrier ~1300 cycles later (s_memtime stamps, profiles/r02_v3_phases.txt): static priority for it. */
-    if (wave >= 4) {
-        __builtin_amdgcn_s_setprio(1);
+#ifdef MFM3_STAGGER
+    {
+        /* de-synchronise the workgroups: the two of a CU half a tile apart, CUs spread over a tile */
+        const uint32_t units = (((blockIdx.x >> 8) & 1u) * 4u + ((blockIdx.x >> 3) & 3u)) * MFM3_STAGGER;
+        for (uint32_t z = 0; z < units; z++) {
+            __builtin_amdgcn_s_sleep(64); /* 64 x 64 clocks */
+        }
     }
+#endif
+#ifdef MFM3_PRIO
+    if (wave >= 4) {
+        __builtin_amdgcn_s_setprio(MFM3_PRIO);
+    }
+#endif
     mfm_v4i a_h[KQ], a_l[KQ];
     /* 128 * sum(W) + 8192 of the wave's 16 rows: 64 bytes of LDS per wave (read back as the initial value of the low
      * accumulator of every column group; four registers that need not be live through the epilogue) */
@@ -464,40 +471,67 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 }
             }
 
-            /* The four column groups.  (Software pipelining them by one - the recombination of group g - 1 issued between
-             * the MFMAs of group g - was tried: the scheduler does not move inline asm between MFMAs, and written in
-             * plain C the recombination costs a third instruction per sum; it needs a hand-scheduled asm block.) */
+            /* The four column groups, software pipelined by one: the recombination of group g - 1 (12 VALU instructions)
+             * is issued between the matrix instructions of group g - two instructions between two MFMAs of a wave issue
+             * in the MFMA's shadow (profiles/r02_ubench_shadow.txt), and no accumulator is read right behind its MFMA. */
+            {
+                mfm_v4i accA[3], accB[3];
+                uint32_t og[4][KQ];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                uint32_t og[KQ];
+                for (int g = 0; g < 4; g++) {
 #pragma unroll
-                for (int kq = 0; kq < KQ; kq++) {
-                    og[kq] = ofs[g][kq];
-                }
-                column_group(og, f[g]);
-                if (g == 1) {
-                    /* rotator entries of this tile, four consecutive ones per channel: requested half-way through
-                     * the matrix phase (16 registers that need not be live before), needed behind it */
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
-                        rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
-                        rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+                    for (int kq = 0; kq < KQ; kq++) {
+                        og[g][kq] = ofs[g][kq];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                mfma_chain(og[0], accA);
+                mfma_chain(og[1], accB);
+                finish(accA, f[0]);
+#ifndef MFM3_NO_GROUPSCHED
+                for (int i = 0; i < 3 * KQ; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+#endif
+                /* rotator entries of this tile, four consecutive ones per channel: requested half-way through the matrix
+                 * phase (16 registers that need not be live before), needed behind it */
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
+                    rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
+                    rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chain(og[2], accA);
+                finish(accB, f[1]);
+#ifndef MFM3_NO_GROUPSCHED
+                for (int i = 0; i < 3 * KQ; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chain(og[3], accB);
+                finish(accA, f[2]);
+#ifndef MFM3_NO_GROUPSCHED
+                for (int i = 0; i < 3 * KQ; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+#endif
+                settle();
+                finish(accB, f[3]);
             }
         }
 
-        /* The next image goes to the other buffer between the matrix phase and the epilogue; after the barrier nobody
-         * reads the current buffer any more.  (Measured against storing it at the very end of the tile, which gives the
-         * loads a whole tile to arrive: this order is 4 % faster.) */
+#ifdef MFM3_STAGE_EARLY
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
             stage_store(cur ^ 1u, j, pre[j]);
         }
         __syncthreads();
+#endif
         if (rb_valid) {
             const uint32_t ch0 = rb * 8u + 2u * kg;
             /* ---- one channel after the other (register pressure): derotation, discriminator, stores ---- */
@@ -589,6 +623,17 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 voff[c] += MFM_V3_OT * 2u;
             }
         }
+
+        /* The next image goes to the other buffer at the very end of the tile: its loads have had the whole tile to
+         * arrive (written before the epilogue, the wait for them - HBM latency with every workgroup asking at once -
+         * cost 12 % of the launch).  After the barrier nobody reads the current buffer any more. */
+#ifndef MFM3_STAGE_EARLY
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            stage_store(cur ^ 1u, j, pre[j]);
+        }
+        __syncthreads();
+#endif
 
         if (!n_valid) {
             break;
