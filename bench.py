@@ -274,7 +274,7 @@ def main():
                                    f"decimation {decim}, fs {fs} Hz-shaped int16 IQ, block 2^{args.block_log2} samples",
                        "channels_per_gpu": cpg, "channels_total": total_ch, "block_samples": block,
                        "input_msamp_per_s": msamp,
-                       "parallelism": "1 GPU" if world == 1 else
+                       "parallelism": "1 GPU" if not use_dist else
                                       f"channel shards x{world} + RCCL {exchange.algo} of the IQ block"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -288,6 +288,14 @@ def main():
             "protocol": {"settle_seconds": args.settle_seconds, "settle_steps": settle_steps + 8,
                          "warmup_steps": args.warmup, "timed_steps": args.steps},
             "compute_roofline": compute_roof,
+            # N > 1: every step moves the whole block to each of the other N - 1 GPUs; the bench replays blocks as fast
+            # as the GPUs take them, so this - not the kernel - is what an N > 1 line is usually bound by (a live
+            # 2.4 MS/s stream is 10 MB/s).  xGMI: 7 links x ~153 GB/s per GPU, point to point.
+            "exchange": None if not use_dist else {
+                "algo": exchange.algo, "bytes_per_step_per_peer": block * 4, "peers": world - 1,
+                "delivered_GBps_per_peer": block * 4 / (dt / args.steps) / 1e9,
+                "delivered_GBps_total": block * 4 * (world - 1) / (dt / args.steps) / 1e9,
+                "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7},
             "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],
                          "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"]},
         }

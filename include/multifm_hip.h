@@ -185,6 +185,58 @@ const char *mfm_strerror(int err);
 const char *mfm_last_error(void); /* thread-local detail of the last failure */
 
 /*
+ * ---- one channel set on several GPUs of a node (SURVEY.md section 8b "set_devices", section 8e) -----------------
+ * The reference fans every delivered sample_buf out to all channel threads (multifm/receiver.c:78-98).  A device
+ * group does the same across GPUs: channels are cut into contiguous shards (mfm_shard_range), one engine per device;
+ * mfm_group_push() stages a block on the first device and broadcasts it with RCCL (ncclBroadcast over xGMI, in place
+ * into every other engine's input buffer), then every engine runs its shard.  No other exchange.  Blocks come back per
+ * shard: mfm_group_fetch() fills one mfm_block per shard, all for the same stream position; channel c of the group is
+ * row c - first_channel of its shard's block (mfm_group_shard_info).  One host thread at a time may push, another one
+ * fetch/release (as for a single engine).  RCCL (librccl.so) is loaded at run time, and only by groups that exchange.
+ */
+#define MFM_GROUP_MAX_DEVICES 16
+#define MFM_X_AUTO 0u /* one device: direct staging, no RCCL; several: RCCL broadcast */
+#define MFM_X_RCCL 1u /* always through the RCCL broadcast path (exercises the call sequence on a one-GPU box) */
+
+struct mfm_group_config {
+    uint32_t abi_version;       /* MFM_ABI_VERSION */
+    uint32_t nr_devices;        /* 1..MFM_GROUP_MAX_DEVICES; devices beyond the channel count stay idle */
+    int32_t devices[MFM_GROUP_MAX_DEVICES]; /* HIP device ordinals; devices[0] ingests and is the broadcast root */
+    uint32_t sample_rate_hz;
+    uint32_t decimation;
+    uint32_t max_block_samples;
+    uint32_t flags;             /* MFM_F_* handed to every engine (MFM_F_DEVICE_ONLY is not valid here) */
+    uint32_t exchange;          /* MFM_X_* */
+};
+
+struct mfm_group; /* opaque */
+
+/* channels [first, first + count) of nr_channels belong to shard `shard` of nr_shards: contiguous ranges whose sizes
+ * differ by at most one (empty only when there are fewer channels than shards).  Pure function. */
+void mfm_shard_range(uint32_t nr_channels, uint32_t nr_shards, uint32_t shard, uint32_t *first, uint32_t *count);
+
+int mfm_group_create(struct mfm_group **pg, const struct mfm_group_config *cfg);
+void mfm_group_destroy(struct mfm_group **pg);
+/* as mfm_engine_add_channel(); returns the channel's index in the group */
+int mfm_group_add_channel(struct mfm_group *g, int32_t offset_hz, const double *lpf_taps, size_t nr_taps, double channel_gain,
+                          int want_iq);
+/* cut the shards, create and commit one engine per non-empty shard, set up the RCCL communicators */
+int mfm_group_commit(struct mfm_group *g);
+int mfm_group_nr_shards(struct mfm_group *g); /* >= 1 after commit */
+int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_channel, uint32_t *nr_channels, int32_t *device);
+/* host ingest of one block in any MFM_IN_* format.  MFM_E_BUSY when a shard's output ring is full (nothing was
+ * staged: fetch/release and retry). */
+int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format);
+/* oldest finished block of every shard into blks[0 .. nr_shards); MFM_E_DONE when nothing is pending */
+int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks);
+int mfm_group_release(struct mfm_group *g);
+int mfm_group_sync(struct mfm_group *g);
+int mfm_group_get_stats(struct mfm_group *g, uint32_t shard, struct mfm_stats *st);
+/* whether blocks travel through RCCL, how many blocks were pushed through it and how many bytes it moved to
+ * non-root devices */
+int mfm_group_exchange_info(struct mfm_group *g, int *uses_rccl, uint64_t *blocks, uint64_t *bytes_exchanged);
+
+/*
  * ---- PCM stage behind the FIFO -------------------------------------------
  * The decoder / resampler processes read a channel's PCM FIFO and run it through a real-valued rational
  * resampler and an optional DC blocker before the protocol decoders (decoder/decoder.c:580-673):

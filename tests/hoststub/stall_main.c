@@ -1,0 +1,88 @@
+/* Drives the receiver (tsl-sdr_amd/host/mfm_receiver.c) on the test double of the device group: a front end that keeps
+ * delivering while the device side is stalled.  Prints one JSON line of what happened. */
+#include "mfm_receiver.h"
+
+#include <fcntl.h>
+#include <stdio.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+void stub_set_busy(int busy);
+unsigned long stub_pushed(void);
+unsigned long stub_samples(void);
+unsigned long stub_busy_returns(void);
+
+static aresult_t rx_func(struct receiver *rx) { (void)rx; return A_OK; }
+static aresult_t cleanup_func(struct receiver *rx) { (void)rx; return A_OK; }
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        return 2;
+    }
+    const char *fifo = argv[1]; /* a plain file: opens without a reader */
+    char json[1024];
+    snprintf(json, sizeof(json),
+             "{\"nrSampBufs\": 8, \"sampleRateHz\": 1000000, \"centerFreqHz\": 100000000, \"decimationFactor\": 4,"
+             " \"lpfTaps\": [0.25, 0.25, 0.25, 0.25], \"channels\": [{\"outFifo\": \"%s\", \"chanCenterFreq\": 100010000}]}",
+             fifo);
+    struct config *cfg = NULL;
+    struct receiver rx, *prx = &rx;
+    if (FAILED(config_new(&cfg)) || FAILED(config_add_string(cfg, json))) {
+        return 3;
+    }
+    const size_t spb = 4096;
+    if (FAILED(receiver_init(&rx, cfg, rx_func, cleanup_func, spb)) || FAILED(receiver_start(&rx))) {
+        return 4;
+    }
+    /* phase 1: the device side is stalled; the front end tries to deliver 40 buffers as fast as it can */
+    stub_set_busy(1);
+    unsigned delivered = 0, dropped = 0;
+    uint64_t worst_alloc_ns = 0;
+    for (int i = 0; i < 40; i++) {
+        struct sample_buf *sb = NULL;
+        const uint64_t t0 = tsl_get_clock_monotonic();
+        aresult_t r = receiver_sample_buf_alloc(&rx, &sb);
+        const uint64_t dt = tsl_get_clock_monotonic() - t0;
+        worst_alloc_ns = dt > worst_alloc_ns ? dt : worst_alloc_ns;
+        if (FAILED(r)) {
+            dropped++; /* the reference's policy: the samples of this read are lost, counted (receiver.c:57-63) */
+            continue;
+        }
+        memset(sb->data_buf, 0, spb * 4);
+        sb->nr_samples = (uint32_t)spb;
+        if (FAILED(receiver_sample_buf_deliver(&rx, sb))) {
+            return 5;
+        }
+        delivered++;
+    }
+    usleep(20000); /* let the submit thread meet the stalled device */
+    const unsigned long pushed_while_stalled = stub_pushed();
+    const size_t alloc_fails_stalled = rx.nr_samp_buf_alloc_fails;
+    const uint64_t worst_deliver_stalled = rx.max_deliver_ns;
+    /* phase 2: the device side recovers; everything queued goes through, the pool refills */
+    stub_set_busy(0);
+    if (FAILED(receiver_drain(&rx))) {
+        return 6;
+    }
+    struct sample_buf *sb = NULL;
+    const int pool_back = !FAILED(receiver_sample_buf_alloc(&rx, &sb));
+    if (pool_back) {
+        sb->nr_samples = (uint32_t)spb;
+        memset(sb->data_buf, 0, spb * 4);
+        if (FAILED(receiver_sample_buf_deliver(&rx, sb)) || FAILED(receiver_drain(&rx))) {
+            return 7;
+        }
+        delivered++;
+    }
+    printf("{\"delivered\": %u, \"dropped\": %u, \"alloc_fails\": %zu, \"pushed_while_stalled\": %lu, \"pushed\": %lu, "
+           "\"samples\": %lu, \"busy_returns\": %lu, \"worst_deliver_ns_stalled\": %llu, \"worst_alloc_ns\": %llu, "
+           "\"pool_back\": %d}\n",
+           delivered, dropped, alloc_fails_stalled, pushed_while_stalled, stub_pushed(), stub_samples(), stub_busy_returns(),
+           (unsigned long long)worst_deliver_stalled, (unsigned long long)worst_alloc_ns, pool_back);
+    if (FAILED(receiver_cleanup(&prx))) {
+        return 8;
+    }
+    config_delete(&cfg);
+    return 0;
+}

@@ -1,0 +1,150 @@
+"""The device group (mfm_group_*): one channel set on several GPUs behind the C ABI (SURVEY.md section 8b "set_devices",
+section 8e).  Shard arithmetic and argument checks on the CPU; on the GPU box (one device) the group is run through both
+of its ingest paths - direct staging, and the RCCL path a multi-GPU group uses (ncclCommInitAll, in-place ncclBroadcast
+into the engines' input buffers, submit ordered behind it) - and compared with the oracle."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_tile_the_channel_set_like_the_python_side(pkg):
+    for n in (1, 2, 63, 64, 65, 1000, 1024, 2048):
+        for g in (1, 2, 3, 4, 8, 16):
+            got = []
+            for s in range(g):
+                lo, cnt = pkg.binding.shard_range(n, g, s)
+                assert n // g <= cnt <= -(-n // g)
+                got.extend(range(lo, lo + cnt))
+                # the C host and bench.py (torch.distributed ranks) must agree on who owns which channel
+                assert (lo, lo + cnt) == tuple(pkg.dist.shard_range(n, s, g))
+            assert got == list(range(n))
+
+
+def test_group_argument_checks(pkg):
+    b = pkg.binding
+    lib = pkg.load_library()
+    for devices, ok in (((), False), ((0, 0), False), (tuple(range(17)), False)):
+        cfg = b.GroupConfig()
+        cfg.abi_version = b.MFM_ABI_VERSION
+        cfg.nr_devices = len(devices)
+        for i, d in enumerate(devices[:16]):
+            cfg.devices[i] = d
+        cfg.sample_rate_hz, cfg.decimation, cfg.max_block_samples = 1000000, 40, 4096
+        h = C.c_void_p()
+        assert (lib.mfm_group_create(C.byref(h), C.byref(cfg)) == 0) == ok
+    with pytest.raises(b.MfmError):
+        b.Group(1000000, 40, 4096, devices=(0,), flags=b.MFM_F_DEVICE_ONLY)
+    g = b.Group(1000000, 40, 4096, devices=(0, 1))
+    with pytest.raises(b.MfmError):
+        g.add_channel(1000, np.ones(8))          # taps < decimation: rejected like the engine does
+    with pytest.raises(b.MfmError):
+        g.commit()                               # no channels
+    g.close()
+
+
+def _drive(grp, iq, block, pkg):
+    parts, pos = [], 0
+    while pos < len(iq):
+        m = min(block, len(iq) - pos)
+        rc = grp.push(iq[pos:pos + m])
+        if rc == pkg.binding.MFM_E_BUSY:
+            parts.append(grp.fetch()[1])
+            continue
+        pos += m
+    grp.sync()
+    while True:
+        got = grp.fetch()
+        if got is None:
+            break
+        parts.append(got[1])
+    return np.concatenate(parts, axis=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["direct", "rccl"])
+def test_group_on_one_device_matches_oracle(pkg, ora, exchange):
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=70)
+    iq = pkg.synth.synth_iq(96 * 3000 + 321, fs, offs[:4], seed=7)
+    b = pkg.binding
+    grp = b.Group(fs, decim, 1 << 16, devices=(0,), exchange=b.MFM_X_RCCL if exchange == "rccl" else b.MFM_X_AUTO)
+    for o, g in zip(offs, gains):
+        grp.add_channel(int(o), taps, float(g))
+    grp.commit()
+    assert grp.nr_shards == 1 and grp.shard_info(0) == (0, 70, 0)
+    pcm = _drive(grp, iq, 50000, pkg)
+    uses, blocks, moved = grp.exchange_info()
+    grp.close()
+    assert uses == (exchange == "rccl") and (blocks > 0) == uses and moved == 0  # one device: nothing leaves it
+    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
+    assert pcm.shape == ref.shape and np.array_equal(pcm, ref)
+
+
+@pytest.mark.gpu
+def test_group_with_more_devices_than_the_box_has_fails_cleanly(pkg):
+    import torch
+    n = torch.cuda.device_count()
+    g = pkg.binding.Group(1000000, 40, 4096, devices=tuple(range(n + 1)))
+    for k in range(n + 1):
+        g.add_channel(1000 * k, np.ones(64) / 64)
+    with pytest.raises(pkg.binding.MfmError) as ei:
+        g.commit()
+    assert ei.value.code == pkg.binding.MFM_E_DEVICE
+    g.close()
+
+
+@pytest.mark.gpu
+def test_multifm_driver_through_the_rccl_exchange(tmp_path, pkg, ora):
+    """multifm_amd with "gpuDevices": [0] and "gpuExchange": "rccl": the C host's multi-device ingest path (submit
+    thread -> mfm_group_push -> stage on the root, ncclBroadcast, submit) on the one GPU of the box; FIFO byte streams
+    must be the oracle's PCM."""
+    fs, decim, center = 1000000, 40, 929500000
+    offs = [112500, -200000, 3125]
+    taps_file = os.path.join(ROOT, "etc", "lpf_25khz_1000k_128.json")
+    taps = np.array(json.load(open(taps_file))["lpfTaps"])
+    n = 4096 * 21 + 77
+    iq = pkg.synth.synth_iq(n, fs, offs, seed=5)
+    cap = tmp_path / "cap.bin"
+    cap.write_bytes(iq.tobytes())
+    cfg = {"device": {"type": "file", "filename": str(cap), "fileFormat": "cs16"}, "sampleRateHz": fs, "centerFreqHz": center,
+           "nrSampBufs": 16, "decimationFactor": decim, "gpuDevices": [0], "gpuExchange": "rccl", "channels": []}
+    outs = []
+    for i, f in enumerate(offs):
+        o = tmp_path / f"ch{i}.pcm"
+        o.write_bytes(b"")
+        cfg["channels"].append({"outFifo": str(o), "chanCenterFreq": int(center + f)})
+        outs.append(o)
+    cj = tmp_path / "cfg.json"
+    cj.write_text(json.dumps(cfg))
+    exe = os.path.join(ROOT, "tsl-sdr_amd", "host", "multifm_amd")
+    r = subprocess.run([exe, str(cj), taps_file], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RCCL exchange forced" in r.stderr
+    cre = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[0] for o in offs])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[1] for o in offs])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    for i, o in enumerate(outs):
+        got = np.frombuffer(o.read_bytes(), dtype=np.int16)
+        assert np.array_equal(got, ref[i]), i
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_distributed_path_on_one_rank(pkg):
+    """bench.py with BENCH_FORCE_DIST=1: process group on RCCL, in-place broadcast of the block into the engine's
+    input buffer, submit behind it - the N > 1 code path of the bench on the one GPU of the box."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--settle-seconds", "0", "--no-cpu-baseline", "--no-fp32", "--block-log2", "22"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]

@@ -34,6 +34,9 @@ ABI_SYMBOLS = [
     "mfm_pocsag_fetch_events", "mfm_bch3121_decode_device", "mfm_bch3121_decode_host", "mfm_hosttwin_bch3121_decode",
     "mfm_f32_create", "mfm_f32_add_channel", "mfm_f32_commit", "mfm_f32_destroy", "mfm_f32_max_out",
     "mfm_f32_process_device", "mfm_f32_process_host",
+    "mfm_shard_range", "mfm_group_create", "mfm_group_destroy", "mfm_group_add_channel", "mfm_group_commit",
+    "mfm_group_nr_shards", "mfm_group_shard_info", "mfm_group_push", "mfm_group_fetch", "mfm_group_release",
+    "mfm_group_sync", "mfm_group_get_stats", "mfm_group_exchange_info",
     "mfm_mm_create", "mfm_mm_destroy", "mfm_mm_max_decisions", "mfm_mm_process_device", "mfm_mm_process_host",
 ]
 
@@ -50,6 +53,15 @@ class EngineConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("sample_rate_hz", C.c_uint32),
                 ("decimation", C.c_uint32), ("max_block_samples", C.c_uint32), ("flags", C.c_uint32),
                 ("ext_input", C.c_void_p * 2)]
+
+
+class GroupConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("nr_devices", C.c_uint32), ("devices", C.c_int32 * 16),
+                ("sample_rate_hz", C.c_uint32), ("decimation", C.c_uint32), ("max_block_samples", C.c_uint32),
+                ("flags", C.c_uint32), ("exchange", C.c_uint32)]
+
+
+MFM_X_AUTO, MFM_X_RCCL = 0, 1
 
 
 class Block(C.Structure):
@@ -140,6 +152,21 @@ def load_library():
     lib.mfm_engine_reset.argtypes = [vp]
     lib.mfm_engine_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.mfm_engine_stream.argtypes = [vp]
+    lib.mfm_shard_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mfm_shard_range.restype = None
+    lib.mfm_group_create.argtypes = [C.POINTER(vp), C.POINTER(GroupConfig)]
+    lib.mfm_group_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_group_destroy.restype = None
+    lib.mfm_group_add_channel.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_size_t, C.c_double, C.c_int]
+    lib.mfm_group_commit.argtypes = [vp]
+    lib.mfm_group_nr_shards.argtypes = [vp]
+    lib.mfm_group_shard_info.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+    lib.mfm_group_push.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    lib.mfm_group_fetch.argtypes = [vp, C.POINTER(Block)]
+    lib.mfm_group_release.argtypes = [vp]
+    lib.mfm_group_sync.argtypes = [vp]
+    lib.mfm_group_get_stats.argtypes = [vp, C.c_uint32, C.POINTER(Stats)]
+    lib.mfm_group_exchange_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.mfm_engine_get_launch_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
     lib.mfm_engine_get_launch_ms.restype = C.c_size_t
     lib.mfm_engine_stream.restype = vp
@@ -366,6 +393,97 @@ class Engine:
     @property
     def stream(self):
         return self.lib.mfm_engine_stream(self.h)
+
+
+def shard_range(nr_channels, nr_shards, shard):
+    """mfm_shard_range: (first, count) of a shard's contiguous channel range."""
+    lib = load_library()
+    lo, n = C.c_uint32(), C.c_uint32()
+    lib.mfm_shard_range(nr_channels, nr_shards, shard, C.byref(lo), C.byref(n))
+    return lo.value, n.value
+
+
+class Group:
+    """mfm_group_*: one channel set on several devices of a node (RCCL broadcast of every block)."""
+
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, devices=(0,), flags=0, exchange=MFM_X_AUTO):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = GroupConfig()
+        cfg.abi_version = MFM_ABI_VERSION
+        cfg.nr_devices = len(devices)
+        for i, d in enumerate(devices):
+            cfg.devices[i] = d
+        cfg.sample_rate_hz, cfg.decimation, cfg.max_block_samples = sample_rate_hz, decimation, max_block_samples
+        cfg.flags, cfg.exchange = flags, exchange
+        rc = self.lib.mfm_group_create(C.byref(self.h), C.byref(cfg))
+        if rc < 0:
+            raise MfmError(rc, "mfm_group_create", self.lib.mfm_last_error().decode())
+        self.nr_channels = 0
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise MfmError(rc, what, self.lib.mfm_last_error().decode() or self.lib.mfm_strerror(rc).decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_group_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_channel(self, offset_hz, lpf_taps, gain=1.0, want_iq=False):
+        t = np.ascontiguousarray(lpf_taps, dtype=np.float64)
+        self.nr_channels += 1
+        return self._chk(self.lib.mfm_group_add_channel(self.h, int(offset_hz), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        t.size, float(gain), int(want_iq)), "mfm_group_add_channel")
+
+    def commit(self):
+        self._chk(self.lib.mfm_group_commit(self.h), "mfm_group_commit")
+        self.nr_shards = self._chk(self.lib.mfm_group_nr_shards(self.h), "mfm_group_nr_shards")
+
+    def shard_info(self, shard):
+        lo, n, dev = C.c_uint32(), C.c_uint32(), C.c_int32()
+        self._chk(self.lib.mfm_group_shard_info(self.h, shard, C.byref(lo), C.byref(n), C.byref(dev)), "mfm_group_shard_info")
+        return lo.value, n.value, dev.value
+
+    def push(self, data, fmt=MFM_IN_CS16):
+        """returns 0 or MFM_E_BUSY; data: int16 [n, 2] (cs16) or uint8 [n, 2]"""
+        a = np.ascontiguousarray(data)
+        rc = self.lib.mfm_group_push(self.h, a.ctypes.data, a.shape[0], fmt)
+        if rc == MFM_E_BUSY:
+            return rc
+        return self._chk(rc, "mfm_group_push")
+
+    def fetch(self):
+        """oldest finished block of all shards as one [nr_channels, n] array, or None"""
+        blks = (Block * self.nr_shards)()
+        rc = self.lib.mfm_group_fetch(self.h, blks)
+        if rc == MFM_E_DONE:
+            return None
+        self._chk(rc, "mfm_group_fetch")
+        parts = []
+        for s in range(self.nr_shards):
+            _, n, _ = self.shard_info(s)
+            b = blks[s]
+            arr = np.ctypeslib.as_array(b.pcm, shape=(n, b.stride))[:, :b.nr_outputs].copy()
+            parts.append(arr)
+        first = blks[0].first_output
+        self._chk(self.lib.mfm_group_release(self.h), "mfm_group_release")
+        return first, np.concatenate(parts, axis=0)
+
+    def sync(self):
+        self._chk(self.lib.mfm_group_sync(self.h), "mfm_group_sync")
+
+    def exchange_info(self):
+        u, b, x = C.c_int(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.mfm_group_exchange_info(self.h, C.byref(u), C.byref(b), C.byref(x)), "mfm_group_exchange_info")
+        return bool(u.value), b.value, x.value
 
 
 class Resampler:

@@ -25,6 +25,7 @@
 #include "mfm_kernel.h"
 #include "mfm_numerics.h"
 #include "mfm_taps.h"
+#include "mfm_engine_internal.h"
 
 extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, int dbg_iq, uint32_t lds_bytes,
                                                 hipStream_t stream);
@@ -33,13 +34,6 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, uint32_t lds_bytes, uint32_t grid,
                                                    hipStream_t stream);
 
-#if defined(MFM_TRACE)
-static unsigned long long *g_trace_dev = nullptr;
-extern "C" int mfm_trace_read(unsigned long long *dst)
-{
-    return (g_trace_dev && hipMemcpy(dst, g_trace_dev, 64 * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess) ? 0 : -1;
-}
-#endif
 
 namespace {
 
@@ -1123,17 +1117,6 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.lut = e->d_lut;
             M.pcm = slot->d_pcm;
             M.iq_dbg = L.iq_dbg;
-#if defined(MFM_TRACE)
-            {
-                static unsigned long long *d_trace = nullptr;
-                if (!d_trace) {
-                    HIP_TRY(hipMalloc(&d_trace, 64 * 128 * 8));
-                }
-                HIP_TRY(hipMemsetAsync(d_trace, 0, 64 * 128 * 8, e->s_compute));
-                M.trace = d_trace;
-                g_trace_dev = d_trace;
-            }
-#endif
             const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_per_cu);
             HIP_TRY(mfm_launch_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, e->m_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */
@@ -1197,18 +1180,10 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
     return MFM_OK;
 }
 
-int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
+/* would a block of nr_samples find a free output slot?  (refused before anything is staged, so a caller can drain
+ * and retry) */
+static int check_output_room(struct mfm_engine *e, size_t nr_samples)
 {
-    if (!e || !iq) {
-        return fail(MFM_E_INVAL, "NULL argument");
-    }
-    if (!e->committed) {
-        return fail(MFM_E_STATE, "commit first");
-    }
-    if (0 == nr_samples || nr_samples > e->cfg.max_block_samples) {
-        return fail(MFM_E_INVAL, "block of %zu samples (max %u)", nr_samples, e->cfg.max_block_samples);
-    }
-    /* refuse before staging anything if the output ring is full, so a caller can drain and retry */
     if (!(e->cfg.flags & MFM_F_DEVICE_ONLY)) {
         std::lock_guard<std::mutex> guard(e->mu);
         const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
@@ -1216,31 +1191,21 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
             return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
         }
     }
-    void *dst = nullptr;
-    size_t cap = 0;
-    int rc = mfm_engine_acquire_input(e, &dst, &cap);
-    if (rc != MFM_OK) {
-        return rc;
-    }
-    const int cur = e->cur_in;
-    if (!e->h_in[cur]) {
-        HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cfg.max_block_samples * 4, hipHostMallocDefault));
-    }
-    /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
-    memcpy(e->h_in[cur], iq, nr_samples * 4);
-    HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
-    return mfm_engine_submit(e, nr_samples, e->s_in, 1);
+    return MFM_OK;
 }
 
-int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format)
+/*
+ * Host -> device staging of one block WITHOUT submitting it (mfm_engine_internal.h): the samples (int16 pairs, or
+ * 8-bit pairs widened on the device exactly as the reference's front ends widen them on the host) are placed where
+ * the next submit() expects them, by work queued on the engine's copy stream.  *d_dst is that device address - what a
+ * device group broadcasts to its other members before every member submits.
+ */
+int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, int format, void **d_dst)
 {
-    if (!e || !bytes) {
+    if (!e || !data) {
         return fail(MFM_E_INVAL, "NULL argument");
     }
-    if (format == MFM_IN_CS16) {
-        return mfm_engine_push(e, static_cast<const int16_t *>(bytes), nr_samples);
-    }
-    if (format != MFM_IN_CS8 && format != MFM_IN_CU8 && format != MFM_IN_RTLSDR_U8) {
+    if (format != MFM_IN_CS16 && format != MFM_IN_CS8 && format != MFM_IN_CU8 && format != MFM_IN_RTLSDR_U8) {
         return fail(MFM_E_INVAL, "unknown sample format %d", format);
     }
     if (!e->committed) {
@@ -1249,16 +1214,13 @@ int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_sam
     if (0 == nr_samples || nr_samples > e->cfg.max_block_samples) {
         return fail(MFM_E_INVAL, "block of %zu samples (max %u)", nr_samples, e->cfg.max_block_samples);
     }
-    if (!(e->cfg.flags & MFM_F_DEVICE_ONLY)) {
-        std::lock_guard<std::mutex> guard(e->mu);
-        const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
-        if (n_avail >= e->nr_taps && e->slots[e->submit_seq % e->nslots].state != OutSlot::FREE) {
-            return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
-        }
+    int rc = check_output_room(e, nr_samples);
+    if (rc != MFM_OK) {
+        return rc;
     }
     void *dst = nullptr;
     size_t cap = 0;
-    int rc = mfm_engine_acquire_input(e, &dst, &cap);
+    rc = mfm_engine_acquire_input(e, &dst, &cap);
     if (rc != MFM_OK) {
         return rc;
     }
@@ -1266,19 +1228,52 @@ int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_sam
     if (!e->h_in[cur]) {
         HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cfg.max_block_samples * 4, hipHostMallocDefault));
     }
-    if (!e->d_raw[cur]) {
-        HIP_TRY(hipMalloc(&e->d_raw[cur], (size_t)e->cfg.max_block_samples * 2 + 16));
+    /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
+    if (format == MFM_IN_CS16) {
+        memcpy(e->h_in[cur], data, nr_samples * 4);
+        HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
+    } else {
+        if (!e->d_raw[cur]) {
+            HIP_TRY(hipMalloc(&e->d_raw[cur], (size_t)e->cfg.max_block_samples * 2 + 16));
+        }
+        /* the unpack kernel of the previous use of d_raw[cur] ran before the kernel acquire_input() waited for */
+        memcpy(e->h_in[cur], data, nr_samples * 2);
+        HIP_TRY(hipMemcpyAsync(e->d_raw[cur], e->h_in[cur], nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
+        uint32_t blocks = (uint32_t)((nr_samples / 8 + 255) / 256);
+        blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+        hipLaunchKernelGGL(mfm_unpack_kernel, dim3(blocks), dim3(256), 0, e->s_in, e->d_raw[cur],
+                           static_cast<uint32_t *>(dst), (uint32_t)nr_samples, format);
+        HIP_TRY(hipGetLastError());
     }
-    /* acquire_input() waited for the kernel that consumed this pair; the unpack kernel of the previous use of
-     * d_raw[cur] ran before that kernel on the same stream order */
-    memcpy(e->h_in[cur], bytes, nr_samples * 2);
-    HIP_TRY(hipMemcpyAsync(e->d_raw[cur], e->h_in[cur], nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
-    uint32_t blocks = (uint32_t)((nr_samples / 8 + 255) / 256);
-    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-    hipLaunchKernelGGL(mfm_unpack_kernel, dim3(blocks), dim3(256), 0, e->s_in, e->d_raw[cur], static_cast<uint32_t *>(dst),
-                       (uint32_t)nr_samples, format);
-    HIP_TRY(hipGetLastError());
-    return mfm_engine_submit(e, nr_samples, e->s_in, 1);
+    if (d_dst) {
+        *d_dst = dst;
+    }
+    return MFM_OK;
+}
+
+void *mfm_engine_copy_stream(struct mfm_engine *e)
+{
+    return (e && e->committed) ? e->s_in : nullptr;
+}
+
+int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples)
+{
+    if (!e || !e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    return check_output_room(e, nr_samples);
+}
+
+int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
+{
+    const int rc = mfm_engine_stage(e, iq, nr_samples, MFM_IN_CS16, nullptr);
+    return rc != MFM_OK ? rc : mfm_engine_submit(e, nr_samples, e->s_in, 1);
+}
+
+int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format)
+{
+    const int rc = mfm_engine_stage(e, bytes, nr_samples, format, nullptr);
+    return rc != MFM_OK ? rc : mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 
 int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk)

@@ -1,0 +1,21 @@
+/*
+ * mfm_engine_internal.h - engine entry points used by other translation units of libmultifm_hip.so (the device
+ * group, mfm_group.hip).  Not part of the public C ABI (include/multifm_hip.h); hidden visibility.
+ */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+struct mfm_engine;
+
+extern "C" {
+/* stage one block (MFM_IN_* format) into the engine's next input buffer on its copy stream, without submitting;
+ * MFM_E_BUSY when the output ring has no free slot for it.  *d_dst = device address of the staged samples. */
+__attribute__((visibility("hidden"))) int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples,
+                                                           int format, void **d_dst);
+/* the stream mfm_engine_stage() queues its work on (hipStream_t) */
+__attribute__((visibility("hidden"))) void *mfm_engine_copy_stream(struct mfm_engine *e);
+/* MFM_OK when a block of nr_samples would find a free output slot, MFM_E_BUSY otherwise */
+__attribute__((visibility("hidden"))) int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples);
+}

@@ -1,0 +1,464 @@
+/*
+ * mfm_group.hip - one channel set on several MI355X GPUs of one node, behind the C ABI (include/multifm_hip.h,
+ * mfm_group_*).
+ *
+ * The reference fans every delivered sample_buf out to all of its channel threads (multifm/receiver.c:78-98): the
+ * channels are independent given the same wideband input.  Here the channel set is cut into contiguous shards, one
+ * mfm_engine per device; a delivered block is staged on the first device (H2D, 8-bit formats widened there) and
+ * broadcast with RCCL - ncclBroadcast over xGMI, in place into every other engine's input buffer - and then every
+ * engine submits it.  No other exchange: each device copies its own PCM back, the caller demultiplexes by shard
+ * (SURVEY.md section 8e).  One process, one host thread drives all devices (ncclCommInitAll + ncclGroupStart/End).
+ *
+ * RCCL is loaded at run time (dlopen "librccl.so"), and only when a group really exchanges: a single-device group
+ * stages and submits directly and never touches it.  MFM_X_RCCL forces the exchange path for a single device too, so
+ * that the RCCL call sequence can be exercised on a one-GPU box.
+ */
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/multifm_hip.h"
+#include "mfm_engine_internal.h"
+
+extern "C" __attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *msg);
+
+namespace {
+
+int gfail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    mfm_internal_set_error(buf);
+    return code;
+}
+
+/* the slice of the RCCL API used here (rccl.h: ncclResult_t / ncclComm_t / ncclDataType_t are int / pointer / int) */
+typedef void *nccl_comm_t;
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(nccl_comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt8 = 0; /* rccl.h: ncclInt8 = ncclChar = 0 */
+
+int load_rccl(RcclApi *api)
+{
+    if (api->lib) {
+        return MFM_OK;
+    }
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!h) {
+        return gfail(MFM_E_DEVICE, "cannot load librccl.so (%s): a device group of more than one GPU needs RCCL", dlerror());
+    }
+    api->CommInitAll = reinterpret_cast<decltype(api->CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api->Broadcast = reinterpret_cast<decltype(api->Broadcast)>(dlsym(h, "ncclBroadcast"));
+    api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(dlsym(h, "ncclGroupStart"));
+    api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!api->CommInitAll || !api->CommDestroy || !api->Broadcast || !api->GroupStart || !api->GroupEnd) {
+        dlclose(h);
+        return gfail(MFM_E_DEVICE, "librccl.so lacks a required entry point");
+    }
+    api->lib = h;
+    return MFM_OK;
+}
+
+struct ChanDesc {
+    int32_t offset_hz;
+    std::vector<double> taps;
+    double gain;
+    int want_iq;
+};
+
+} /* namespace */
+
+struct mfm_group {
+    mfm_group_config cfg{};
+    std::vector<ChanDesc> chans;
+    std::vector<mfm_engine *> eng; /* one per shard (shards with channels only) */
+    std::vector<int> dev;
+    std::vector<uint32_t> first, count;
+    bool committed = false;
+    bool exchange = false; /* blocks travel through RCCL */
+    RcclApi rccl;
+    std::vector<nccl_comm_t> comm;
+    std::vector<hipStream_t> xs; /* exchange stream per shard (shard 0: the root engine's copy stream) */
+    uint64_t blocks = 0, bytes_exchanged = 0;
+};
+
+extern "C" {
+
+void mfm_shard_range(uint32_t nr_channels, uint32_t nr_shards, uint32_t shard, uint32_t *first, uint32_t *count)
+{
+    /* contiguous ranges whose sizes differ by at most one (any contiguous partition is valid);
+     * the same rule as tsl-sdr_amd/dist.py shard_range(), which bench.py's ranks use.  Shards are empty only when
+     * there are fewer channels than shards. */
+    uint32_t lo = 0, hi = 0;
+    if (nr_shards && shard < nr_shards) {
+        const uint32_t base = nr_channels / nr_shards, extra = nr_channels % nr_shards;
+        lo = shard * base + (shard < extra ? shard : extra);
+        hi = lo + base + (shard < extra ? 1u : 0u);
+    }
+    if (first) {
+        *first = lo;
+    }
+    if (count) {
+        *count = hi - lo;
+    }
+}
+
+int mfm_group_create(struct mfm_group **pg, const struct mfm_group_config *cfg)
+{
+    if (!pg || !cfg) {
+        return gfail(MFM_E_INVAL, "NULL argument");
+    }
+    *pg = nullptr;
+    if (cfg->abi_version != MFM_ABI_VERSION) {
+        return gfail(MFM_E_INVAL, "ABI version %u, library is %u", cfg->abi_version, MFM_ABI_VERSION);
+    }
+    if (cfg->nr_devices < 1 || cfg->nr_devices > MFM_GROUP_MAX_DEVICES) {
+        return gfail(MFM_E_INVAL, "a device group has 1..%d devices, not %u", MFM_GROUP_MAX_DEVICES, cfg->nr_devices);
+    }
+    for (uint32_t i = 0; i < cfg->nr_devices; i++) {
+        for (uint32_t j = 0; j < i; j++) {
+            if (cfg->devices[i] == cfg->devices[j]) {
+                return gfail(MFM_E_INVAL, "device %d listed twice", cfg->devices[i]);
+            }
+        }
+    }
+    if (0 == cfg->decimation || 0 == cfg->sample_rate_hz || 0 == cfg->max_block_samples) {
+        return gfail(MFM_E_INVAL, "decimation, sample rate and max block must be non-zero");
+    }
+    if (cfg->flags & MFM_F_DEVICE_ONLY) {
+        return gfail(MFM_E_INVAL, "a device group delivers its blocks through mfm_group_fetch(): MFM_F_DEVICE_ONLY is not valid");
+    }
+    mfm_group *g = new (std::nothrow) mfm_group();
+    if (!g) {
+        return gfail(MFM_E_NOMEM, "group allocation failed");
+    }
+    g->cfg = *cfg;
+    *pg = g;
+    return MFM_OK;
+}
+
+static void group_release(mfm_group *g)
+{
+    for (size_t i = 0; i < g->eng.size(); i++) {
+        if (g->eng[i]) {
+            (void)mfm_engine_sync(g->eng[i]);
+        }
+    }
+    for (size_t i = 0; i < g->comm.size(); i++) {
+        if (g->comm[i] && g->rccl.CommDestroy) {
+            (void)hipSetDevice(g->dev[i]);
+            (void)g->rccl.CommDestroy(g->comm[i]);
+        }
+    }
+    g->comm.clear();
+    for (size_t i = 1; i < g->xs.size(); i++) { /* xs[0] belongs to the root engine */
+        if (g->xs[i]) {
+            (void)hipSetDevice(g->dev[i]);
+            (void)hipStreamDestroy(g->xs[i]);
+        }
+    }
+    g->xs.clear();
+    for (size_t i = 0; i < g->eng.size(); i++) {
+        mfm_engine_destroy(&g->eng[i]);
+    }
+    g->eng.clear();
+    g->committed = false;
+}
+
+void mfm_group_destroy(struct mfm_group **pg)
+{
+    if (!pg || !*pg) {
+        return;
+    }
+    group_release(*pg);
+    /* the RCCL library stays loaded: unloading it under a process that may hold other communicators is not safe */
+    delete *pg;
+    *pg = nullptr;
+}
+
+int mfm_group_add_channel(struct mfm_group *g, int32_t offset_hz, const double *lpf_taps, size_t nr_taps, double channel_gain,
+                          int want_iq)
+{
+    if (!g || !lpf_taps || 0 == nr_taps) {
+        return gfail(MFM_E_INVAL, "NULL or empty taps");
+    }
+    if (g->committed) {
+        return gfail(MFM_E_STATE, "channel set is frozen after commit");
+    }
+    if (!g->chans.empty() && g->chans[0].taps.size() != nr_taps) {
+        return gfail(MFM_E_INVAL, "all channels share one tap count (%zu), got %zu", g->chans[0].taps.size(), nr_taps);
+    }
+    if (nr_taps < g->cfg.decimation) {
+        return gfail(MFM_E_INVAL, "taps (%zu) < decimation (%u) is not a valid multifm configuration", nr_taps,
+                     g->cfg.decimation);
+    }
+    ChanDesc c;
+    c.offset_hz = offset_hz;
+    c.taps.assign(lpf_taps, lpf_taps + nr_taps);
+    c.gain = channel_gain;
+    c.want_iq = want_iq;
+    g->chans.push_back(std::move(c));
+    return (int)g->chans.size() - 1;
+}
+
+int mfm_group_commit(struct mfm_group *g)
+{
+    if (!g) {
+        return gfail(MFM_E_INVAL, "NULL group");
+    }
+    if (g->committed) {
+        return gfail(MFM_E_STATE, "already committed");
+    }
+    if (g->chans.empty()) {
+        return gfail(MFM_E_INVAL, "no channels");
+    }
+    const uint32_t C = (uint32_t)g->chans.size(), G = g->cfg.nr_devices;
+    int rc = MFM_OK;
+    for (uint32_t s = 0; s < G && rc == MFM_OK; s++) {
+        uint32_t lo = 0, n = 0;
+        mfm_shard_range(C, G, s, &lo, &n);
+        if (0 == n) {
+            continue; /* fewer channels than devices: the trailing devices stay idle */
+        }
+        mfm_engine_config ec;
+        memset(&ec, 0, sizeof(ec));
+        ec.abi_version = MFM_ABI_VERSION;
+        ec.device = g->cfg.devices[s];
+        ec.sample_rate_hz = g->cfg.sample_rate_hz;
+        ec.decimation = g->cfg.decimation;
+        ec.max_block_samples = g->cfg.max_block_samples;
+        ec.flags = g->cfg.flags;
+        mfm_engine *e = nullptr;
+        rc = mfm_engine_create(&e, &ec);
+        if (rc != MFM_OK) {
+            break;
+        }
+        g->eng.push_back(e);
+        g->dev.push_back(ec.device);
+        g->first.push_back(lo);
+        g->count.push_back(n);
+        for (uint32_t c = lo; c < lo + n && rc >= 0; c++) {
+            const ChanDesc &d = g->chans[c];
+            rc = mfm_engine_add_channel(e, d.offset_hz, d.taps.data(), d.taps.size(), d.gain, d.want_iq);
+        }
+        rc = rc < 0 ? rc : mfm_engine_commit(e);
+    }
+    if (rc != MFM_OK) {
+        group_release(g);
+        return rc; /* the failing call left its message */
+    }
+    const size_t S = g->eng.size();
+    g->exchange = S > 1 || g->cfg.exchange == MFM_X_RCCL;
+    if (g->exchange) {
+        rc = load_rccl(&g->rccl);
+        if (rc != MFM_OK) {
+            group_release(g);
+            return rc;
+        }
+        g->comm.assign(S, nullptr);
+        const int nrc = g->rccl.CommInitAll(g->comm.data(), (int)S, g->dev.data());
+        if (nrc != 0) {
+            const char *why = g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?";
+            g->comm.clear();
+            group_release(g);
+            return gfail(MFM_E_DEVICE, "ncclCommInitAll over %zu devices failed: %s", S, why);
+        }
+        g->xs.assign(S, nullptr);
+        g->xs[0] = static_cast<hipStream_t>(mfm_engine_copy_stream(g->eng[0]));
+        for (size_t i = 1; i < S; i++) {
+            if (hipSetDevice(g->dev[i]) != hipSuccess ||
+                hipStreamCreateWithFlags(&g->xs[i], hipStreamNonBlocking) != hipSuccess) {
+                group_release(g);
+                return gfail(MFM_E_DEVICE, "cannot create the exchange stream on device %d", g->dev[i]);
+            }
+        }
+    }
+    g->committed = true;
+    return MFM_OK;
+}
+
+int mfm_group_nr_shards(struct mfm_group *g)
+{
+    return (g && g->committed) ? (int)g->eng.size() : gfail(MFM_E_STATE, "commit first");
+}
+
+int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_channel, uint32_t *nr_channels, int32_t *device)
+{
+    if (!g || !g->committed || shard >= g->eng.size()) {
+        return gfail(MFM_E_INVAL, "no such shard");
+    }
+    if (first_channel) {
+        *first_channel = g->first[shard];
+    }
+    if (nr_channels) {
+        *nr_channels = g->count[shard];
+    }
+    if (device) {
+        *device = g->dev[shard];
+    }
+    return MFM_OK;
+}
+
+int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format)
+{
+    if (!g || !data) {
+        return gfail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    const size_t S = g->eng.size();
+    if (!g->exchange) {
+        return format == MFM_IN_CS16 ? mfm_engine_push(g->eng[0], static_cast<const int16_t *>(data), nr_samples)
+                                     : mfm_engine_push_bytes(g->eng[0], data, nr_samples, format);
+    }
+    /* every member must have room for the block before anything is staged: the members move in lock step */
+    for (size_t i = 1; i < S; i++) {
+        const int rc = mfm_engine_output_room(g->eng[i], nr_samples);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+    }
+    void *d_root = nullptr;
+    int rc = mfm_engine_stage(g->eng[0], data, nr_samples, format, &d_root); /* MFM_E_BUSY: nothing staged yet */
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    std::vector<void *> dst(S, nullptr);
+    dst[0] = d_root;
+    for (size_t i = 1; i < S; i++) {
+        size_t cap = 0;
+        rc = mfm_engine_acquire_input(g->eng[i], &dst[i], &cap);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+        if (cap < nr_samples) {
+            return gfail(MFM_E_INVAL, "shard %zu cannot take %zu samples", i, nr_samples);
+        }
+    }
+    /* the wideband block, as bytes, from the root's input buffer into every member's input buffer (the root's own
+     * broadcast is in place).  One thread drives all devices: the calls sit in one RCCL group. */
+    const size_t bytes = nr_samples * 4;
+    int nrc = g->rccl.GroupStart();
+    for (size_t i = 0; i < S && nrc == 0; i++) {
+        nrc = g->rccl.Broadcast(d_root, dst[i], bytes, kNcclInt8, 0, g->comm[i], g->xs[i]);
+    }
+    const int nre = g->rccl.GroupEnd();
+    nrc = nrc ? nrc : nre;
+    if (nrc != 0) {
+        return gfail(MFM_E_DEVICE, "ncclBroadcast of a %zu-byte block failed: %s", bytes,
+                     g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?");
+    }
+    for (size_t i = 0; i < S; i++) {
+        rc = mfm_engine_submit(g->eng[i], nr_samples, g->xs[i], 1);
+        if (rc != MFM_OK) {
+            return rc; /* cannot happen after the checks above short of a device error */
+        }
+    }
+    g->blocks++;
+    g->bytes_exchanged += bytes * (S - 1);
+    return MFM_OK;
+}
+
+int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks)
+{
+    if (!g || !blks) {
+        return gfail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    for (size_t i = 0; i < g->eng.size(); i++) {
+        const int rc = mfm_engine_fetch(g->eng[i], &blks[i]);
+        if (rc != MFM_OK) {
+            if (rc == MFM_E_DONE && i != 0) {
+                return gfail(MFM_E_STATE, "shards out of step: shard %zu has no block where shard 0 has one", i);
+            }
+            return rc;
+        }
+        if (blks[i].first_output != blks[0].first_output || blks[i].nr_outputs != blks[0].nr_outputs) {
+            return gfail(MFM_E_STATE, "shards out of step at output %llu", (unsigned long long)blks[0].first_output);
+        }
+    }
+    return MFM_OK;
+}
+
+int mfm_group_release(struct mfm_group *g)
+{
+    if (!g || !g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    int rc = MFM_OK;
+    for (size_t i = 0; i < g->eng.size(); i++) {
+        const int r = mfm_engine_release(g->eng[i]);
+        rc = rc == MFM_OK ? r : rc;
+    }
+    return rc;
+}
+
+int mfm_group_sync(struct mfm_group *g)
+{
+    if (!g || !g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    for (size_t i = 0; i < g->xs.size(); i++) {
+        if (i > 0 && (hipSetDevice(g->dev[i]) != hipSuccess || hipStreamSynchronize(g->xs[i]) != hipSuccess)) {
+            return gfail(MFM_E_DEVICE, "exchange stream of device %d failed", g->dev[i]);
+        }
+    }
+    for (size_t i = 0; i < g->eng.size(); i++) {
+        const int rc = mfm_engine_sync(g->eng[i]);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+    }
+    return MFM_OK;
+}
+
+int mfm_group_get_stats(struct mfm_group *g, uint32_t shard, struct mfm_stats *st)
+{
+    if (!g || !g->committed || shard >= g->eng.size()) {
+        return gfail(MFM_E_INVAL, "no such shard");
+    }
+    return mfm_engine_get_stats(g->eng[shard], st);
+}
+
+int mfm_group_exchange_info(struct mfm_group *g, int *uses_rccl, uint64_t *blocks, uint64_t *bytes_exchanged)
+{
+    if (!g || !g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    if (uses_rccl) {
+        *uses_rccl = g->exchange ? 1 : 0;
+    }
+    if (blocks) {
+        *blocks = g->blocks;
+    }
+    if (bytes_exchanged) {
+        *bytes_exchanged = g->bytes_exchanged;
+    }
+    return MFM_OK;
+}
+
+} /* extern "C" */

@@ -94,8 +94,6 @@ struct mfm_launch_mfma {
     uint32_t ah_mask;     /* bit kq set: some tap of k-step kq (32 complex taps) lies outside [-128, 127], i.e. its high-byte
                              plane is not all zero.  Low-pass taps decay towards both ends, so for the outer k-steps the two
                              products with the high-byte plane are zero and are not computed. */
-    uint32_t skew;        /* units of ~128 clocks waves 4..7 wait after each tile barrier (staggers the LDS-heavy
-                             matrix phase of the two halves of a workgroup) */
     uint32_t tail_src, tail_n; /* samples x[tail_src .. tail_src + tail_n) are the history the next block needs ... */
     uint32_t *tail_dst;   /* ... at the front of the other input buffer (workgroup 0 copies them) */
     const uint32_t *afrag;   /* [nrb][kq][plane hi,lo][lane][4 dwords] */
@@ -107,7 +105,6 @@ struct mfm_launch_mfma {
     const float2 *lut;
     int16_t *pcm;
     uint32_t *iq_dbg;
-    unsigned long long *trace; /* NULL unless the library was built with -DMFM_TRACE */
 };
 
 /* ---------------------------------------------------------------------------------------------

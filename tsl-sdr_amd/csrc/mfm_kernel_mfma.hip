@@ -42,22 +42,6 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 
 #define MFM_M_NT (MFM_MFMA_NW * 64)
 
-/* Optional phase trace for tools/trace_phases.py (build with -DMFM_TRACE): wave 0 of a few workgroups
- * drops s_memtime stamps into L.trace.  Compiled out of the product library. */
-#if defined(MFM_TRACE)
-#define MFM_STAMP(id)                                                                                        \
-    do {                                                                                                     \
-        if (L.trace && blockIdx.x < 64 && tid == 0 && tr_n < 60) {                                          \
-            L.trace[blockIdx.x * 128 + 2 * tr_n] = (unsigned long long)(id);                                 \
-            L.trace[blockIdx.x * 128 + 2 * tr_n + 1] = __builtin_readcyclecounter();                         \
-            tr_n++;                                                                                          \
-        }                                                                                                    \
-    } while (0)
-#else
-#define MFM_STAMP(id)                                                                                        \
-    do {                                                                                                     \
-    } while (0)
-#endif
 #define MFM_M_NEW 31 /* new outputs per 32-column iteration */
 /* sched_barrier mask: ALU | VALU | SALU | MFMA | DS | DS-read | DS-write may cross, vector memory may not */
 #define MFM_SCHED_ALL_BUT_VMEM 0x38F
@@ -158,10 +142,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t kg = lane >> 4, n = lane & 15u;
-#if defined(MFM_TRACE)
-    uint32_t tr_n = 0;
-#endif
-    MFM_STAMP(1);
     const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
@@ -316,7 +296,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     if (have) {
         rot_offsets(tile, (slice * MFM_MFMA_NW + wave) * 8u + 2u * kg, slice * MFM_MFMA_NW + wave < L.nrb, k_off);
     }
-    MFM_STAMP(2);
 
     /* Vector memory in this loop is straight-line code: every load and store below is issued on every path
      * (row blocks past the end are clamped, outputs that must not be written go to a dump slot behind the output
@@ -494,28 +473,11 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     #pragma unroll
                     for (int kq = 0; kq < KQ; kq++) {
                         const int cb = kq & 1, nb = cb ^ 1;
-#if defined(MFM_EXPERIMENT) && MFM_EXPERIMENT == 1
-                        /* sensitivity run (wrong results): every second k-step reuses the previous B fragments */
-                        if (kq + 1 < KQ) {
-                            if ((kq & 1) == 1) {
-                                bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
-                                bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
-                            } else {
-                                bh[nb] = bh[cb];
-                                bl[nb] = bl[cb];
-                            }
-                        }
-#else
                         if (kq + 1 < KQ) {
                             bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
                             bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
                         }
-#endif
-#if defined(MFM_EXPERIMENT) && MFM_EXPERIMENT == 3
-                        if (false) { /* sensitivity run (wrong results): no high-plane products at all */
-#else
                         if ((ah_mask >> kq) & 1u) { /* uniform: skipped where the high-byte tap plane is all zero */
-#endif
                             hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
                             md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md, 0, 0, 0);
                         }
@@ -540,7 +502,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     pre[j] = stage_load(have_n ? tile_n : tile, j);
                 }
             }
-            MFM_STAMP(6);
 
             int pcm[2][2];
             if (it == 0) {
@@ -566,18 +527,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 for (int gq = 0; gq < 2; gq++) {
                     mfm_conj_mul(q[gq][c], pp[gq], &s_re[gq], &s_im[gq]);
                 }
-#if defined(MFM_EXPERIMENT) && MFM_EXPERIMENT == 2
-                /* sensitivity run (wrong results): no discriminator arithmetic */
-                out[0] = s_re[0] ^ s_im[0];
-                out[1] = s_re[1] ^ s_im[1];
-#else
                 mfm_discriminate2(s_re, s_im, lut_t, lut_d, out);
-#endif
                 pcm[0][c] = out[0];
                 pcm[1][c] = out[1];
             }
-
-            MFM_STAMP(8);
             /* rotator entries of the next iteration (of the next tile after the last one) */
             uint2 rvn[2][2];
             if (it + 1 < NIT) {
@@ -595,8 +548,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 }
                 __builtin_amdgcn_sched_barrier(MFM_SCHED_ALL_BUT_VMEM);
             }
-
-            MFM_STAMP(9);
             /* PCM: every lane stores its four values; the ones that are not outputs (column 0 of group 0, columns
              * past n_new, channels past the end) go to the dump slot */
             const uint32_t dump = L.nchan * L.out_stride + lane;
@@ -629,7 +580,6 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     }
                 }
             }
-            MFM_STAMP(7);
 #pragma unroll
             for (int gq = 0; gq < 2; gq++) {
 #pragma unroll
@@ -658,15 +608,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 }
             }
         }
-
-        MFM_STAMP(4);
         __syncthreads(); /* next tile's image is complete and nobody reads the current one any more */
-        if (wave >= MFM_MFMA_NW / 2) {
-            for (uint32_t z = 0; z < L.skew; z++) {
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        MFM_STAMP(5);
         cur ^= 1u;
         item = item_n;
         tile = tile_n;

@@ -226,6 +226,9 @@ static struct json_node *parse_value(struct parser *ps, int depth)
 
 static struct json_node *obj_find(struct json_node *o, const char *key)
 {
+    if (NULL == key) {
+        return o; /* the node itself: how the atoms of an array ("gpuDevices": [0, 1]) are read */
+    }
     if (!o || o->kind != J_OBJ) {
         return NULL;
     }

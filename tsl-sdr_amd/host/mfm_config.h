@@ -27,6 +27,7 @@ void config_delete(struct config **pcfg);
 aresult_t config_add(struct config *cfg, const char *filename);
 aresult_t config_add_string(struct config *cfg, const char *json_text);
 
+/* key == NULL in the getters below: the value of the node `cfg` points at itself (an atom of an array) */
 aresult_t config_get(struct config *cfg, struct config *sub, const char *key);
 aresult_t config_get_integer(struct config *cfg, int *val, const char *key);
 aresult_t config_get_float(struct config *cfg, double *val, const char *key);

@@ -63,11 +63,11 @@ static aresult_t _sample_buf_release(struct sample_buf *buf)
 
 /* ---- channels ---- */
 
-static struct mfm_engine *g_bound_engine; /* set by receiver_init() around its channel loop */
+static struct mfm_group *g_bound_group; /* set by receiver_init() around its channel loop */
 
-void demod_thread_bind_engine(struct mfm_engine *engine)
+void demod_thread_bind_group(struct mfm_group *group)
 {
-    g_bound_engine = engine;
+    g_bound_group = group;
 }
 
 aresult_t demod_thread_new(struct demod_thread **pthr, unsigned core_id, int32_t offset_hz, uint32_t samp_hz,
@@ -86,8 +86,8 @@ aresult_t demod_thread_new(struct demod_thread **pthr, unsigned core_id, int32_t
     (void)samp_hz; /* the engine was created with the receiver's sample rate and decimation */
 
     *pthr = NULL;
-    if (NULL == g_bound_engine) {
-        MFM_MSG(SEV_FATAL, "NO-ENGINE", "demod_thread_new() outside receiver_init(): no engine is bound");
+    if (NULL == g_bound_group) {
+        MFM_MSG(SEV_FATAL, "NO-ENGINE", "demod_thread_new() outside receiver_init(): no device group is bound");
         return A_E_INVAL;
     }
     if (FAILED(ret = TZAALLOC(thr, SYS_CACHE_LINE_LENGTH))) {
@@ -98,7 +98,7 @@ aresult_t demod_thread_new(struct demod_thread **pthr, unsigned core_id, int32_t
     list_init(&thr->dt_node);
 
     const bool want_iq = NULL != fir_debug_output && '\0' != *fir_debug_output;
-    int chan = mfm_engine_add_channel(g_bound_engine, offset_hz, lpf_taps, lpf_nr_taps, channel_gain, want_iq);
+    int chan = mfm_group_add_channel(g_bound_group, offset_hz, lpf_taps, lpf_nr_taps, channel_gain, want_iq);
     if (chan < 0) {
         MFM_MSG(SEV_FATAL, "BAD-CHANNEL", "Channel at offset %d Hz rejected: %s", offset_hz, mfm_last_error());
         ret = A_E_INVAL;
@@ -154,14 +154,14 @@ aresult_t demod_thread_delete(struct demod_thread **pthr)
 }
 
 /* write one channel's share of a finished block: the FIFO byte stream of demod.c:93, EPIPE policy :95-110 */
-static void _demod_thread_emit(struct demod_thread *dthr, const struct mfm_block *blk)
+static void _demod_thread_emit(struct demod_thread *dthr, const struct mfm_block *blk, size_t row)
 {
     const size_t n = blk->nr_outputs;
-    const int16_t *pcm = blk->pcm + (size_t)dthr->chan_index * blk->stride;
+    const int16_t *pcm = blk->pcm + row * blk->stride;
 
     dthr->total_nr_demod_samples += n;
     if (-1 != dthr->debug_signal_fd && NULL != blk->iq) {
-        const int16_t *iq = blk->iq + (size_t)dthr->chan_index * blk->stride * 2;
+        const int16_t *iq = blk->iq + row * blk->stride * 2;
         if (0 > write(dthr->debug_signal_fd, iq, n * 2 * sizeof(int16_t))) {
             int errnum = errno;
             MFM_MSG(SEV_WARNING, "CANT-WRITE-DEBUG-FILE", "Unable to write %zu bytes to post-demod debug file. "
@@ -231,60 +231,103 @@ aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *bu
     TSL_ASSERT_ARG(NULL != buf);
     TSL_BUG_ON(0 == buf->nr_samples); /* multifm/receiver.c:84 */
 
-    /* one consumer: the engine.  It copies the samples into its pinned staging slot inside push(), so the
-     * buffer goes back to the pool right away. */
+    const uint64_t t0 = tsl_get_clock_monotonic();
+    /* One consumer - the submit thread - so refcount 1 (multifm/receiver.c:86 sets it to the number of channel
+     * threads).  Nothing is copied and nothing is waited for here: the pointer goes into a ring with as many slots as
+     * the pool has frames.  A front end that outruns the GPU finds the pool empty at its next
+     * receiver_sample_buf_alloc() and drops there, counted, as the reference does. */
     atomic_store((_Atomic uint32_t *)&buf->refcount, 1);
-    for (;;) {
-        int rc;
-        switch (buf->sample_type) {
-        case RAW_COMPLEX_INT_8:
-            rc = mfm_engine_push_bytes(rx->engine, buf->data_buf, buf->nr_samples, MFM_IN_CS8);
-            break;
-        case RAW_COMPLEX_FILE_UINT_8:
-            rc = mfm_engine_push_bytes(rx->engine, buf->data_buf, buf->nr_samples, MFM_IN_CU8);
-            break;
-        case RAW_COMPLEX_RTLSDR_UINT_8:
-            rc = mfm_engine_push_bytes(rx->engine, buf->data_buf, buf->nr_samples, MFM_IN_RTLSDR_U8);
-            break;
-        default:
-            rc = mfm_engine_push(rx->engine, (const int16_t *)buf->data_buf, buf->nr_samples);
-        }
-        if (MFM_OK == rc) {
-            break;
-        }
-        if (MFM_E_BUSY == rc) {
-            /* all output slots hold blocks the drain thread has not written out yet */
+    if (rx->failed) {
+        (void)sample_buf_decref(buf);
+        return A_E_DEVICE;
+    }
+    const size_t head = rx->ring_head;
+    TSL_BUG_ON(head - rx->ring_tail >= rx->ring_slots); /* more buffers in flight than the pool holds */
+    rx->ring[head % rx->ring_slots] = buf;
+    atomic_thread_fence(memory_order_release);
+    rx->ring_head = head + 1;
+    rx->nr_bufs_delivered++;
+    const uint64_t dt = tsl_get_clock_monotonic() - t0;
+    if (dt > rx->max_deliver_ns) {
+        rx->max_deliver_ns = dt;
+    }
+    return A_OK;
+}
+
+static int _format_of(const struct sample_buf *buf)
+{
+    switch (buf->sample_type) {
+    case RAW_COMPLEX_INT_8: return MFM_IN_CS8;
+    case RAW_COMPLEX_FILE_UINT_8: return MFM_IN_CU8;
+    case RAW_COMPLEX_RTLSDR_UINT_8: return MFM_IN_RTLSDR_U8;
+    default: return MFM_IN_CS16;
+    }
+}
+
+/* the submit thread: ring -> device group; the only place that waits for the GPU on the input side */
+static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
+{
+    struct receiver *rx = BL_CONTAINER_OF(wthr, struct receiver, submit_thr);
+    while (worker_thread_is_running(wthr) || rx->ring_tail != rx->ring_head) {
+        const size_t tail = rx->ring_tail;
+        if (tail == rx->ring_head) {
             usleep(200);
             continue;
         }
-        PANIC("mfm_engine_push failed: %s", mfm_last_error());
+        atomic_thread_fence(memory_order_acquire);
+        struct sample_buf *buf = rx->ring[tail % rx->ring_slots];
+        if (!rx->failed) {
+            for (;;) {
+                const int rc = mfm_group_push(rx->group, buf->data_buf, buf->nr_samples, _format_of(buf));
+                if (MFM_OK == rc) {
+                    break;
+                }
+                if (MFM_E_BUSY == rc && !rx->failed) {
+                    usleep(200); /* every output slot holds a block the drain thread has not written out yet */
+                    continue;
+                }
+                MFM_MSG(SEV_FATAL, "ENGINE-PUSH", "mfm_group_push failed: %s", mfm_last_error());
+                rx->failed = 1;
+                break;
+            }
+        }
+        rx->ring_tail = tail + 1;
+        rx->nr_bufs_submitted++;
+        TSL_BUG_IF_FAILED(sample_buf_decref(buf)); /* back to the pool */
     }
-    rx->nr_bufs_delivered++;
-    return sample_buf_decref(buf);
+    return rx->failed ? A_E_DEVICE : A_OK;
 }
 
 static aresult_t _receiver_drain_once(struct receiver *rx, bool *got)
 {
-    struct mfm_block blk;
+    struct mfm_block blks[MFM_GROUP_MAX_DEVICES];
     struct demod_thread *dthr = NULL;
 
     *got = false;
-    int rc = mfm_engine_fetch(rx->engine, &blk);
+    int rc = mfm_group_fetch(rx->group, blks);
     if (MFM_E_DONE == rc) {
         return A_OK;
     }
     if (MFM_OK != rc) {
-        MFM_MSG(SEV_FATAL, "ENGINE-FETCH", "mfm_engine_fetch failed: %s", mfm_last_error());
+        MFM_MSG(SEV_FATAL, "ENGINE-FETCH", "mfm_group_fetch failed: %s", mfm_last_error());
         return A_E_DEVICE;
     }
     if (!rx->muted) {
         list_for_each_type(dthr, &rx->demod_threads, dt_node) {
-            _demod_thread_emit(dthr, &blk);
+            /* which shard holds this channel, and which row of the shard's block it is */
+            for (int s = 0; s < rx->nr_shards; s++) {
+                uint32_t first = 0, count = 0;
+                if (MFM_OK == mfm_group_shard_info(rx->group, (uint32_t)s, &first, &count, NULL) &&
+                    (uint32_t)dthr->chan_index >= first && (uint32_t)dthr->chan_index < first + count) {
+                    _demod_thread_emit(dthr, &blks[s], (size_t)dthr->chan_index - first);
+                    break;
+                }
+            }
         }
     }
     rx->nr_blocks_drained++;
     *got = true;
-    return MFM_OK == mfm_engine_release(rx->engine) ? A_OK : A_E_DEVICE;
+    return MFM_OK == mfm_group_release(rx->group) ? A_OK : A_E_DEVICE;
 }
 
 static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
@@ -293,6 +336,7 @@ static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
     while (worker_thread_is_running(wthr)) {
         bool got = false;
         if (FAILED(_receiver_drain_once(rx, &got))) {
+            rx->failed = 1; /* deliver(), the submit thread and receiver_drain() stop waiting for us */
             return A_E_DEVICE;
         }
         if (!got) {
@@ -305,23 +349,38 @@ static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
 aresult_t receiver_drain(struct receiver *rx)
 {
     TSL_ASSERT_ARG(NULL != rx);
-    /* wait for the device, then until every finished block has been written out */
-    if (MFM_OK != mfm_engine_sync(rx->engine)) {
+    /* everything delivered has been submitted, the devices are done, every finished block has been written out */
+    while (rx->submit_thr.started && rx->nr_bufs_submitted != rx->nr_bufs_delivered) {
+        if (rx->failed) {
+            return A_E_DEVICE;
+        }
+        usleep(200);
+    }
+    if (rx->failed || MFM_OK != mfm_group_sync(rx->group)) {
         return A_E_DEVICE;
     }
     for (;;) {
-        struct mfm_stats st;
-        if (MFM_OK != mfm_engine_get_stats(rx->engine, &st)) {
-            return A_E_DEVICE;
+        bool pending = false;
+        for (int s = 0; s < rx->nr_shards; s++) {
+            struct mfm_stats st;
+            if (MFM_OK != mfm_group_get_stats(rx->group, (uint32_t)s, &st)) {
+                return A_E_DEVICE;
+            }
+            pending = pending || 0 != st.pending_blocks;
         }
-        if (0 == st.pending_blocks) {
+        if (!pending) {
             return A_OK;
+        }
+        if (rx->failed) {
+            return A_E_DEVICE;
         }
         if (rx->drain_thr.started) {
             usleep(500); /* the drain thread owns fetch/release */
         } else {
             bool got = false;
-            TSL_BUG_IF_FAILED(_receiver_drain_once(rx, &got));
+            if (FAILED(_receiver_drain_once(rx, &got))) {
+                return A_E_DEVICE;
+            }
         }
     }
 }
@@ -350,7 +409,20 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
     rx->samp_alloc = NULL;
     rx->cleanup_func = cleanup_func;
     rx->thread_func = rx_func;
-    rx->engine = NULL;
+    rx->nr_samp_buf_alloc_fails = 0;
+    rx->input_done = false;
+    rx->nr_blocks_drained = 0;
+    memset(&rx->wthr, 0, sizeof(rx->wthr));
+    memset(&rx->submit_thr, 0, sizeof(rx->submit_thr));
+    memset(&rx->drain_thr, 0, sizeof(rx->drain_thr));
+    rx->group = NULL;
+    rx->nr_shards = 0;
+    rx->ring = NULL;
+    rx->ring_slots = 0;
+    rx->ring_head = rx->ring_tail = 0;
+    rx->failed = 0;
+    rx->nr_bufs_delivered = rx->nr_bufs_submitted = 0;
+    rx->max_deliver_ns = 0;
     rx->nr_demod_threads = 0;
     list_init(&rx->demod_threads);
 
@@ -398,25 +470,56 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
         goto done;
     }
 
-    /* one engine for the whole channel set; "gpuDevice" picks the HIP device (default 0) */
+    /* one device group for the whole channel set: "gpuDevices": [d0, d1, ...] shards the channels over several GPUs of
+     * the node (d0 ingests and broadcasts), "gpuDevice": d is the one-GPU form (default device 0); "gpuExchange":
+     * "rccl" sends the blocks through the RCCL broadcast path even on one device */
     {
-        struct mfm_engine_config ec;
+        struct mfm_group_config gc;
+        struct config devs = CONFIG_INIT_EMPTY, dev = CONFIG_INIT_EMPTY;
+        const char *xchg = NULL;
         int gpu = 0;
-        memset(&ec, 0, sizeof(ec));
-        (void)config_get_integer(cfg, &gpu, "gpuDevice");
-        ec.abi_version = MFM_ABI_VERSION;
-        ec.device = gpu;
-        ec.sample_rate_hz = (uint32_t)sample_rate;
-        ec.decimation = (uint32_t)decimation_factor;
-        ec.max_block_samples = (uint32_t)samples_per_buf;
-        if (MFM_OK != mfm_engine_create(&rx->engine, &ec)) {
+        size_t dctr = 0;
+        memset(&gc, 0, sizeof(gc));
+        gc.abi_version = MFM_ABI_VERSION;
+        if (!FAILED(config_get(cfg, &devs, "gpuDevices"))) {
+            aresult_t dret = A_OK;
+            (void)dret;
+            CONFIG_ARRAY_FOR_EACH(dev, &devs, dret, dctr) {
+                int d = -1;
+                if (gc.nr_devices >= MFM_GROUP_MAX_DEVICES || FAILED(config_get_integer(&dev, &d, NULL)) || d < 0) {
+                    MFM_MSG(SEV_ERROR, "BAD-GPU-DEVICES", "'gpuDevices' must be an array of at most %d device numbers.",
+                            MFM_GROUP_MAX_DEVICES);
+                    ret = A_E_INVAL;
+                    goto done;
+                }
+                gc.devices[gc.nr_devices++] = d;
+            }
+        }
+        if (0 == gc.nr_devices) {
+            (void)config_get_integer(cfg, &gpu, "gpuDevice");
+            gc.devices[0] = gpu;
+            gc.nr_devices = 1;
+        }
+        if (!FAILED(config_get_string(cfg, &xchg, "gpuExchange")) && 0 == strcmp(xchg, "rccl")) {
+            gc.exchange = MFM_X_RCCL;
+        }
+        gc.sample_rate_hz = (uint32_t)sample_rate;
+        gc.decimation = (uint32_t)decimation_factor;
+        gc.max_block_samples = (uint32_t)samples_per_buf;
+        if (MFM_OK != mfm_group_create(&rx->group, &gc)) {
             MFM_MSG(SEV_FATAL, "ENGINE-CREATE", "Unable to create the channel engine: %s", mfm_last_error());
             ret = A_E_DEVICE;
             goto done;
         }
+        MFM_MSG(SEV_INFO, "GPU-DEVICES", "Channels are sharded over %u GPU(s), first device %d%s", gc.nr_devices,
+                gc.devices[0], gc.exchange == MFM_X_RCCL ? " (RCCL exchange forced)" : "");
+        rx->ring_slots = (size_t)nr_samp_bufs;
+        if (FAILED(ret = TACALLOC(&rx->ring, rx->ring_slots, sizeof(*rx->ring), SYS_CACHE_LINE_LENGTH))) {
+            goto done;
+        }
     }
 
-    demod_thread_bind_engine(rx->engine);
+    demod_thread_bind_group(rx->group);
     CONFIG_ARRAY_FOR_EACH(channel, &channels, ret, arr_ctr) {
         const char *fifo_name = NULL, *signal_debug = NULL;
         int nb_center_freq = -1;
@@ -451,7 +554,7 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
                 (double)nb_center_freq / 1e6, channel_gain_db, fifo_name, (NULL != signal_debug ? " DEBUG: " : ""),
                 (NULL != signal_debug ? signal_debug : ""));
     }
-    demod_thread_bind_engine(NULL);
+    demod_thread_bind_group(NULL);
     if (FAILED(ret)) {
         MFM_MSG(SEV_ERROR, "CHANNEL-SETUP-FAILURE", "Error reading array of channels, aborting.");
         goto done;
@@ -481,11 +584,15 @@ aresult_t receiver_start(struct receiver *rx)
     TSL_ASSERT_ARG(NULL != rx);
 
     /* the channel set is complete: build the tables and go to the device */
-    if (MFM_OK != mfm_engine_commit(rx->engine)) {
+    if (MFM_OK != mfm_group_commit(rx->group)) {
         MFM_MSG(SEV_ERROR, "ENGINE-COMMIT", "Unable to start the channel engine: %s", mfm_last_error());
         return A_E_DEVICE;
     }
+    rx->nr_shards = mfm_group_nr_shards(rx->group);
     if (FAILED(ret = worker_thread_new(&rx->drain_thr, _receiver_drain_thread, WORKER_THREAD_CPU_MASK_ANY))) {
+        return ret;
+    }
+    if (FAILED(ret = worker_thread_new(&rx->submit_thr, _receiver_submit_thread, WORKER_THREAD_CPU_MASK_ANY))) {
         return ret;
     }
     if (FAILED(ret = worker_thread_new(&rx->wthr, _receiver_worker_thread, WORKER_THREAD_CPU_MASK_ANY))) {
@@ -505,8 +612,12 @@ aresult_t receiver_cleanup(struct receiver **prx)
     /* stop the producer first, then let what it delivered reach the FIFOs */
     TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->wthr));
     TSL_BUG_IF_FAILED(worker_thread_delete(&rx->wthr));
-    if (NULL != rx->engine && rx->drain_thr.started) {
-        (void)receiver_drain(rx);
+    if (NULL != rx->group && rx->drain_thr.started) {
+        (void)receiver_drain(rx); /* returns A_E_DEVICE instead of waiting for a thread that has given up */
+        if (rx->submit_thr.started) {
+            TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->submit_thr));
+            TSL_BUG_IF_FAILED(worker_thread_delete(&rx->submit_thr));
+        }
         TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->drain_thr));
         TSL_BUG_IF_FAILED(worker_thread_delete(&rx->drain_thr));
     }
@@ -517,7 +628,10 @@ aresult_t receiver_cleanup(struct receiver **prx)
         list_del(&cur->dt_node);
         TSL_BUG_IF_FAILED(demod_thread_delete(&cur));
     }
-    mfm_engine_destroy(&rx->engine);
+    mfm_group_destroy(&rx->group);
+    if (NULL != rx->ring) {
+        TFREE(rx->ring);
+    }
     TSL_BUG_IF_FAILED(frame_alloc_delete(&rx->samp_alloc));
     *prx = NULL;
     return A_OK;

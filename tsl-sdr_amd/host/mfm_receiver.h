@@ -9,9 +9,11 @@
  * so a front end written against them (file_if, rtl_sdr_if, airspy_if, uhd_if) compiles and behaves the
  * same: allocate a sample_buf from the receiver's pool, fill data_buf with interleaved int16 I,Q, set
  * nr_samples, deliver.  What differs is behind the interface: a demod_thread is a channel REGISTRATION on
- * the receiver's mfm_engine (no pthread per channel); deliver() hands the buffer to that one engine
- * (refcount 1, released as soon as the samples are staged for H2D); one drain thread writes every
- * channel's PCM to its FIFO.
+ * the receiver's device group (no pthread per channel; "gpuDevices": [..] in the receiver configuration shards the
+ * channels over several GPUs of the node, mfm_group_*); deliver() only queues the buffer's pointer (refcount 1) and
+ * returns - a submit thread copies it to the device(s) and gives it back to the pool, a drain thread writes every
+ * channel's PCM to its FIFO.  The front end's thread never waits for the GPU: when the device falls behind, the pool
+ * runs dry and receiver_sample_buf_alloc() drops + counts exactly as in the reference (multifm/receiver.c:57-63).
  */
 #pragma once
 
@@ -70,14 +72,14 @@ struct demod_thread {
 
 /*
  * demod_thread_new() keeps the reference signature.  core_id is ignored (there is no thread to pin).
- * The channel is registered on the engine made current with demod_thread_bind_engine(), which
+ * The channel is registered on the device group made current with demod_thread_bind_group(), which
  * receiver_init() does around its channel loop.
  */
 aresult_t demod_thread_new(struct demod_thread **pthr, unsigned core_id, int32_t offset_hz, uint32_t samp_hz,
                            const char *out_fifo, int decimation_factor, const double *lpf_taps, size_t lpf_nr_taps,
                            const char *fir_debug_output, double channel_gain);
 aresult_t demod_thread_delete(struct demod_thread **pthr);
-void demod_thread_bind_engine(struct mfm_engine *engine);
+void demod_thread_bind_group(struct mfm_group *group);
 
 /* ---- receiver (multifm/receiver.h) ---- */
 
@@ -96,11 +98,18 @@ struct receiver {
     receiver_rx_thread_func_t thread_func;
 
     /* MI355X build */
-    struct mfm_engine *engine;
-    struct worker_thread drain_thr;
+    struct mfm_group *group;      /* the channel set on one or more devices */
+    int nr_shards;                /* after receiver_start() */
+    struct worker_thread submit_thr, drain_thr;
+    struct sample_buf **ring;     /* delivered, not yet submitted buffers: single producer (front end), single
+                                     consumer (submit thread); as many slots as the pool has frames, so it never fills */
+    size_t ring_slots;
+    volatile size_t ring_head, ring_tail;
     volatile bool input_done;     /* front end reached end of input */
-    size_t nr_bufs_delivered;
+    volatile int failed;          /* a device error stopped the submit or the drain thread (A_E_DEVICE from then on) */
+    volatile size_t nr_bufs_delivered, nr_bufs_submitted;
     size_t nr_blocks_drained;
+    uint64_t max_deliver_ns;      /* longest receiver_sample_buf_deliver() call so far */
 };
 
 aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,
