@@ -57,39 +57,81 @@ def parse():
     return ap.parse_args()
 
 
+def _native_oracle(ora):
+    """The oracle's C restatement rebuilt on this host with the reference's own optimisation flags (-O2 -march=native,
+    CMakeLists.txt:77); the shipped liboracle.so is built for x86-64-v3 because it has to run wherever the tests go.
+    Returns (run_channels callable, description)."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    odir = os.path.join(ROOT, "oracle")
+    out = os.path.join(tempfile.gettempdir(), f"liboracle_native_{os.getuid()}.so")
+    srcs = [os.path.join(odir, f) for f in ("mfm_oracle.c", "pocsag_oracle.c", "f32_oracle.c")]
+    cmd = ["gcc", "-std=gnu11", "-O2", "-march=native", "-ffp-contract=off", "-fwrapv", "-fPIC", "-D_GNU_SOURCE", "-shared",
+           "-o", out] + srcs + ["-lm", "-lpthread"]
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+        lib = C.CDLL(out)
+        i16p = C.POINTER(C.c_int16)
+        lib.mfmo_run_channels.argtypes = [i16p, C.c_size_t, C.c_size_t, i16p, i16p, C.c_size_t, C.c_uint, i16p, i16p, i16p,
+                                          C.c_size_t, C.c_uint]
+        lib.mfmo_run_channels.restype = C.c_size_t
+    except Exception:
+        return (lambda iq, cre, cim, incr, decim, threads: ora.run_channels(iq, cre, cim, incr, decim, threads=threads)[0],
+                "oracle/liboracle.so as shipped (-O2 -march=x86-64-v3; the native rebuild failed)")
+
+    def run(iq, cre, cim, incr, decim, threads):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        nch, T = cre.shape
+        nout = (iq.shape[0] - T) // decim + 1
+        pcm = np.zeros((nch, nout), np.int16)
+        p = lambda a: a.ctypes.data_as(i16p)  # noqa: E731
+        got = lib.mfmo_run_channels(p(iq), iq.shape[0], nch, p(cre), p(cim), T, decim, p(incr), p(pcm), None, nout, threads)
+        assert got == nout
+        return pcm
+
+    return run, "oracle/*.c rebuilt here with gcc -O2 -march=native (the reference's flags, CMakeLists.txt:77)"
+
+
 def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
     """The oracle (a port of the reference's per-channel loop) on the host cores, thread-per-channel
     like multifm/receiver.c:89-95, on a bounded sample of the same workload."""
     from __graft_entry__ import load_oracle
     ora = load_oracle()
+    run, how = _native_oracle(ora)
     cores = os.cpu_count() or 1
     nch = len(offs)
-    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
-    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
-    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    cre = np.ascontiguousarray(np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)]), np.int16)
+    cim = np.ascontiguousarray(np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)]), np.int16)
+    incr = np.ascontiguousarray(np.stack([ora.rot_incr(int(o), fs, decim) for o in offs]), np.int16)
     threads = min(cores, nch)
     n_cal = 1 << 19
     iq = pkg.synth.synth_iq(n_cal, fs, offs[:4], seed=7)
+    # one channel on one core: the figure SURVEY.md section 6 quotes for the reference's scalar path (434 MSamp/s)
     t0 = time.perf_counter()
-    ora.run_channels(iq, cre, cim, incr, decim, threads=threads)
+    reps = 0
+    while time.perf_counter() - t0 < min(2.0, target_s / 4):
+        run(iq, cre[:1], cim[:1], incr[:1], decim, 1)
+        reps += 1
+    one_core = reps * n_cal / (time.perf_counter() - t0) / 1e6
+    t0 = time.perf_counter()
+    run(iq, cre, cim, incr, decim, threads)
     t_cal = time.perf_counter() - t0
     n = int(min(1 << 24, max(n_cal, n_cal * target_s / max(t_cal, 1e-3))))
     big = np.tile(iq, (-(-n // n_cal), 1))[:n]
-    t0 = time.perf_counter()
-    ora.run_channels(big, cre, cim, incr, decim, threads=threads)
-    t_one = time.perf_counter() - t0
-    del t_one  # first pass only warms the pages and the thread pool
+    run(big, cre, cim, incr, decim, threads)  # first pass only warms the pages and the thread pool
     passes = 0
     t0 = time.perf_counter()
     while True:
-        ora.run_channels(big, cre, cim, incr, decim, threads=threads)
+        run(big, cre, cim, incr, decim, threads)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= target_s:
             break
     return {"value": passes * n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
-            "sample": f"{passes} passes over {n} IQ samples x {nch} channels, oracle/liboracle.so "
-                      f"(-O2 -march=x86-64-v3), {threads} threads thread-per-channel, {dt:.1f} s"}
+            "msamp_per_s_one_channel_one_core": one_core,
+            "sample": f"{passes} passes over {n} IQ samples x {nch} channels, {how}, {threads} threads "
+                      f"thread-per-channel, {dt:.1f} s"}
 
 
 def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=24, iters=30):

@@ -85,6 +85,13 @@ def test_reference_shaped_configs(pkg, ora, name, kernel):
     fs, decim, taps, offs, gains = pkg.synth.plan(name)
     iq = pkg.synth.synth_iq(4096 * 60, fs, offs, seed=21)
     _check(pkg, ora, fs, decim, taps, offs, iq, 4096, gains=gains, kernel=kernel)
+    if name == "pocsag_rtlsdr" and kernel != "dot2":
+        # decimation 25 is not a multiple of 8: LDS rows padded from 50 to 64 bytes, zero taps over the padding
+        # (filter/direct_fir.c:328-417 has no restriction on the decimation; neither has the matrix kernel now)
+        eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=4096, kernel=kernel)
+        st = eng.stats()
+        eng.close()
+        assert st["kernel_variant"] == 1
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -189,6 +196,24 @@ def test_odd_geometries(pkg, ora, decim, ntaps):
     n = max(decim * 700 + ntaps + 5, 3000)
     iq = pkg.synth.synth_iq(n, fs, offs, seed=decim)
     _check(pkg, ora, fs, decim, taps, offs, iq, 8192)
+
+
+@pytest.mark.parametrize("decim,ntaps,nch", [(25, 128, 2), (25, 128, 70), (7, 33, 3), (12, 40, 9), (20, 64, 5), (97, 128, 3),
+                                             (50, 200, 4), (99, 300, 3), (6, 16, 2), (36, 36, 3), (100, 300, 2)])
+def test_decimations_that_are_not_multiples_of_8_run_on_the_matrix_kernel(pkg, ora, decim, ntaps, nch):
+    """LDS rows padded to 16-byte multiples, zero taps over the padding, 4-sample staging chunks that straddle rows
+    stored sample by sample: any decimation with at least 3/4 of a padded row in use."""
+    fs = 1200000
+    taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
+    offs = pkg.synth.channel_offsets(nch, fs) if nch > 3 else [12345, -250000, 100000][:nch]
+    n = decim * 900 + ntaps + 11
+    iq = pkg.synth.synth_iq(n, fs, list(offs)[:3], seed=decim + ntaps)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 15, want_iq=False)
+    st = eng.stats()
+    eng.close()
+    assert st["kernel_variant"] == 1, st
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, want_iq=(nch == 2))
+    _check(pkg, ora, fs, decim, taps, offs, iq, 5000, want_iq=False)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)

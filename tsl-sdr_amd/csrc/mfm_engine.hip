@@ -150,6 +150,7 @@ struct mfm_engine {
 
     /* matrix-core path (mfm_kernel_mfma.hip) */
     bool use_mfma = false;
+    uint32_t m_row_bytes = 0, m_nstage = 0;
     uint32_t m_ks = 0, m_ot = 0, m_rs = 0, m_plane_bytes = 0, m_lut_off = 0, m_krow_off = 0, m_nrb = 0,
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
     bool m_fixed_planes = false;
@@ -320,8 +321,10 @@ void free_device(mfm_engine *e)
 
 uint32_t input_capacity(uint32_t max_block, uint32_t nr_taps)
 {
-    /* history tail (< nr_taps samples) + block, rounded to 64 samples */
-    return (max_block + nr_taps + 63u) & ~63u;
+    /* history tail (< nr_taps samples) + block + one 16-byte staging chunk of slack (a chunk that starts on the last
+     * real sample must still be readable in place: decimations that are not multiples of 4 start their chunks at any
+     * sample), rounded to 64 samples */
+    return (max_block + nr_taps + 4u + 63u) & ~63u;
 }
 
 int write_state_fresh(mfm_engine *e)
@@ -639,11 +642,18 @@ static int commit_locked(struct mfm_engine *e)
         tapoff[i] = ((i % D) * rs2 + i / D) * 4u;
     }
 
-    /* ---- matrix-core path: usable when rows of 2*D plane bytes are 16-byte multiples, the taps fit
-     *      in registers and every tap splits into two signed bytes ---- */
+    /* ---- matrix-core path.  An LDS row (the D samples between two outputs) is 2*D plane bytes; the B fragments are
+     *      16-byte reads, so rows are padded to 16-byte multiples when D is not a multiple of 8, and the taps (the A
+     *      operand) carry zeros over the padding: decimation 25 of etc/pocsag_rtlsdr.json = rows of 50 + 14 bytes,
+     *      128 taps = 5 full rows + 3 taps = 326 elements -> 6 k-steps instead of 4.  Usable while at least 3/4 of a
+     *      row is samples, the padded filter fits the 16 k-steps of the streaming variant and every tap splits into
+     *      two signed bytes. ---- */
     std::vector<uint32_t> afrag;
     std::vector<int32_t> krow;
-    e->use_mfma = (D % 8 == 0) && T <= 32u * MFM_MFMA_KQ_STREAM_MAX && !(e->cfg.flags & MFM_F_FORCE_DOT2);
+    const uint32_t row_bytes_p = (2u * D + 15u) & ~15u;
+    const uint32_t k_elems = ((T - 1u) / D) * row_bytes_p + 2u * ((T - 1u) % D) + 2u; /* element index of the last tap + 1 */
+    e->use_mfma = 8u * D >= 3u * row_bytes_p && k_elems <= 64u * MFM_MFMA_KQ_STREAM_MAX &&
+                  !(e->cfg.flags & MFM_F_FORCE_DOT2);
     for (const Channel &ch : e->chans) {
         for (uint32_t i = 0; i < T && e->use_mfma; i++) {
             if (ch.cre[i] > 32639 || ch.cim[i] > 32639 || ch.cim[i] < -32639) {
@@ -653,10 +663,11 @@ static int commit_locked(struct mfm_engine *e)
     }
     if (e->use_mfma) {
         uint32_t kq = 1;
-        while (32u * kq < T) {
+        while (64u * kq < k_elems) {
             kq *= 2;
         }
-        const uint32_t row_bytes = 2u * D;
+        const uint32_t row_bytes = row_bytes_p;
+        const bool padded = row_bytes_p != 2u * D;
         /* LDS row stride: an ODD multiple of 32 bytes.  tools/ubench_lds.hip: the B-fragment read pattern (lane
          * 16 kg + n reads 16 bytes at n * rs + 16 kg) runs at the full ds_read_b128 rate for rs = 224 and at 76-81 %
          * of it for 80, 144, 176, 192, 208, 272 - odd multiples of 16 bytes are not enough. */
@@ -667,8 +678,10 @@ static int commit_locked(struct mfm_engine *e)
         uint32_t ot = 0, plane = 0, lds = 0;
         const uint32_t want[] = { 2u * 31u, 31u }; /* new outputs per tile: two 31-output iterations, or one for large decimations */
         for (uint32_t cand : want) {
-            const uint32_t nst = ((cand * D + 32u * kq) + 3u) & ~3u;
-            const uint32_t rows = (2u * nst + row_bytes - 1u) / row_bytes;
+            /* samples a tile stages: its outputs' rows plus the rows the last window reaches into */
+            const uint32_t nst = padded ? ((cand * D + ((64u * kq + row_bytes - 1u) / row_bytes) * D) + 3u) & ~3u
+                                        : ((cand * D + 32u * kq) + 3u) & ~3u;
+            const uint32_t rows = (nst + D - 1u) / D;
             const uint32_t pb = rows * rs_m;
             /* two staging buffers x two byte planes + atan LUT + staging offsets + rotator constants of up to 256 channels */
             const uint32_t nch_t = (nst / 4u + MFM_MFMA_NW * 64u - 1u) / (MFM_MFMA_NW * 64u); /* staging chunks per thread */
@@ -692,6 +705,9 @@ static int commit_locked(struct mfm_engine *e)
             e->use_mfma = false;
         } else {
             e->m_ks = kq;
+            e->m_row_bytes = row_bytes;
+            e->m_nstage = padded ? ((ot * D + ((64u * kq + row_bytes - 1u) / row_bytes) * D) + 3u) & ~3u
+                                 : ((ot * D + 32u * kq) + 3u) & ~3u;
             e->m_ot = ot;
             e->m_rs = rs_m;
             e->m_plane_bytes = plane;
@@ -716,8 +732,10 @@ static int commit_locked(struct mfm_engine *e)
             /* W[2c] = (cr0,-ci0,cr1,-ci1..), W[2c+1] = (ci0,cr0,ci1,cr1..) (filter/complex.h:40-46) */
             const uint32_t K = 64u * kq;
             auto w_at = [&](uint32_t row, uint32_t k) -> int32_t {
-                const uint32_t c = row / 2u, i = k / 2u;
-                if (c >= C || i >= T) {
+                /* element k of a window = byte k % row_bytes of LDS row k / row_bytes: sample (k / row_bytes) * D +
+                 * (k % row_bytes) / 2 while the byte is inside the 2 * D sample bytes, padding (zero tap) behind them */
+                const uint32_t c = row / 2u, pos = k % row_bytes, i = (k / row_bytes) * D + pos / 2u;
+                if (c >= C || pos >= 2u * D || i >= T) {
                     return 0;
                 }
                 const int32_t cr = e->chans[c].cre[i], ci = e->chans[c].cim[i];
@@ -1089,8 +1107,10 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.x_last4 = (e->cap_in - 4u) & ~3u;
             M.kq = e->m_ks;
             M.ot = e->m_ot;
-            M.nstage = ((e->m_ot * D + 32u * e->m_ks) + 3u) & ~3u;
+            M.nstage = e->m_nstage;
             M.rs = e->m_rs;
+            M.row_bytes = e->m_row_bytes;
+            M.split_rows = (D % 4u) != 0u ? 1u : 0u;
             M.plane_bytes = e->m_plane_bytes;
             M.fixed_planes = e->m_fixed_planes ? 1u : 0u;
             M.lut_off = e->m_lut_off;

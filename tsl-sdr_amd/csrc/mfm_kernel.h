@@ -79,6 +79,9 @@ struct mfm_launch_mfma {
                              decimations whose 62-output tile does not fit LDS, one (31) */
     uint32_t nstage;      /* samples staged per tile: ot*D + 32*kq, rounded up to 4 */
     uint32_t rs;          /* LDS row stride in bytes (row = 2*D plane bytes), an odd multiple of 32 */
+    uint32_t row_bytes;   /* plane bytes of a row as the GEMM sees it: 2*D rounded up to 16.  For decimations that are not
+                             multiples of 8 the rows are padded and the taps carry zeros over the padding */
+    uint32_t split_rows;  /* 1: a 4-sample staging chunk can straddle two rows (D % 4 != 0): stored sample by sample */
     uint32_t plane_bytes; /* bytes of one byte-plane in LDS (16-byte multiple) */
     uint32_t fixed_planes; /* 1: the four planes sit MFM_M_PLANE_DIST bytes apart (H0, L0, H1, L1) whatever their size,
                               so the distance is an instruction immediate; 0: packed, plane_bytes apart */

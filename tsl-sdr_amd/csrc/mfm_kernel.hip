@@ -253,14 +253,11 @@ extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, in
 #define MFM_LAUNCH(OPL_, DBG_)                                                                               \
     do {                                                                                                     \
         auto kfn = mfm_channel_kernel<OPL_, DBG_>;                                                           \
-        static uint32_t lds_set_ = 0;                                                                        \
-        if (lds_bytes > lds_set_) {                                                                          \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            if (e_ != hipSuccess) {                                                                          \
-                return e_;                                                                                   \
-            }                                                                                                \
-            lds_set_ = lds_bytes;                                                                            \
+        /* every launch: the attribute is per device (engines on several devices share this code) */         \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        if (e_ != hipSuccess) {                                                                              \
+            return e_;                                                                                       \
         }                                                                                                    \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, *L);                                         \
     } while (0)

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t kg = lane >> 4, n = lane & 15u;
-    const uint32_t D = L.decim, row_bytes = 2u * D, rs = L.rs;
+    /* row_bytes: plane bytes of one LDS row = 2 * D rounded up to 16 (decimations that are not multiples of 8 pad
+     * their rows; the engine lays zero taps over the padding, so what the pad bytes hold does not matter) */
+    const uint32_t D = L.decim, row_bytes = L.row_bytes, rs = L.rs;
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
     /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
@@ -199,8 +201,11 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-        const uint32_t p8 = (tid + (uint32_t)j * MFM_M_NT) * 8u;
-        sta_s[j * MFM_M_NT + tid] = (p8 / row_bytes) * rs + p8 % row_bytes;
+        /* samples 4q .. 4q+3 of the tile: row (4q) / D, 2 plane bytes per sample; bits 16..18: how many of the four
+         * samples still belong to that row (fewer than 4 only when D is not a multiple of 4) */
+        const uint32_t s0 = (tid + (uint32_t)j * MFM_M_NT) * 4u;
+        const uint32_t r0 = s0 / D, c0 = s0 % D;
+        sta_s[j * MFM_M_NT + tid] = (r0 * rs + 2u * c0) | (min(4u, D - c0) << 16);
     }
 
     auto stage_load = [&](uint32_t tile, int j) -> uint4 {
@@ -208,11 +213,20 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
          * the stream start feed nothing but column 0 of tile 0 (replaced by the carried sample), samples
          * past n_avail feed only columns >= n_new (never stored) or zero-padded taps.  Sample indices fit
          * 31 bits (the engine caps a block at 2^30 samples). */
-        int gs = (int)(tile * L.ot * D) + (4 * (int)(tid + (uint32_t)j * MFM_M_NT) - (int)D);
-        gs = gs < 0 ? 0 : gs;
+        const int g0 = (int)(tile * L.ot * D) + (4 * (int)(tid + (uint32_t)j * MFM_M_NT) - (int)D);
+        int gs = g0 < 0 ? 0 : g0;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
         /* uniform base + 32-bit byte offset: one VGPR of address instead of a 64-bit pair */
-        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
+        uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
+        if (L.split_rows) {
+            /* chunks start at any sample here: the one that straddles the stream start (g0 = -1 .. -3) holds real
+             * samples behind the missing ones and must keep them in place (the clamp above moved them) */
+            const int sh = -g0;
+            if (sh > 0 && sh < 4) {
+                v = sh == 1 ? make_uint4(0, v.x, v.y, v.z) : sh == 2 ? make_uint4(0, 0, v.x, v.y) : make_uint4(0, 0, 0, v.x);
+            }
+        }
+        return v;
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
         if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
@@ -222,9 +236,23 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             hi.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
             lo.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) ^ 0x80808080u;
             lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) ^ 0x80808080u;
-            uint8_t *base = smem + buf * buf_bytes + sta_s[j * MFM_M_NT + tid]; /* own slot: no barrier needed */
-            *reinterpret_cast<uint2 *>(base) = hi;
-            *reinterpret_cast<uint2 *>(base + plane_dist) = lo;
+            const uint32_t st = sta_s[j * MFM_M_NT + tid];
+            uint8_t *base = smem + buf * buf_bytes + (st & 0xffffu); /* own slot: no barrier needed */
+            if (!L.split_rows) {
+                *reinterpret_cast<uint2 *>(base) = hi;
+                *reinterpret_cast<uint2 *>(base + plane_dist) = lo;
+            } else {
+                /* the four samples may straddle two rows: sample by sample, two plane bytes each */
+                const uint32_t in_row = st >> 16, hop = rs - 2u * D;
+                const uint32_t h[4] = { hi.x & 0xffffu, hi.x >> 16, hi.y & 0xffffu, hi.y >> 16 };
+                const uint32_t l[4] = { lo.x & 0xffffu, lo.x >> 16, lo.y & 0xffffu, lo.y >> 16 };
+#pragma unroll
+                for (uint32_t m = 0; m < 4; m++) {
+                    uint8_t *p = base + 2u * m + (m >= in_row ? hop : 0u);
+                    *reinterpret_cast<uint16_t *>(p) = (uint16_t)h[m];
+                    *reinterpret_cast<uint16_t *>(p + plane_dist) = (uint16_t)l[m];
+                }
+            }
         }
     };
     /* where column 0 of tile `tile` sits in this lane's two channels' rotator tables */
@@ -642,14 +670,12 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 #define MFM_LAUNCH_T(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_)                                                \
     do {                                                                                                     \
         auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_>;                         \
-        static uint32_t lds_set_ = 0;                                                                        \
-        if (lds_bytes > lds_set_) {                                                                          \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                         \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            if (e_ != hipSuccess) {                                                                          \
-                return e_;                                                                                   \
-            }                                                                                                \
-            lds_set_ = lds_bytes;                                                                            \
+        /* every launch: the attribute is per device, and engines on different devices or threads share this   \
+         * code (a process-wide "already set" flag would skip the second device) */                           \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        if (e_ != hipSuccess) {                                                                              \
+            return e_;                                                                                       \
         }                                                                                                    \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
     } while (0)

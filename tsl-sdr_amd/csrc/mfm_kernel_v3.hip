@@ -190,6 +190,146 @@ static __device__ __forceinline__ bool mfm3_decode_item(const mfm_launch_v3 &L, 
     return item < L.nitems && *chunk < L.nchunks;
 }
 
+/*
+ * Hand-scheduled column group for the decimation-96 / 128-tap geometry (DFIX = 96, KQ = 4, AHM = 0x6: the high-byte tap
+ * plane is zero in k-steps 0 and 3 -> 12 MFMAs).  Why by hand: on gfx950 an MFMA and other VALU work of one SIMD do not
+ * overlap, EXCEPT that up to two instructions behind an MFMA of the same wave issue in its shadow
+ * (profiles/r02_ubench_shadow.txt: 4 x (MFMA, 2 VALU) takes as long as 4 MFMAs; a third instruction per gap and
+ * everything is paid in full).  The compiler does not move inline asm between MFMAs, and in plain C the recombination
+ * costs a third instruction per sum.  So the block interleaves, never more than two per gap:
+ *   - the 12 MFMAs of THIS column group,
+ *   - the B-fragment reads of its k-steps 2, 3 and of k-steps 0, 1 of the NEXT group (those of its own k-steps 0, 1
+ *     were requested by the previous block), with counted s_waitcnt lgkmcnt (LDS returns in order),
+ *   - the recombination + first Q14 rounding of the PREVIOUS group (8 v_lshl_add_u32 + 4 SDWA shifts), which also
+ *     keeps every accumulator three MFMAs away from its first reader (no hazard padding).
+ * Two asm statements per group (an asm statement takes at most 30 operands).  B fragments: X0, X1 = k-steps 0, 1
+ * (in: this group's, out: the next group's, still in flight at exit), Y0, Y1 = k-steps 2, 3.
+ * acc = {hh, md, ll}; accP = the previous group's; tP = its recombined sums, in the end its packed samples in tP[0], tP[2].
+ */
+#define MFM3_MF(d, a, b, c) "v_mfma_i32_16x16x64_i8 %[" #d "], %[" #a "], %[" #b "], " c "\n\t"
+#define MFM3_RD(d, o) "ds_read_b128 %[" #d "], %[lb] offset:%[" #o "]\n\t"
+#define MFM3_LA(d, a, b) "v_lshl_add_u32 %[" #d "], %[" #a "], 8, %[" #b "]\n\t"
+#define MFM3_SH0(d, a) "v_lshrrev_b32_sdwa %[" #d "], 14, %[" #a "] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+#define MFM3_SH1(d, a) "v_lshrrev_b32_sdwa %[" #d "], 14, %[" #a "] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+
+template <bool HAS_PREV, bool HAS_NEXT, int O2, int O3, int N0, int N1>
+static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, const mfm_v4i &al0, const mfm_v4i &al1,
+                                                      const mfm_v4i &al2, const mfm_v4i &al3, const mfm_v4i &ah1,
+                                                      const mfm_v4i &ah2, mfm_v4i &x0h, mfm_v4i &x0l, mfm_v4i &x1h,
+                                                      mfm_v4i &x1l, const mfm_v4i (&accP)[3], mfm_v4i (&acc)[3],
+                                                      uint32_t (&tP)[4])
+{
+    constexpr int LO = 16384; /* high-byte plane -> low-byte plane */
+    mfm_v4i hh, md, ll, y0h, y0l, y1h, y1l;
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (HAS_PREV) {
+        asm volatile(
+            "ds_read_b128 %[ll], %[ka]\n\t"                                  /* 128 * sum(W) + 8192 of the lane's rows */
+            MFM3_RD(y0h, o2) MFM3_RD(y0l, o2l)
+            "s_waitcnt lgkmcnt(3)\n\t"                                       /* x0, x1 (requested by the previous block) */
+            MFM3_MF(md, al0, x0h, "0")
+            "s_waitcnt lgkmcnt(2)\n\t"
+            MFM3_MF(ll, al0, x0l, "%[ll]")
+            MFM3_RD(y1h, o3) MFM3_RD(y1l, o3l)
+            MFM3_MF(hh, ah1, x1h, "0")
+            MFM3_LA(t0, h0, m0) MFM3_LA(t1, h1, m1)
+            MFM3_MF(md, ah1, x1l, "%[md]")
+            MFM3_LA(t2, h2, m2) MFM3_LA(t3, h3, m3)
+            MFM3_MF(ll, al1, x1l, "%[ll]")
+            MFM3_MF(md, al1, x1h, "%[md]")
+            : [hh] "=&v"(hh), [md] "=&v"(md), [ll] "=&v"(ll), [y0h] "=&v"(y0h), [y0l] "=&v"(y0l), [y1h] "=&v"(y1h),
+              [y1l] "=&v"(y1l), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+            : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [x0h] "v"(x0h), [x0l] "v"(x0l),
+              [x1h] "v"(x1h), [x1l] "v"(x1l), [h0] "v"(accP[0][0]), [h1] "v"(accP[0][1]), [h2] "v"(accP[0][2]),
+              [h3] "v"(accP[0][3]), [m0] "v"(accP[1][0]), [m1] "v"(accP[1][1]), [m2] "v"(accP[1][2]), [m3] "v"(accP[1][3]),
+              [o2] "n"(O2), [o2l] "n"(O2 + LO), [o3] "n"(O3), [o3l] "n"(O3 + LO)
+            : "memory");
+    } else {
+        asm volatile(
+            "ds_read_b128 %[ll], %[ka]\n\t"
+            MFM3_RD(y0h, o2) MFM3_RD(y0l, o2l)
+            "s_waitcnt lgkmcnt(3)\n\t"
+            MFM3_MF(md, al0, x0h, "0")
+            "s_waitcnt lgkmcnt(2)\n\t"
+            MFM3_MF(ll, al0, x0l, "%[ll]")
+            MFM3_RD(y1h, o3) MFM3_RD(y1l, o3l)
+            MFM3_MF(hh, ah1, x1h, "0")
+            MFM3_MF(md, ah1, x1l, "%[md]")
+            MFM3_MF(ll, al1, x1l, "%[ll]")
+            MFM3_MF(md, al1, x1h, "%[md]")
+            : [hh] "=&v"(hh), [md] "=&v"(md), [ll] "=&v"(ll), [y0h] "=&v"(y0h), [y0l] "=&v"(y0l), [y1h] "=&v"(y1h),
+              [y1l] "=&v"(y1l)
+            : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [x0h] "v"(x0h), [x0l] "v"(x0l),
+              [x1h] "v"(x1h), [x1l] "v"(x1l), [o2] "n"(O2), [o2l] "n"(O2 + LO), [o3] "n"(O3), [o3l] "n"(O3 + LO)
+            : "memory");
+    }
+    /* second half: k-steps 2, 3; the next group's k-steps 0, 1 go into x0, x1 (free since MFMAs 2 and 6) */
+    if (HAS_PREV && HAS_NEXT) {
+        asm volatile(
+            MFM3_RD(x0h, n0) MFM3_RD(x0l, n0l)
+            "s_waitcnt lgkmcnt(4)\n\t"                                       /* y0 (k-step 2) */
+            MFM3_MF(hh, ah2, y0h, "%[hh]")
+            MFM3_LA(t0, t0, l0) MFM3_LA(t1, t1, l1)
+            MFM3_MF(md, ah2, y0l, "%[md]")
+            MFM3_LA(t2, t2, l2) MFM3_LA(t3, t3, l3)
+            MFM3_MF(ll, al2, y0l, "%[ll]")
+            MFM3_RD(x1h, n1) MFM3_RD(x1l, n1l)
+            MFM3_MF(md, al2, y0h, "%[md]")
+            "s_waitcnt lgkmcnt(4)\n\t"                                       /* y1 (k-step 3) */
+            MFM3_MF(ll, al3, y1l, "%[ll]")
+            MFM3_SH0(t0, t0) MFM3_SH0(t2, t2)
+            MFM3_MF(md, al3, y1h, "%[md]")
+            MFM3_SH1(t0, t1) MFM3_SH1(t2, t3)
+            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3),
+              [x0h] "=&v"(x0h), [x0l] "=&v"(x0l), [x1h] "=&v"(x1h), [x1l] "=&v"(x1l)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [y0h] "v"(y0h), [y0l] "v"(y0l), [y1h] "v"(y1h),
+              [y1l] "v"(y1l), [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]), [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]),
+              [n0] "n"(N0), [n0l] "n"(N0 + LO), [n1] "n"(N1), [n1l] "n"(N1 + LO)
+            : "memory");
+    } else if (HAS_NEXT) {
+        asm volatile(
+            MFM3_RD(x0h, n0) MFM3_RD(x0l, n0l)
+            "s_waitcnt lgkmcnt(4)\n\t"
+            MFM3_MF(hh, ah2, y0h, "%[hh]")
+            MFM3_MF(md, ah2, y0l, "%[md]")
+            MFM3_MF(ll, al2, y0l, "%[ll]")
+            MFM3_RD(x1h, n1) MFM3_RD(x1l, n1l)
+            MFM3_MF(md, al2, y0h, "%[md]")
+            "s_waitcnt lgkmcnt(4)\n\t"
+            MFM3_MF(ll, al3, y1l, "%[ll]")
+            MFM3_MF(md, al3, y1h, "%[md]")
+            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [x0h] "=&v"(x0h), [x0l] "=&v"(x0l), [x1h] "=&v"(x1h), [x1l] "=&v"(x1l)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [y0h] "v"(y0h), [y0l] "v"(y0l), [y1h] "v"(y1h),
+              [y1l] "v"(y1l), [n0] "n"(N0), [n0l] "n"(N0 + LO), [n1] "n"(N1), [n1l] "n"(N1 + LO)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_waitcnt lgkmcnt(2)\n\t"                                       /* y0; nothing is requested for a next group */
+            MFM3_MF(hh, ah2, y0h, "%[hh]")
+            MFM3_LA(t0, t0, l0) MFM3_LA(t1, t1, l1)
+            MFM3_MF(md, ah2, y0l, "%[md]")
+            MFM3_LA(t2, t2, l2) MFM3_LA(t3, t3, l3)
+            MFM3_MF(ll, al2, y0l, "%[ll]")
+            MFM3_MF(md, al2, y0h, "%[md]")
+            "s_waitcnt lgkmcnt(0)\n\t"
+            MFM3_MF(ll, al3, y1l, "%[ll]")
+            MFM3_SH0(t0, t0) MFM3_SH0(t2, t2)
+            MFM3_MF(md, al3, y1h, "%[md]")
+            MFM3_SH1(t0, t1) MFM3_SH1(t2, t3)
+            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3)
+            : [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [y0h] "v"(y0h), [y0l] "v"(y0l), [y1h] "v"(y1h), [y1l] "v"(y1l),
+              [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]), [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3])
+            : "memory");
+    }
+    acc[0] = hh;
+    acc[1] = md;
+    acc[2] = ll;
+    tP[0] = t0;
+    tP[1] = t1;
+    tP[2] = t2;
+    tP[3] = t3;
+}
+
 /* LDS row stride of a decimation: 2 * D plane bytes rounded up to an odd multiple of 32 (the engine's rule) */
 static constexpr uint32_t mfm3_row_stride(uint32_t decim)
 {
