@@ -7,5 +7,5 @@ for x in "$@"; do
 done
 wait
 for x in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/exp/libexp_$x.so $B/mfm_kernel.o $B/${KEEP:-mfm_kernel_mfma}.o tools/exp/k_$x.o $B/mfm_resampler.o $B/mfm_f32.o $B/mfm_mm.o $B/mfm_pocsag.o $B/mfm_engine.o $B/mfm_taps.o -lm -lpthread
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/exp/libexp_$x.so $B/mfm_kernel.o $B/${KEEP:-mfm_kernel_mfma}.o tools/exp/k_$x.o $B/mfm_resampler.o $B/mfm_f32.o $B/mfm_mm.o $B/mfm_pocsag.o $B/mfm_engine.o $B/mfm_group.o $B/mfm_taps.o -lm -lpthread -ldl
 done

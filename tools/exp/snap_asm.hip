@@ -25,8 +25,8 @@
  */
 #include <hip/hip_runtime.h>
 
-#include "mfm_kernel.h"
-#include "mfm_numerics.h"
+#include "../../tsl-sdr_amd/csrc/mfm_kernel.h"
+#include "../../tsl-sdr_amd/csrc/mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 

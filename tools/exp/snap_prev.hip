@@ -25,8 +25,8 @@
  */
 #include <hip/hip_runtime.h>
 
-#include "mfm_kernel.h"
-#include "mfm_numerics.h"
+#include "../../tsl-sdr_amd/csrc/mfm_kernel.h"
+#include "../../tsl-sdr_amd/csrc/mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 
@@ -215,113 +215,109 @@ static __device__ __forceinline__ bool mfm3_decode_item(const mfm_launch_v3 &L, 
 template <bool HAS_PREV, bool HAS_NEXT, int O2, int O3, int N0, int N1>
 static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, const mfm_v4i &al0, const mfm_v4i &al1,
                                                       const mfm_v4i &al2, const mfm_v4i &al3, const mfm_v4i &ah1,
-                                                      const mfm_v4i &ah2, mfm_v4i &b0h, mfm_v4i &b0l, mfm_v4i &b1h,
-                                                      mfm_v4i &b1l, mfm_v4i &b2h, mfm_v4i &b2l, const mfm_v4i (&accP)[3],
-                                                      mfm_v4i (&acc)[3], uint32_t (&tP)[4])
+                                                      const mfm_v4i &ah2, mfm_v4i &x0h, mfm_v4i &x0l, mfm_v4i &x1h,
+                                                      mfm_v4i &x1l, const mfm_v4i (&accP)[3], mfm_v4i (&acc)[3],
+                                                      uint32_t (&tP)[4])
 {
-    /* Three fragment buffers (h + l each), rotating: in: b0 = k-step 0, b1 = k-step 1 of this group (requested by the
-     * previous block); b2 takes k-step 2, b0 k-step 3 once k-step 0 is through; out: b1 = k-step 0, b2 = k-step 1 of the
-     * next group, still in flight.  The caller rotates (b0, b1, b2) <- (b1, b2, b0) from group to group. */
     constexpr int LO = 16384; /* high-byte plane -> low-byte plane */
-    mfm_v4i hh, md, ll;
+    mfm_v4i hh, md, ll, y0h, y0l, y1h, y1l;
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (HAS_PREV) {
         asm volatile(
             "ds_read_b128 %[ll], %[ka]\n\t"                                  /* 128 * sum(W) + 8192 of the lane's rows */
-            MFM3_RD(b2h, o2) MFM3_RD(b2l, o2l)
-            "s_waitcnt lgkmcnt(3)\n\t"                                       /* b0, b1 (requested by the previous block) */
-            MFM3_MF(md, al0, b0h, "0")
+            MFM3_RD(y0h, o2) MFM3_RD(y0l, o2l)
+            "s_waitcnt lgkmcnt(3)\n\t"                                       /* x0, x1 (requested by the previous block) */
+            MFM3_MF(md, al0, x0h, "0")
             "s_waitcnt lgkmcnt(2)\n\t"
-            MFM3_MF(ll, al0, b0l, "%[ll]")
-            MFM3_RD(b0h, o3) MFM3_RD(b0l, o3l)                               /* k-step 3 replaces k-step 0 */
-            MFM3_MF(hh, ah1, b1h, "0")
+            MFM3_MF(ll, al0, x0l, "%[ll]")
+            MFM3_RD(y1h, o3) MFM3_RD(y1l, o3l)
+            MFM3_MF(hh, ah1, x1h, "0")
             MFM3_LA(t0, h0, m0) MFM3_LA(t1, h1, m1)
-            MFM3_MF(md, ah1, b1l, "%[md]")
+            MFM3_MF(md, ah1, x1l, "%[md]")
             MFM3_LA(t2, h2, m2) MFM3_LA(t3, h3, m3)
-            MFM3_MF(ll, al1, b1l, "%[ll]")
-            MFM3_MF(md, al1, b1h, "%[md]")
-            : [hh] "=&v"(hh), [md] "=&v"(md), [ll] "=&v"(ll), [b2h] "=&v"(b2h), [b2l] "=&v"(b2l), [b0h] "+v"(b0h),
-              [b0l] "+v"(b0l), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-            : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [b1h] "v"(b1h), [b1l] "v"(b1l),
-              [h0] "v"(accP[0][0]), [h1] "v"(accP[0][1]), [h2] "v"(accP[0][2]), [h3] "v"(accP[0][3]), [m0] "v"(accP[1][0]),
-              [m1] "v"(accP[1][1]), [m2] "v"(accP[1][2]), [m3] "v"(accP[1][3]), [o2] "n"(O2), [o2l] "n"(O2 + LO),
-              [o3] "n"(O3), [o3l] "n"(O3 + LO)
+            MFM3_MF(ll, al1, x1l, "%[ll]")
+            MFM3_MF(md, al1, x1h, "%[md]")
+            : [hh] "=&v"(hh), [md] "=&v"(md), [ll] "=&v"(ll), [y0h] "=&v"(y0h), [y0l] "=&v"(y0l), [y1h] "=&v"(y1h),
+              [y1l] "=&v"(y1l), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+            : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [x0h] "v"(x0h), [x0l] "v"(x0l),
+              [x1h] "v"(x1h), [x1l] "v"(x1l), [h0] "v"(accP[0][0]), [h1] "v"(accP[0][1]), [h2] "v"(accP[0][2]),
+              [h3] "v"(accP[0][3]), [m0] "v"(accP[1][0]), [m1] "v"(accP[1][1]), [m2] "v"(accP[1][2]), [m3] "v"(accP[1][3]),
+              [o2] "n"(O2), [o2l] "n"(O2 + LO), [o3] "n"(O3), [o3l] "n"(O3 + LO)
             : "memory");
     } else {
         asm volatile(
             "ds_read_b128 %[ll], %[ka]\n\t"
-            MFM3_RD(b2h, o2) MFM3_RD(b2l, o2l)
+            MFM3_RD(y0h, o2) MFM3_RD(y0l, o2l)
             "s_waitcnt lgkmcnt(3)\n\t"
-            MFM3_MF(md, al0, b0h, "0")
+            MFM3_MF(md, al0, x0h, "0")
             "s_waitcnt lgkmcnt(2)\n\t"
-            MFM3_MF(ll, al0, b0l, "%[ll]")
-            MFM3_RD(b0h, o3) MFM3_RD(b0l, o3l)
-            MFM3_MF(hh, ah1, b1h, "0")
-            MFM3_MF(md, ah1, b1l, "%[md]")
-            MFM3_MF(ll, al1, b1l, "%[ll]")
-            MFM3_MF(md, al1, b1h, "%[md]")
-            : [hh] "=&v"(hh), [md] "=&v"(md), [ll] "=&v"(ll), [b2h] "=&v"(b2h), [b2l] "=&v"(b2l), [b0h] "+v"(b0h),
-              [b0l] "+v"(b0l)
-            : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [b1h] "v"(b1h), [b1l] "v"(b1l),
-              [o2] "n"(O2), [o2l] "n"(O2 + LO), [o3] "n"(O3), [o3l] "n"(O3 + LO)
+            MFM3_MF(ll, al0, x0l, "%[ll]")
+            MFM3_RD(y1h, o3) MFM3_RD(y1l, o3l)
+            MFM3_MF(hh, ah1, x1h, "0")
+            MFM3_MF(md, ah1, x1l, "%[md]")
+            MFM3_MF(ll, al1, x1l, "%[ll]")
+            MFM3_MF(md, al1, x1h, "%[md]")
+            : [hh] "=&v"(hh), [md] "=&v"(md), [ll] "=&v"(ll), [y0h] "=&v"(y0h), [y0l] "=&v"(y0l), [y1h] "=&v"(y1h),
+              [y1l] "=&v"(y1l)
+            : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [x0h] "v"(x0h), [x0l] "v"(x0l),
+              [x1h] "v"(x1h), [x1l] "v"(x1l), [o2] "n"(O2), [o2l] "n"(O2 + LO), [o3] "n"(O3), [o3l] "n"(O3 + LO)
             : "memory");
     }
-    /* second half: k-steps 2, 3; the next group's k-step 0 goes into b1 (free since MFMA 6), its k-step 1 into b2 (free
-     * behind MFMA 10) */
+    /* second half: k-steps 2, 3; the next group's k-steps 0, 1 go into x0, x1 (free since MFMAs 2 and 6) */
     if (HAS_PREV && HAS_NEXT) {
         asm volatile(
-            MFM3_RD(b1h, n0) MFM3_RD(b1l, n0l)
-            "s_waitcnt lgkmcnt(4)\n\t"                                       /* b2 = k-step 2 */
-            MFM3_MF(hh, ah2, b2h, "%[hh]")
+            MFM3_RD(x0h, n0) MFM3_RD(x0l, n0l)
+            "s_waitcnt lgkmcnt(4)\n\t"                                       /* y0 (k-step 2) */
+            MFM3_MF(hh, ah2, y0h, "%[hh]")
             MFM3_LA(t0, t0, l0) MFM3_LA(t1, t1, l1)
-            MFM3_MF(md, ah2, b2l, "%[md]")
+            MFM3_MF(md, ah2, y0l, "%[md]")
             MFM3_LA(t2, t2, l2) MFM3_LA(t3, t3, l3)
-            MFM3_MF(ll, al2, b2l, "%[ll]")
-            MFM3_MF(md, al2, b2h, "%[md]")
-            MFM3_RD(b2h, n1) MFM3_RD(b2l, n1l)
-            "s_waitcnt lgkmcnt(4)\n\t"                                       /* b0 = k-step 3 */
-            MFM3_MF(ll, al3, b0l, "%[ll]")
+            MFM3_MF(ll, al2, y0l, "%[ll]")
+            MFM3_RD(x1h, n1) MFM3_RD(x1l, n1l)
+            MFM3_MF(md, al2, y0h, "%[md]")
+            "s_waitcnt lgkmcnt(4)\n\t"                                       /* y1 (k-step 3) */
+            MFM3_MF(ll, al3, y1l, "%[ll]")
             MFM3_SH0(t0, t0) MFM3_SH0(t2, t2)
-            MFM3_MF(md, al3, b0h, "%[md]")
+            MFM3_MF(md, al3, y1h, "%[md]")
             MFM3_SH1(t0, t1) MFM3_SH1(t2, t3)
             : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3),
-              [b1h] "=&v"(b1h), [b1l] "=&v"(b1l), [b2h] "+v"(b2h), [b2l] "+v"(b2l)
-            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0h] "v"(b0h), [b0l] "v"(b0l),
-              [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]), [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]),
+              [x0h] "=&v"(x0h), [x0l] "=&v"(x0l), [x1h] "=&v"(x1h), [x1l] "=&v"(x1l)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [y0h] "v"(y0h), [y0l] "v"(y0l), [y1h] "v"(y1h),
+              [y1l] "v"(y1l), [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]), [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]),
               [n0] "n"(N0), [n0l] "n"(N0 + LO), [n1] "n"(N1), [n1l] "n"(N1 + LO)
             : "memory");
     } else if (HAS_NEXT) {
         asm volatile(
-            MFM3_RD(b1h, n0) MFM3_RD(b1l, n0l)
+            MFM3_RD(x0h, n0) MFM3_RD(x0l, n0l)
             "s_waitcnt lgkmcnt(4)\n\t"
-            MFM3_MF(hh, ah2, b2h, "%[hh]")
-            MFM3_MF(md, ah2, b2l, "%[md]")
-            MFM3_MF(ll, al2, b2l, "%[ll]")
-            MFM3_MF(md, al2, b2h, "%[md]")
-            MFM3_RD(b2h, n1) MFM3_RD(b2l, n1l)
+            MFM3_MF(hh, ah2, y0h, "%[hh]")
+            MFM3_MF(md, ah2, y0l, "%[md]")
+            MFM3_MF(ll, al2, y0l, "%[ll]")
+            MFM3_RD(x1h, n1) MFM3_RD(x1l, n1l)
+            MFM3_MF(md, al2, y0h, "%[md]")
             "s_waitcnt lgkmcnt(4)\n\t"
-            MFM3_MF(ll, al3, b0l, "%[ll]")
-            MFM3_MF(md, al3, b0h, "%[md]")
-            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [b1h] "=&v"(b1h), [b1l] "=&v"(b1l), [b2h] "+v"(b2h), [b2l] "+v"(b2l)
-            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0h] "v"(b0h), [b0l] "v"(b0l),
-              [n0] "n"(N0), [n0l] "n"(N0 + LO), [n1] "n"(N1), [n1l] "n"(N1 + LO)
+            MFM3_MF(ll, al3, y1l, "%[ll]")
+            MFM3_MF(md, al3, y1h, "%[md]")
+            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [x0h] "=&v"(x0h), [x0l] "=&v"(x0l), [x1h] "=&v"(x1h), [x1l] "=&v"(x1l)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [y0h] "v"(y0h), [y0l] "v"(y0l), [y1h] "v"(y1h),
+              [y1l] "v"(y1l), [n0] "n"(N0), [n0l] "n"(N0 + LO), [n1] "n"(N1), [n1l] "n"(N1 + LO)
             : "memory");
     } else {
         asm volatile(
-            "s_waitcnt lgkmcnt(2)\n\t"                                       /* b2; nothing is requested for a next group */
-            MFM3_MF(hh, ah2, b2h, "%[hh]")
+            "s_waitcnt lgkmcnt(2)\n\t"                                       /* y0; nothing is requested for a next group */
+            MFM3_MF(hh, ah2, y0h, "%[hh]")
             MFM3_LA(t0, t0, l0) MFM3_LA(t1, t1, l1)
-            MFM3_MF(md, ah2, b2l, "%[md]")
+            MFM3_MF(md, ah2, y0l, "%[md]")
             MFM3_LA(t2, t2, l2) MFM3_LA(t3, t3, l3)
-            MFM3_MF(ll, al2, b2l, "%[ll]")
-            MFM3_MF(md, al2, b2h, "%[md]")
+            MFM3_MF(ll, al2, y0l, "%[ll]")
+            MFM3_MF(md, al2, y0h, "%[md]")
             "s_waitcnt lgkmcnt(0)\n\t"
-            MFM3_MF(ll, al3, b0l, "%[ll]")
+            MFM3_MF(ll, al3, y1l, "%[ll]")
             MFM3_SH0(t0, t0) MFM3_SH0(t2, t2)
-            MFM3_MF(md, al3, b0h, "%[md]")
+            MFM3_MF(md, al3, y1h, "%[md]")
             MFM3_SH1(t0, t1) MFM3_SH1(t2, t3)
             : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3)
-            : [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b2h] "v"(b2h), [b2l] "v"(b2l), [b0h] "v"(b0h), [b0l] "v"(b0l),
+            : [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [y0h] "v"(y0h), [y0l] "v"(y0l), [y1h] "v"(y1h), [y1l] "v"(y1l),
               [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]), [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3])
             : "memory");
     }
@@ -608,56 +604,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 }
             }
 
-            if constexpr (DFIX == 96 && KQ == 4 && AHM == 0x6) {
-                /* ---- the four column groups as hand-scheduled blocks (mfm3_group_d96): software pipelined by one group,
-                 *      B fragments requested two k-steps ahead ---- */
-                constexpr int RS = (int)mfm3_row_stride(96), SP = 4096;
-                /* ofs[g][kq] as compile-time constants: cross = (0, 0, 0, 1), within = (0, 64, 128, 0) */
-#define MFM3_OFS(g, kq) ((((g) + ((kq) == 3 ? 1 : 0)) & 3) * SP + (1 + (((g) + ((kq) == 3 ? 1 : 0)) >> 2)) * RS + ((kq) == 3 ? 0 : 64 * (kq)))
-                const uint32_t ka = (uint32_t)(uintptr_t)krow_s;
-                mfm_v4i ph, pl, qh, ql, rh = { 0, 0, 0, 0 }, rl = { 0, 0, 0, 0 }; /* three rotating fragment buffers */
-                /* k-steps 0, 1 of group 0 (the blocks request those of the following group themselves) */
-                asm volatile("ds_read_b128 %[x0h], %[lb] offset:%[a]\n\t"
-                             "ds_read_b128 %[x0l], %[lb] offset:%[al]\n\t"
-                             "ds_read_b128 %[x1h], %[lb] offset:%[b]\n\t"
-                             "ds_read_b128 %[x1l], %[lb] offset:%[bl]\n\t"
-                             : [x0h] "=&v"(ph), [x0l] "=&v"(pl), [x1h] "=&v"(qh), [x1l] "=&v"(ql)
-                             : [lb] "v"(lb), [a] "n"(MFM3_OFS(0, 0)), [al] "n"(MFM3_OFS(0, 0) + 16384), [b] "n"(MFM3_OFS(0, 1)),
-                               [bl] "n"(MFM3_OFS(0, 1) + 16384)
-                             : "memory");
-                mfm_v4i acc0[3], acc1[3];
-                uint32_t t[4];
-                const mfm_v4i none[3] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-                mfm3_group_d96<false, true, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, none, acc0, t);
-                mfm3_group_d96<true, true, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qh, ql, rh, rl, ph, pl, acc0, acc1, t);
-                f[0][0] = t[0];
-                f[0][1] = t[2];
-                mfm3_group_d96<true, true, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rh, rl, ph, pl, qh, ql, acc1, acc0, t);
-                f[1][0] = t[0];
-                f[1][1] = t[2];
-                mfm3_group_d96<true, false, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, acc0, acc1, t);
-                f[2][0] = t[0];
-                f[2][1] = t[2];
-                /* rotator entries of this tile, four consecutive ones per channel: requested at the end of the matrix phase
-                 * (its registers are all taken until here), needed behind the staging stores and the barrier */
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
-                    rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
-                    rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                settle();
-                finish(acc1, f[3]);
-#undef MFM3_OFS
-            } else {
-            /* The four column groups, one after the other (run-time geometry; the hand-scheduled blocks above are the
-             * software-pipelined form for the fixed one). */
+            /* The four column groups.  (Software pipelining them by one - the recombination of group g - 1 issued between
+             * the MFMAs of group g - was tried: the scheduler does not move inline asm between MFMAs, and written in
+             * plain C the recombination costs a third instruction per sum; it needs a hand-scheduled asm block.) */
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 uint32_t og[KQ];
@@ -678,7 +627,6 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
             }
         }
 
