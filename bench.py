@@ -296,11 +296,13 @@ def main():
                         "frac": dot2_per_launch / (k_ms * 1e-3) / VALU_DOT2_PEAK}
     msamp = args.steps * block / dt / 1e6
 
-    # HBM bytes per launch from the committed PMC passes (profiles/): only quoted for the exact workload they
-    # were collected on
+    # HBM bytes per launch from the committed PMC passes (profiles/, tools/prof_r02.sh: FETCH_SIZE and WRITE_SIZE each in
+    # its own rocprofv3 --pmc run, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): only quoted for the
+    # exact workload and kernel they were collected on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if mfma and world == 1 and args.block_log2 == 26 and cpg == 64 and args.config == "cfg2_64ch" and os.path.exists(tpath):
+    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and args.config == "cfg2_64ch" \
+            and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
 
     if rank == 0:
