@@ -91,6 +91,13 @@ def lib():
         o.mfmo_pocsag_msgdec_free.restype = None
         o.mfmo_pocsag_msgdec_batch.argtypes = [C.c_void_p, u32p, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t,
                                                C.POINTER(C.c_size_t)]
+        o.mfmo_flex_new.restype = C.c_void_p
+        o.mfmo_flex_free.argtypes = [C.c_void_p]
+        o.mfmo_flex_free.restype = None
+        o.mfmo_flex_on_pcm.argtypes = [C.c_void_p, _i16p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        o.mfmo_flex_phase_process.argtypes = [u32p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.c_void_p,
+                                              C.c_size_t, C.POINTER(C.c_size_t)]
         o.mfmo_mm_init.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
         o.mfmo_mm_init.restype = None
         o.mfmo_mm_process.argtypes = [C.c_void_p, _i16p, C.c_size_t, _i16p, C.c_size_t]
@@ -349,6 +356,70 @@ class PocsagMsgDec:
 
     def __del__(self):
         self.close()
+
+
+# ---- FLEX (oracle/flex_oracle.c) ---------------------------------------------------------------------------
+
+# struct mfmo_flex_event / struct mfmo_flex_msg
+FLEX_EVENT_DTYPE = np.dtype([("type", "<u4"), ("coding", "<u4"), ("sample", "<u8"), ("sync_sample", "<u8"), ("eye", "<u4"),
+                             ("a", "<u4"), ("b", "<u4"), ("inv_a", "<u4"), ("fiw_raw", "<u4"), ("fiw", "<u4"),
+                             ("fiw_rc", "<u4"), ("sample_range", "<i4"), ("sample_delta", "<i4"), ("cycle", "<u4"),
+                             ("frame", "<u4"), ("pad", "<u4"), ("words", "<u4", (4, 88))])
+FLEX_MSG_DTYPE = np.dtype([("kind", "<u4"), ("baud", "<u4"), ("phase", "<u4"), ("cycle", "<u4"), ("frame", "<u4"),
+                           ("aux0", "<u4"), ("aux1", "<u4"), ("aux2", "<u4"), ("capcode", "<u8"), ("sample", "<u8"),
+                           ("len", "<u4"), ("pad", "<u4"), ("text", "S256")])
+FLEX_EV_FRAME, FLEX_EV_BAD_BAUD, FLEX_EV_BAD_FIW = 1, 2, 3
+FLEX_MSG_ALNUM, FLEX_MSG_NUM, FLEX_MSG_SIV = 1, 2, 3
+
+
+def flex_msg_tuple(m, with_sample=True):
+    """(kind, baud, phase, cycle, frame, aux0, aux1, aux2, capcode, text[, sample])"""
+    n = int(m["len"])
+    raw = bytes(m["text"]).ljust(256, b"\0")[:n]
+    t = (int(m["kind"]), int(m["baud"]), int(m["phase"]), int(m["cycle"]), int(m["frame"]), int(m["aux0"]), int(m["aux1"]),
+         int(m["aux2"]), int(m["capcode"]), raw)
+    return t + (int(m["sample"]),) if with_sample else t
+
+
+class Flex:
+    """Oracle FLEX decoder for one channel: feed(pcm) -> (events, messages) of that call."""
+
+    def __init__(self):
+        self.h = lib().mfmo_flex_new()
+        assert self.h
+
+    def feed(self, pcm):
+        x = np.ascontiguousarray(pcm, dtype=np.int16)
+        cap_ev = x.size // 1000 + 8
+        cap_ms = 64 * (x.size // 28000 + 2)
+        ev = np.zeros(cap_ev, FLEX_EVENT_DTYPE)
+        ms = np.zeros(cap_ms, FLEX_MSG_DTYPE)
+        nev, nms = C.c_size_t(0), C.c_size_t(0)
+        if x.size:
+            lib().mfmo_flex_on_pcm(self.h, p16(x), x.size, ev.ctypes.data, cap_ev, C.byref(nev), ms.ctypes.data, cap_ms,
+                                   C.byref(nms))
+        assert nev.value <= cap_ev and nms.value <= cap_ms
+        return ev[:nev.value].copy(), [flex_msg_tuple(m) for m in ms[:nms.value]]
+
+    def close(self):
+        if self.h:
+            lib().mfmo_flex_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def flex_phase_process(words, coding, phase, cycle, frame, sample=0):
+    """oracle message layer on the 88 words of one phase -> (words after the in-place corrections, messages)"""
+    w = np.ascontiguousarray(words, dtype=np.uint32).copy()
+    assert w.size == 88
+    ms = np.zeros(128, FLEX_MSG_DTYPE)
+    n = C.c_size_t(0)
+    r = lib().mfmo_flex_phase_process(w.ctypes.data_as(C.POINTER(C.c_uint32)), coding, phase, cycle, frame, sample,
+                                      ms.ctypes.data, 128, C.byref(n))
+    assert r == 0 and n.value <= 128
+    return w, [flex_msg_tuple(m) for m in ms[:n.value]]
 
 
 def unpack_bytes(raw, fmt):

@@ -218,3 +218,211 @@ def pocsag_fm_iq(bits, baud, sample_rate_hz, carrier_hz, deviation_hz=4500.0, am
     out[:, 0] = np.clip(np.round(i), -32768, 32767)
     out[:, 1] = np.clip(np.round(q), -32768, 32767)
     return out
+
+
+# ---- synthetic FLEX ------------------------------------------------------------
+# Written from the published frame layout, not from the decoder: 115.2 ms sync 1 at 1600 bit/s 2-FSK (32 bits of
+# 1010.., A = mode code + 0x5939, B = 0x5555, inverted A, the frame information word), 25 ms sync 2 at the frame's
+# own symbol rate, then 11 blocks of 160 ms; every block carries 8 words per phase, bit-interleaved, words LSB
+# first.  Words use the same BCH(31,21) + parity layout as POCSAG (info = bits 0..20).  Numbers that have to agree
+# with the reference are cited (pager/pager_flex.c).
+
+FLEX_RATE = 16000                                   # pager_flex_priv.h:231: "The input for this must always be a 16kHz signal"
+FLEX_CODINGS = (                                    # pager_flex.c:46-96
+    dict(seq_a=0x78F3, baud=1600, levels=2, phases=(0,), sym_rate=1600, sync2_dots=4),
+    dict(seq_a=0x84E7, baud=3200, levels=2, phases=(0, 2), sym_rate=3200, sync2_dots=24),
+    dict(seq_a=0x4F97, baud=3200, levels=4, phases=(0, 2), sym_rate=1600, sync2_dots=12),
+    dict(seq_a=0x215F, baud=6400, levels=4, phases=(0, 1, 2, 3), sym_rate=3200, sync2_dots=32),
+)
+FLEX_NUM_TABLE = "0123456789XU -]["                  # pager_flex.c:686-704
+
+flex_codeword = pocsag_codeword
+
+
+def flex_checksummed(info21):
+    """set bits 0..3 so that the six nibbles of the 21-bit word add up to 15 modulo 16 (pager_flex.c:107-119)"""
+    w = int(info21) & 0x1FFFF0
+    s = sum((w >> (4 * n)) & 0xF for n in range(6))
+    return w | ((0xF - s) & 0xF)
+
+
+def flex_fiw(cycle, frame, roaming=0, repeat=0, traffic=0):
+    return flex_codeword(flex_checksummed((cycle & 0xF) << 4 | (frame & 0x7F) << 8 | (roaming & 1) << 15 | (repeat & 1) << 16
+                                          | (traffic & 0xF) << 17))
+
+
+def flex_biw(vsw, eob=0, priority=0, carry=0, collapse=0):
+    return flex_codeword(flex_checksummed((priority & 0xF) << 4 | (eob & 3) << 8 | (vsw & 0x3F) << 10 | (carry & 3) << 16
+                                          | (collapse & 7) << 18))
+
+
+def flex_extra_biw(function, payload14):
+    return flex_codeword(flex_checksummed((function & 7) << 4 | (payload14 & 0x3FFF) << 7))
+
+
+def _flex_pack(bits):
+    """bit list -> 21-bit info values, LSB first"""
+    out = []
+    for i in range(0, len(bits), 21):
+        chunk = bits[i:i + 21]
+        out.append(sum(int(b) << k for k, b in enumerate(chunk)))
+    return out
+
+
+def flex_alnum_body(text, seq=3, fragment=False, maildrop=False, signature=0x2A):
+    """message words of an alphanumeric page: header, then 3 characters per word; the first character slot of an
+    initial fragment (seq 3) carries the signature.  ETX (0x03) fills the last word."""
+    head = (int(fragment) << 10) | ((seq & 3) << 11) | (int(maildrop) << 20)
+    chars = list(text.encode("ascii"))
+    if seq == 3:
+        chars = [signature & 0x7F] + chars
+    while len(chars) % 3:
+        chars.append(0x03)
+    words = [head]
+    for i in range(0, len(chars), 3):
+        words.append(chars[i] | chars[i + 1] << 7 | chars[i + 2] << 14)
+    return [flex_codeword(w) for w in words]
+
+
+def flex_numeric_body(digits, k=0):
+    """message words of a numeric page: 2 check bits, then 4-bit digits, packed 21 bits per word, filled with spaces"""
+    bits = [(k >> i) & 1 for i in range(2)]
+    for ch in digits:
+        v = FLEX_NUM_TABLE.index(ch)
+        bits += [(v >> i) & 1 for i in range(4)]
+    total = 21 * ((len(bits) + 20) // 21)
+    while len(bits) < total:
+        bits += [0, 0, 1, 1]                         # the "space" digit 0xC, LSB first
+    return [flex_codeword(w) for w in _flex_pack(bits[:total])]
+
+
+def flex_phase_words(records, eob=0, extra_biws=(), idle=(0x000000, 0x1FFFFF)):
+    """records: list of dicts
+         kind   'alnum' | 'numeric' | 'tone' | 'siv' | 'raw'
+         capcode (short address) or long=(first21, second21)
+         alnum: text, seq, fragment, maildrop;  numeric: digits;  tone: digits (3, or 8 with a long address),
+         ttype; siv: siv_type, data;  raw: vtype (vector type), body (list of info words)
+       -> the 88 words of one phase: BIW, addresses, vectors, message words, idle fill."""
+    addr_start = 1 + eob
+    addr_words, recs = [], []
+    for r in records:
+        if "long" in r:
+            a = [flex_codeword(r["long"][0]), flex_codeword(r["long"][1])]
+        else:
+            a = [flex_codeword(int(r["capcode"]) + 32768)]
+        recs.append((r, len(addr_words), len(a)))
+        addr_words += a
+    vsw = addr_start + len(addr_words)
+    body_at = vsw + len(addr_words)
+    words = {0: flex_biw(vsw, eob=eob)}
+    for i, w in enumerate(extra_biws):
+        words[1 + i] = w
+    for i, w in enumerate(addr_words):
+        words[addr_start + i] = w
+    for r, aoff, alen in recs:
+        kind = r["kind"]
+        is_long = alen == 2
+        if kind == "alnum":
+            body = flex_alnum_body(r["text"], r.get("seq", 3), r.get("fragment", False), r.get("maildrop", False))
+            vec = flex_checksummed(5 << 4 | (body_at & 0x7F) << 7 | (len(body) & 0x7F) << 14)
+        elif kind == "numeric":
+            body = flex_numeric_body(r["digits"])
+            vec = flex_checksummed(3 << 4 | (body_at & 0x7F) << 7 | ((len(body) - 1) & 7) << 14)
+        elif kind == "tone":
+            d = [FLEX_NUM_TABLE.index(c) for c in r.get("digits", "000")]
+            vec = flex_checksummed(2 << 4 | (r.get("ttype", 0) & 3) << 7 | d[0] << 9 | d[1] << 13 | d[2] << 17)
+            body = []
+            if is_long:
+                rest = (d[3:] + [12] * 5)[:5]
+                body = [flex_codeword(sum(v << (4 * i) for i, v in enumerate(rest)))]
+        elif kind == "siv":
+            vec = flex_checksummed(1 << 4 | (r["siv_type"] & 7) << 7 | (r["data"] & 0x7FF) << 10)
+            body = [flex_codeword(0)] if is_long else []
+        else:
+            body = [flex_codeword(w) for w in r.get("body", [])]
+            vec = flex_checksummed((r["vtype"] & 7) << 4 | (body_at & 0x7F) << 7 | (len(body) & 0x7F) << 14)
+        words[vsw + aoff] = flex_codeword(vec)
+        if is_long:
+            # the second vector slot of a long address carries the first message word
+            if not body:
+                body = [flex_codeword(0)]
+            words[vsw + aoff + 1] = body[0]
+            body = body[1:]
+        for w in body:
+            words[body_at] = w
+            body_at += 1
+    if body_at > 88:
+        raise ValueError("phase overflows 88 words")
+    fill = [flex_codeword(v) for v in idle]
+    return np.array([words.get(i, fill[i % len(fill)]) for i in range(88)], dtype=np.uint32)
+
+
+def flex_interleave(words88):
+    """88 words -> 2816 bits in transmit order: per block of 8 words, bit j of word 0..7, j = 0..31"""
+    w = np.asarray(words88, dtype=np.uint64).reshape(11, 8)
+    j = np.arange(32, dtype=np.uint64)
+    return ((w[:, None, :] >> j[None, :, None]) & 1).astype(np.uint8).reshape(-1)   # [block][bit][word]
+
+
+def flex_symbols(coding, phase_bits):
+    """phase_bits: dict phase index -> 2816 bits.  Returns the block's symbols (0..3 for 4-FSK: bit 1 = phase A/C,
+    bit 0 = phase B/D, as the slicer numbers them, pager_flex.c:148-171; 0/1 for 2-FSK)."""
+    c = FLEX_CODINGS[coding]
+    ph = [np.asarray(phase_bits[p], dtype=np.uint8) for p in c["phases"]]
+    if len(ph) == 1:
+        return ph[0]
+    if len(ph) == 2 and c["levels"] == 2:
+        return np.stack([ph[0], ph[1]], axis=1).reshape(-1)
+    if len(ph) == 2:
+        return ph[0] * 2 + ph[1]
+    return np.stack([ph[0] * 2 + ph[1], ph[2] * 2 + ph[3]], axis=1).reshape(-1)
+
+
+def flex_frame_levels(coding, cycle, frame, phases, corrupt=None, fiw_flip=0, a_flip=0):
+    """One frame as a list of (level, samples) runs at 16 kHz; level in {-3, -1, +1, +3} thirds of the deviation.
+    phases: dict phase index -> 88 words (missing phases are idle).  corrupt: {(phase, word): xor mask}."""
+    c = FLEX_CODINGS[coding]
+    a = ((c["seq_a"] << 16) | 0x5939) ^ a_flip
+    bits = [(i + 1) & 1 for i in range(32)]                                   # 1010...10
+    bits += [(a >> (31 - k)) & 1 for k in range(32)]
+    bits += [(0x5555 >> (15 - k)) & 1 for k in range(16)]
+    bits += [((~a) >> (31 - k)) & 1 for k in range(32)]
+    fiw = flex_fiw(cycle, frame) ^ fiw_flip
+    bits += [(fiw >> k) & 1 for k in range(32)]
+    runs = [(3 if b else -3, FLEX_RATE // 1600) for b in bits]
+    sps = FLEX_RATE // c["sym_rate"]
+    two = c["levels"] == 2
+    lv = (lambda s: 3 if s else -3) if two else (lambda s: (-3, -1, 3, 1)[s])
+    # sync 2: dots, C, inverted dots, inverted C - the decoder only counts them (pager_flex.c:460-525)
+    nsym_c = 16 if two else 8
+    cpat = [(0xED84 >> (15 - k)) & 1 for k in range(16)]
+    csym = cpat if two else [cpat[2 * k] * 2 + cpat[2 * k + 1] for k in range(8)]
+    dots = [(k + 1) & 1 for k in range(c["sync2_dots"])]
+    top = 1 if two else 2
+    s2 = [top * d for d in dots] + csym[:nsym_c] + [top * (1 - d) for d in dots] + [(1 if two else 3) - s for s in csym[:nsym_c]]
+    runs += [(lv(s), sps) for s in s2]
+    pb = {}
+    for p in c["phases"]:
+        w = np.array(phases.get(p, flex_phase_words([])), dtype=np.uint32).copy()
+        for (pp, wi), mask in (corrupt or {}).items():
+            if pp == p:
+                w[wi] ^= np.uint32(mask)
+        pb[p] = flex_interleave(w)
+    runs += [(lv(int(s)), sps) for s in flex_symbols(coding, pb)]
+    return runs
+
+
+def flex_pcm(frames, amplitude=9000, noise=0.0, lead=0, trail=0, seed=0, offset=0, gap=0):
+    """frames: list of flex_frame_levels() results, sent back to back (`gap` idle samples between them).
+    A level of +-3 is +-amplitude (sync 1 always uses the outer levels).  `offset` adds a DC error."""
+    parts = [np.zeros(lead)]
+    for k, runs in enumerate(frames):
+        lv = np.repeat(np.array([r[0] for r in runs], dtype=np.float64), [r[1] for r in runs])
+        parts.append(lv * (amplitude / 3.0))
+        if gap and k + 1 < len(frames):
+            parts.append(np.zeros(gap))
+    parts.append(np.zeros(trail))
+    x = np.concatenate(parts) + offset
+    if noise > 0:
+        x = x + np.random.RandomState(seed).normal(0.0, noise, size=x.size)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
