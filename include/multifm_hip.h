@@ -353,6 +353,91 @@ int mfm_pocsag_fetch_events(struct mfm_pocsag *p, struct mfm_pocsag_event *out, 
                             size_t *nr_events);
 
 /*
+ * ---- Pager stage: FLEX sync 1 / frame information word / sync 2 / block de-interleave -------
+ * Replaces, for ALL channels at once and on PCM that is still in HBM (16 000 Hz, pager_flex_priv.h:231):
+ *
+ *   pager_flex_on_pcm              pager/pager_flex.c:1401-1455   SYNC_1 -> SYNC_2 -> BLOCK, sample skipping
+ *   _pager_flex_sync_update        pager/pager_flex.c:295-458     ten-phase BS1 search, eye run, A / B / inverted A,
+ *                                                                  frame information word, swing of the signal
+ *   _pager_flex_handle_fiw         pager/pager_flex.c:1312-1345   BCH(31,21) + checksum of the FIW, cycle / frame
+ *   _pager_flex_sync2_update       pager/pager_flex.c:460-525     counts the 25 ms of sync 2
+ *   _pager_flex_block_update       pager/pager_flex.c:1224-1310   2- / 4-level slicer, phase split, block de-interleave
+ *
+ * Output per channel: an event list (frame collected / unknown A code / bad FIW) and, for every frame, the 88 words
+ * of each phase exactly as _pager_flex_phase_append_bit (:1200-1222) leaves them.  What follows in the reference,
+ * _pager_flex_phase_process (:1088-1198: BIW, addresses, vectors, message bodies), is a serial walk over at most
+ * 88 words with in-place corrections; it stays on the host (tsl-sdr_amd/host/mfm_pager_flex.c, same callback
+ * signatures as pager/pager_flex.h:16-87).
+ *
+ * Conventions kept: bit = (sample >= 0); BS1 = 0xaaaaaaaa seen by one of ten registers that take every tenth
+ * sample; a run of three or more consecutive matching samples opens the eye and the sampling clock is set to half
+ * the run length (the run counter is 8 bits wide, as in the reference); only the upper half of A is compared, with
+ * fewer than 4 differing bits (the inverted-A comparison of :278 can never succeed and is not evaluated); swing =
+ * mean of the positive minus mean of the non-positive samples over the 112 sync bits, all in int16 arithmetic;
+ * registers are zero-filled after every reset, so no match is possible for the next 310 samples.
+ * A sync run without a positive or without a non-positive sample (the reference divides by zero) is reported as
+ * MFM_FLEX_EV_BAD_FIW with fiw_rc 3.
+ */
+#define MFM_FLEX_EV_FRAME    1u
+#define MFM_FLEX_EV_BAD_BAUD 2u
+#define MFM_FLEX_EV_BAD_FIW  3u
+#define MFM_FLEX_PHASE_WORDS 88u /* pager_flex_priv.h:175 */
+
+struct mfm_flex_event {
+    uint32_t type;          /* MFM_FLEX_EV_* */
+    uint32_t channel;
+    uint64_t sample;        /* index (per channel, since creation) of the PCM sample that completed the event */
+    uint64_t sync_sample;   /* FRAME: sample of the last FIW bit */
+    uint32_t coding;        /* index into _pager_codings[] (pager_flex.c:46-96); 0xffffffff for BAD_BAUD */
+    uint32_t baud;          /* 1600 / 3200 / 6400; 0 for BAD_BAUD */
+    uint32_t eye;           /* length of the BS1 run (sync->bit_counter at :339) */
+    uint32_t a, b, inv_a;   /* the sync words as collected */
+    uint32_t fiw_raw;       /* the 32 FIW bits as collected */
+    uint32_t fiw;           /* (fiw_raw & 0x7fffffff) after BCH correction */
+    uint32_t fiw_rc;        /* 0 accepted, 1 uncorrectable, 2 checksum, 3 no swing */
+    int32_t sample_range;   /* flex->sample_range / sample_delta (:441-442) */
+    int32_t sample_delta;
+    uint32_t cycle, frame;  /* FIW fields (:1337-1338) */
+    uint32_t frame_index;   /* FRAME: index of this frame's words in the array the same fetch call fills */
+    uint32_t nr_phases;     /* 1 / 2 / 4 */
+    uint32_t reserved;
+};
+
+/* phase_words[] of phases A..D of one frame; phases the coding does not carry are zero */
+struct mfm_flex_frame_words {
+    uint32_t words[4][MFM_FLEX_PHASE_WORDS];
+};
+
+struct mfm_flex; /* opaque */
+
+struct mfm_flex_config {
+    uint32_t abi_version;    /* MFM_ABI_VERSION */
+    int32_t device;
+    uint32_t nr_channels;
+    uint32_t max_in_samples; /* most PCM samples per channel one process call may carry (<= 2^26) */
+    uint32_t max_events;     /* per channel and call; 0 = max_in_samples / 1024 + 8 (cannot overflow) */
+    uint32_t flags;          /* 0 */
+};
+
+int mfm_flex_create(struct mfm_flex **pf, const struct mfm_flex_config *cfg);
+void mfm_flex_destroy(struct mfm_flex **pf);
+/*
+ * Consume nr_in PCM samples per channel, laid out [channel][in_stride] in device memory (for instance the output of
+ * mfm_resampler_process_device).  Work is queued on `stream`; no host synchronisation; d_pcm is read until the
+ * queued work has run.  The events of THIS call replace those of the previous one.
+ */
+int mfm_flex_process_device(struct mfm_flex *f, const int16_t *d_pcm, size_t in_stride, size_t nr_in, void *stream);
+/* Host convenience: same from host memory, synchronous. */
+int mfm_flex_process_host(struct mfm_flex *f, const int16_t *pcm, size_t in_stride, size_t nr_in);
+/*
+ * Wait for the last process call and copy its events (channels ascending, stream order within a channel) and the
+ * words of its frames.  MFM_E_NOMEM when either array is too small (nothing copied, *nr_events / *nr_frames =
+ * needed), MFM_E_STATE when a channel overflowed its device-side lists (only with a caller-chosen max_events).
+ */
+int mfm_flex_fetch_events(struct mfm_flex *f, struct mfm_flex_event *events, size_t max_events, size_t *nr_events,
+                          struct mfm_flex_frame_words *frames, size_t max_frames, size_t *nr_frames);
+
+/*
  * ---- Mueller-Muller clock recovery (BASELINE.json configs[3]: "mueller_muller slicer") -------------------------
  *   mm_init      pager/mueller_muller.c:10-33
  *   mm_process   pager/mueller_muller.c:41-115

@@ -648,6 +648,7 @@ static bool sync1_update(struct mfmo_flex *f, int16_t sample)
 static unsigned handle_fiw(struct mfmo_flex *f)
 {
     if (f->n_high == 0 || f->n_low == 0) {
+        f->fiw_fixed = 0;
         return 3;
     }
     uint32_t w = f->fiw & 0x7fffffffu;
@@ -747,11 +748,11 @@ static void block_update(struct mfmo_flex *f, int16_t sample, struct ev_sink *es
     e->sample_delta = f->sample_delta;
     e->cycle = f->cycle_id;
     e->frame = f->frame_id;
-    for (int p = 0; p < 4; p++) {
-        memcpy(e->words[p], f->ph[p].words, sizeof(e->words[p]));
-    }
     static const uint8_t order[3][4] = { { 0 }, { 0, 2 }, { 0, 1, 2, 3 } };
     const uint8_t *seq = order[cd->nr_phases == 1 ? 0 : cd->nr_phases == 2 ? 1 : 2];
+    for (unsigned k = 0; k < cd->nr_phases; k++) { /* phases this coding does not carry stay zero in the event */
+        memcpy(e->words[seq[k]], f->ph[seq[k]].words, sizeof(e->words[0]));
+    }
     for (unsigned k = 0; k < cd->nr_phases; k++) {
         struct msg_ctx c = { .sink = ms, .baud = cd->baud, .phase = seq[k], .cycle = f->cycle_id, .frame = f->frame_id,
             .sample = f->pos, .len = 0 };

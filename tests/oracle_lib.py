@@ -381,6 +381,20 @@ def flex_msg_tuple(m, with_sample=True):
     return t + (int(m["sample"]),) if with_sample else t
 
 
+class FlexCoding(C.Structure):
+    _fields_ = [("seq_a", C.c_uint16), ("baud", C.c_uint16), ("fsk_levels", C.c_uint8), ("sample_skip", C.c_uint8),
+                ("sync_2_samples", C.c_uint8), ("sym_bits", C.c_uint8), ("sample_fudge", C.c_uint8), ("nr_phases", C.c_uint8),
+                ("symbols_per_block", C.c_uint16)]
+
+
+def flex_coding(idx):
+    f = lib().mfmo_flex_coding
+    f.argtypes = [C.c_uint]
+    f.restype = C.POINTER(FlexCoding)
+    p = f(idx)
+    return p.contents if p else None
+
+
 class Flex:
     """Oracle FLEX decoder for one channel: feed(pcm) -> (events, messages) of that call."""
 

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "mfm_shard_range", "mfm_group_create", "mfm_group_destroy", "mfm_group_add_channel", "mfm_group_commit",
     "mfm_group_nr_shards", "mfm_group_shard_info", "mfm_group_push", "mfm_group_fetch", "mfm_group_release",
     "mfm_group_sync", "mfm_group_get_stats", "mfm_group_exchange_info",
+    "mfm_flex_create", "mfm_flex_destroy", "mfm_flex_process_device", "mfm_flex_process_host", "mfm_flex_fetch_events",
     "mfm_mm_create", "mfm_mm_destroy", "mfm_mm_max_decisions", "mfm_mm_process_device", "mfm_mm_process_host",
 ]
 
@@ -91,6 +92,21 @@ class PocsagEvent(C.Structure):
 # numpy view of struct mfm_pocsag_event (160 bytes)
 POCSAG_EVENT_DTYPE = np.dtype([("type", "<u4"), ("baud", "<u4"), ("channel", "<u4"), ("aux", "<u4"), ("sample", "<u8"),
                                ("nr_ok", "<u4"), ("fail_mask", "<u4"), ("raw", "<u4", (16,)), ("corrected", "<u4", (16,))])
+
+
+class FlexConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("nr_channels", C.c_uint32),
+                ("max_in_samples", C.c_uint32), ("max_events", C.c_uint32), ("flags", C.c_uint32)]
+
+
+# numpy views of struct mfm_flex_event (88 bytes) and struct mfm_flex_frame_words
+FLEX_EVENT_DTYPE = np.dtype([("type", "<u4"), ("channel", "<u4"), ("sample", "<u8"), ("sync_sample", "<u8"),
+                             ("coding", "<u4"), ("baud", "<u4"), ("eye", "<u4"), ("a", "<u4"), ("b", "<u4"),
+                             ("inv_a", "<u4"), ("fiw_raw", "<u4"), ("fiw", "<u4"), ("fiw_rc", "<u4"),
+                             ("sample_range", "<i4"), ("sample_delta", "<i4"), ("cycle", "<u4"), ("frame", "<u4"),
+                             ("frame_index", "<u4"), ("nr_phases", "<u4"), ("reserved", "<u4")])
+FLEX_FRAME_DTYPE = np.dtype([("words", "<u4", (4, 88))])
+MFM_FLEX_EV_FRAME, MFM_FLEX_EV_BAD_BAUD, MFM_FLEX_EV_BAD_FIW = 1, 2, 3
 
 
 class ResamplerConfig(C.Structure):
@@ -191,6 +207,12 @@ def load_library():
     lib.mfm_pocsag_process_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.mfm_pocsag_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t]
     lib.mfm_pocsag_fetch_events.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.mfm_flex_create.argtypes = [C.POINTER(vp), C.POINTER(FlexConfig)]
+    lib.mfm_flex_destroy.argtypes = [C.POINTER(vp)]
+    lib.mfm_flex_destroy.restype = None
+    lib.mfm_flex_process_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+    lib.mfm_flex_process_host.argtypes = [vp, i16p, C.c_size_t, C.c_size_t]
+    lib.mfm_flex_fetch_events.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.mfm_bch3121_decode_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
     lib.mfm_bch3121_decode_host.argtypes = [u32p, C.POINTER(C.c_uint8), C.c_size_t, C.c_int]
     lib.mfm_hosttwin_bch3121_decode.argtypes = [u32p]
@@ -685,6 +707,55 @@ class Pocsag:
         if rc < 0:
             raise MfmError(rc, "mfm_pocsag_fetch_events", self.lib.mfm_strerror(rc).decode())
         return out[:n.value].copy()
+
+
+class Flex:
+    """mfm_flex: FLEX sync 1 / FIW / sync 2 / block de-interleave for all channels of a 16 000 Hz PCM block."""
+
+    def __init__(self, nr_channels, max_in_samples, device=0, max_events=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        cfg = FlexConfig(MFM_ABI_VERSION, device, nr_channels, max_in_samples, max_events, 0)
+        rc = self.lib.mfm_flex_create(C.byref(self.h), C.byref(cfg))
+        if rc < 0:
+            raise MfmError(rc, "mfm_flex_create", self.lib.mfm_strerror(rc).decode())
+        self.nr_channels = nr_channels
+        self.max_events = max_events or (max_in_samples // 1024 + 8)
+        self.max_frames = min(self.max_events, max_in_samples // 28672 + 2)
+
+    def close(self):
+        if self.h:
+            self.lib.mfm_flex_destroy(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_host(self, pcm):
+        """pcm: int16 [C][n]; returns (events, frames) of this call (FLEX_EVENT_DTYPE, FLEX_FRAME_DTYPE)"""
+        a = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.nr_channels, -1)
+        rc = self.lib.mfm_flex_process_host(self.h, _i16p(a), a.shape[1], a.shape[1])
+        if rc < 0:
+            raise MfmError(rc, "mfm_flex_process_host", self.lib.mfm_strerror(rc).decode())
+        return self.fetch_events()
+
+    def process_device(self, d_pcm, in_stride, nr_in, stream=None):
+        rc = self.lib.mfm_flex_process_device(self.h, C.c_void_p(d_pcm), in_stride, nr_in, C.c_void_p(stream or 0))
+        if rc < 0:
+            raise MfmError(rc, "mfm_flex_process_device", self.lib.mfm_strerror(rc).decode())
+
+    def fetch_events(self):
+        cap_e, cap_f = self.nr_channels * self.max_events, self.nr_channels * self.max_frames
+        ev = np.zeros(cap_e, FLEX_EVENT_DTYPE)
+        fw = np.zeros(cap_f, FLEX_FRAME_DTYPE)
+        ne, nf = C.c_size_t(), C.c_size_t()
+        rc = self.lib.mfm_flex_fetch_events(self.h, ev.ctypes.data, cap_e, C.byref(ne), fw.ctypes.data, cap_f, C.byref(nf))
+        if rc < 0:
+            raise MfmError(rc, "mfm_flex_fetch_events", self.lib.mfm_strerror(rc).decode())
+        return ev[:ne.value].copy(), fw[:nf.value].copy()
 
 
 def bch3121_decode(words, device=0):

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/multifm_hip.h"
+#include "mfm_bch.h"
 
 extern "C" __attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *msg);
 
@@ -52,10 +53,7 @@ enum : uint32_t { PG_SEARCH = 0, PG_BATCH = 2, PG_SYNCWORD = 3 };
 
 /* ---- BCH(31,21): tables ------------------------------------------------------------------------------- */
 
-struct BchTables {
-    uint32_t flips[1024];  /* index S1 | S3 << 5 : bits to flip, bit 31 = "uncorrectable" */
-    uint16_t syn[4][256];  /* syndrome contribution of each byte of the word */
-};
+using BchTables = MfmBchTables;
 
 BchTables build_bch_tables()
 {
@@ -133,10 +131,7 @@ const BchTables &bch_tables()
 template <class T>
 __host__ __device__ __forceinline__ uint32_t pg_bch_fix(const T *t, uint32_t w, uint32_t *rc)
 {
-    const uint32_t s = t->syn[0][w & 255u] ^ t->syn[1][(w >> 8) & 255u] ^ t->syn[2][(w >> 16) & 255u] ^ t->syn[3][w >> 24];
-    const uint32_t f = t->flips[s];
-    *rc = f >> 31;
-    return w ^ (f & 0x7fffffffu);
+    return mfm_bch_fix(t, w, rc);
 }
 
 __global__ __launch_bounds__(256) void pg_bch_kernel(uint32_t *words, uint8_t *rc, size_t n, const BchTables *tab)
@@ -974,6 +969,16 @@ int mfm_bch3121_decode_host(uint32_t *words, uint8_t *rc, size_t n, int device)
     (void)hipFree(d_w);
     (void)hipFree(d_rc);
     return r;
+}
+
+int mfm_internal_bch_device_tables(int device, MfmBchTables **out)
+{
+    return pg_device_tables(device, out);
+}
+
+const MfmBchTables *mfm_internal_bch_host_tables(void)
+{
+    return &bch_tables();
 }
 
 int mfm_hosttwin_bch3121_decode(uint32_t *word)

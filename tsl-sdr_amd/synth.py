@@ -296,13 +296,18 @@ def flex_numeric_body(digits, k=0):
     return [flex_codeword(w) for w in _flex_pack(bits[:total])]
 
 
-def flex_phase_words(records, eob=0, extra_biws=(), idle=(0x000000, 0x1FFFFF)):
+_FLEX_FILL = tuple(int(v) for v in np.random.RandomState(88).randint(0, 1 << 21, 88))
+
+
+def flex_phase_words(records, eob=0, extra_biws=(), idle=_FLEX_FILL):
     """records: list of dicts
          kind   'alnum' | 'numeric' | 'tone' | 'siv' | 'raw'
          capcode (short address) or long=(first21, second21)
          alnum: text, seq, fragment, maildrop;  numeric: digits;  tone: digits (3, or 8 with a long address),
          ttype; siv: siv_type, data;  raw: vtype (vector type), body (list of info words)
-       -> the 88 words of one phase: BIW, addresses, vectors, message words, idle fill."""
+       -> the 88 words of one phase: BIW, addresses, vectors, message words, fill.
+       `idle`: information values the unused words cycle through.  (0, 0x1FFFFF) makes the interleaved block an
+       alternating bit pattern - on a 1600 bit/s frame that is one long bit-sync-1 look-alike.)"""
     addr_start = 1 + eob
     addr_words, recs = [], []
     for r in records:
