@@ -432,3 +432,144 @@ def test_gpu_flex_many_channels_and_strides(ora, pkg):
     fx.close()
     with pytest.raises(pkg.binding.MfmError):
         pkg.binding.Flex(0, 100)
+
+
+# ---- the decoder-shaped driver ---------------------------------------------------------------------------------
+
+def _esc(text):
+    """decoder.c:121-166"""
+    out = ""
+    for ch in text:
+        c = chr(ch)
+        if c in "\n\r":
+            out += "\\n"
+        elif c == '"':
+            out += '\\"'
+        elif c == "\\":
+            out += "\\\\"
+        elif c == "/":
+            out += "\\/"
+        elif c == "\b":
+            out += "<BKSP>"
+        elif c == "\f":
+            out += "<FF>"
+        elif c == "\t":
+            out += "\\t"
+        elif ch in (3, 4, 0x17):
+            out += " "
+        elif 32 <= ch < 127:
+            out += c
+        else:
+            out += "\\u%04x" % ch
+    return out
+
+
+def _flex_json_lines(msgs):
+    """decoder.c:173-262 with the timestamp of MFM_DECODER_FIXED_TIME"""
+    out = []
+    for kind, baud, phase, cycle, frame, a0, a1, _a2, cap, text in [m[:10] for m in msgs]:
+        head = ('{"proto":"flex","type":"%s","timestamp":"1970-01-01 00:00:00 UTC","baud":%d,"syncLevel":0,"frameNo":%d,'
+                '"cycleNo":%d,"phaseNo":"%s","capCode":%d,')
+        if kind == 1:
+            out.append(head % ("alphanumeric", baud, frame, cycle, "ABCD"[phase], cap) +
+                       '"fragment":%s,"maildrop":%s,"fragSeq":%d,"message":"%s"}\n' %
+                       ("true" if a0 & 1 else "false", "true" if a0 & 2 else "false", a0 >> 2, _esc(text)))
+        elif kind == 2:
+            out.append(head % ("numeric", baud, frame, cycle, "ABCD"[phase], cap) + '"message":"%s"}\n' % _esc(text))
+        elif kind == 3 and a0 == 0:
+            out.append(head % ("tempAddrActivation", baud, frame, cycle, "ABCD"[phase], cap) +
+                       '"startFrameNo":%d,"tempAddressId":%d}\n' % (a1 & 0x7F, (a1 >> 7) & 0xF))
+    return "".join(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [[], ["-i", "-b", "-p", "0.9999"]])
+def test_decoder_amd_flex_json_matches_oracle(tmp_path, ora, pkg, opts):
+    """decoder/decoder.c's FLEX path (:580-673 loop, :173-262 output; FLEX is its default protocol): four 25 kS/s PCM
+    files, one per coding -> 16/25 -> 16 000 Hz -> FLEX; the JSON lines must be what the oracle chain's messages print as."""
+    import json
+    import subprocess
+    sy = pkg.synth
+    tool = os.path.join(os.path.dirname(HOST_SO), "decoder_amd")
+    recs = RECORDS[:8] + [dict(kind="alnum", capcode=31, text='quote " slash / back \\ tab\t nl\n bell\x07 end\x17')]
+    chans = []
+    for k in range(4):
+        fr = [sy.flex_frame_levels(k, 2 + i, 9 * k + i, {p: sy.flex_phase_words(recs[i:] + recs[:i]) for p in sy.FLEX_CODINGS[k]["phases"]})
+              for i in range(2)]
+        chans.append(sy.flex_pcm(fr, lead=3000 + 517 * k, trail=4000, noise=300, seed=k, rate=25000, offset=500 if "-b" in opts else 0))
+    total = min(len(x) for x in chans)
+    taps = sy.design_lpf(321, 0.45 / 25, 1.0) * 16
+    (tmp_path / "filter.json").write_text(json.dumps({"lpfCoeffs": [float(t) for t in taps]}))
+    invert = "-i" in opts
+    paths = []
+    for c, x in enumerate(chans):
+        p = tmp_path / f"ch{c}.pcm"
+        p.write_bytes(((-x[:total].astype(np.int32)).astype(np.int16) if invert else x[:total]).tobytes())
+        paths.append(str(p))
+    out = tmp_path / "pages.json"
+    env = dict(os.environ, MFM_DECODER_FIXED_TIME="1")
+    r = subprocess.run([tool, "-I", "16", "-D", "25", "-S", "25000", "-F", str(tmp_path / "filter.json"), "-f", "929612500",
+                        "-c", "-o", str(out), "-B", "30000"] + opts + paths, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rtaps = ora.quantize_taps(taps)
+    for c, x in enumerate(chans):
+        xin = (-x[:total].astype(np.int32)).astype(np.int16) if invert else x[:total]
+        res = ora.Resampler(rtaps, 16, 25, dc_pole=0.9999 if "-b" in opts else None, invert=invert)
+        _, msgs = ora.Flex().feed(res.feed(xin))
+        assert len(_pages(msgs)) >= 14 * len(sy.FLEX_CODINGS[c]["phases"]), f"channel {c}: the synthetic pages did not decode"
+        assert (tmp_path / f"pages.json.{c}").read_text() == _flex_json_lines(msgs), f"channel {c}"
+
+
+@pytest.mark.gpu
+def test_flex_chain_through_both_binaries(tmp_path, ora, pkg):
+    """The reference's FLEX deployment end to end at its process boundary: a cs16 capture at 2.4 MS/s with four FLEX
+    carriers (one per coding, 2- and 4-level FSK) -> multifm_amd (D = 96, the 128-tap 25 kHz low-pass: the headline
+    geometry) -> one 25 kS/s PCM sink per channel -> decoder_amd (16/25 -> 16 000 Hz -> FLEX) -> JSON lines.  Must
+    equal the oracle chain run on the same bytes."""
+    import json
+    import subprocess
+    sy = pkg.synth
+    fs, decim = 2400000, 96
+    center = 929612500
+    offs = [-600000, -137500, 212500, 875000]
+    n16 = 33500
+    acc = np.zeros((n16 * fs // 16000, 2), np.float64)
+    for k, o in enumerate(offs):
+        ph = {p: sy.flex_phase_words(RECORDS[k:k + 5]) for p in sy.FLEX_CODINGS[k]["phases"]}
+        iq = sy.flex_fm_iq([sy.flex_frame_levels(k, 7, 30 + k, ph)], fs, float(o), amplitude=5000.0, lead=800 + 300 * k, trail=2700 - 300 * k,
+                           noise=60.0, seed=k)
+        acc[:iq.shape[0]] += iq[:acc.shape[0]]
+    raw = np.clip(np.round(acc), -32768, 32767).astype(np.int16)
+    cap = tmp_path / "capture.cs16"
+    cap.write_bytes(raw.tobytes())
+    taps_file = os.path.join(ROOT, "etc", "lpf_25khz_2400k_128.json")
+    lpf = np.array(json.load(open(taps_file))["lpfTaps"])
+    cfg = {"device": {"type": "file", "filename": str(cap), "fileFormat": "cs16"}, "sampleRateHz": fs, "centerFreqHz": center,
+           "nrSampBufs": 32, "decimationFactor": decim,
+           "channels": [{"outFifo": str(tmp_path / f"ch{c}.pcm"), "chanCenterFreq": int(center + o)} for c, o in enumerate(offs)]}
+    for c in range(4):
+        (tmp_path / f"ch{c}.pcm").write_bytes(b"")
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    host_dir = os.path.dirname(HOST_SO)
+    r = subprocess.run([os.path.join(host_dir, "multifm_amd"), str(tmp_path / "cfg.json"), taps_file], capture_output=True, text=True,
+                       timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rt = sy.design_lpf(321, 0.45 / 25, 1.0) * 16
+    (tmp_path / "filter.json").write_text(json.dumps({"lpfCoeffs": [float(t) for t in rt]}))
+    env = dict(os.environ, MFM_DECODER_FIXED_TIME="1")
+    r = subprocess.run([os.path.join(host_dir, "decoder_amd"), "-I", "16", "-D", "25", "-S", "25000", "-F", str(tmp_path / "filter.json"),
+                        "-f", str(center), "-m", "FLEX", "-c", "-o", str(tmp_path / "pages.json")] +
+                       [str(tmp_path / f"ch{c}.pcm") for c in range(4)], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    iq = raw.reshape(-1, 2)
+    cre = np.stack([ora.make_taps(lpf, int(o), fs, 1.0)[0] for o in offs])
+    cim = np.stack([ora.make_taps(lpf, int(o), fs, 1.0)[1] for o in offs])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    pcm, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
+    rtaps = ora.quantize_taps(rt)
+    for c in range(4):
+        got_pcm = np.frombuffer((tmp_path / f"ch{c}.pcm").read_bytes(), dtype=np.int16)
+        assert np.array_equal(got_pcm, pcm[c]), f"channel {c}: PCM sink differs"
+        _, msgs = ora.Flex().feed(ora.Resampler(rtaps, 16, 25).feed(pcm[c]))
+        assert len(_pages(msgs)) >= 3 * len(sy.FLEX_CODINGS[c]["phases"]), f"channel {c}: the synthetic pages did not decode"
+        assert (tmp_path / f"pages.json.{c}").read_text() == _flex_json_lines(msgs), f"channel {c}: JSON lines differ"

@@ -6,31 +6,38 @@
  * input named on the command line is one channel of a single GPU pipeline
  *
  *     PCM block (host) -> mfm_resampler (I/D, -b, -i) -> mfm_pocsag (slicer / sync / BCH)      on the MI355X
+ *                                                      or  mfm_flex   (sync 1 / FIW / slicer / de-interleave)
  *     events (host)    -> pager_pocsag_on_events -> on_alpha / on_numeric -> JSON line         per channel
+ *                      or pager_flex_on_events   -> on_alnum / on_num / on_siv
  *
  * Same options as decoder.c:404 (-I -D -S -F -f -o -c -b -p -i -m -d is not offered), same JSON line layout
- * (decoder.c:264-318).  Differences, all forced by batching: several inputs are allowed (with more than one,
+ * (decoder.c:173-318); -m FLEX is the default, as in decoder.c:59.  Differences, all forced by batching: several inputs are allowed (with more than one,
  * -o NAME writes NAME.0, NAME.1, ...); inputs are read in lock step and processing stops at the shortest;
  * -B sets the block size, -g the device.  MFM_DECODER_FIXED_TIME=1 prints the epoch instead of the wall clock,
- * so two runs can be diffed.  FLEX and AIS are not part of this build.
+ * so two runs can be diffed.  AIS is not part of this build.
  */
 #include <errno.h>
 #include <ctype.h>
 #include <fcntl.h>
+#include <inttypes.h>
 #include <strings.h>
 #include <time.h>
 #include <unistd.h>
 
 #include "mfm_config.h"
+#include "mfm_pager_flex.h"
 #include "mfm_pager_pocsag.h"
 
 #define DEC_MSG(sev, sys, msg, ...) MESSAGE("DECODER", sev, sys, msg, ##__VA_ARGS__)
 #define Q_15_SHIFT 14 /* filter/filter.h:16 */
 
+enum proto { PROTO_FLEX = 0, PROTO_POCSAG = 1 }; /* decoder.c:51-59 */
+
 struct chan {
     int fd;
     FILE *out;
     struct pager_pocsag *pocsag;
+    struct pager_flex *flex;
 };
 
 static bool g_fixed_time = false;
@@ -105,11 +112,65 @@ static aresult_t on_num(struct pager_pocsag *p, uint16_t baud, uint32_t cap, con
     return on_page(p, "numeric", baud, cap, data, len, fn);
 }
 
+/* decoder.c:173-262 */
+static void flex_head(struct chan *ch, const char *type, uint16_t baud, uint8_t phase, uint8_t cycle_no, uint8_t frame_no,
+                      uint64_t cap_code)
+{
+    time_t now = g_fixed_time ? 0 : time(NULL);
+    struct tm *gmt = gmtime(&now);
+    fprintf(ch->out,
+            "{\"proto\":\"flex\",\"type\":\"%s\",\"timestamp\":\"%04i-%02i-%02i %02i:%02i:%02i UTC\","
+            "\"baud\":%i,\"syncLevel\":%i,\"frameNo\":%u,\"cycleNo\":%u,\"phaseNo\":\"%c\",\"capCode\":%" PRIu64 ",",
+            type, gmt->tm_year + 1900, gmt->tm_mon + 1, gmt->tm_mday, gmt->tm_hour, gmt->tm_min, gmt->tm_sec, baud, 0, frame_no,
+            cycle_no, "ABCD"[phase & 3], cap_code);
+}
+
+static aresult_t on_flex_alnum(struct pager_flex *f, uint16_t baud, uint8_t phase, uint8_t cycle_no, uint8_t frame_no,
+                               uint64_t cap_code, bool fragmented, bool maildrop, uint8_t seq_num, const char *message_bytes,
+                               size_t message_len)
+{
+    struct chan *ch = pager_flex_get_user(f);
+    flex_head(ch, "alphanumeric", baud, phase, cycle_no, frame_no, cap_code);
+    fprintf(ch->out, "\"fragment\":%s,\"maildrop\":%s,\"fragSeq\":%u,\"message\":\"", fragmented ? "true" : "false",
+            maildrop ? "true" : "false", seq_num);
+    for (size_t i = 0; i < message_len; i++) {
+        put_alnum_char(ch->out, message_bytes[i]);
+    }
+    fprintf(ch->out, "\"}\n");
+    fflush(ch->out);
+    return A_OK;
+}
+
+static aresult_t on_flex_num(struct pager_flex *f, uint16_t baud, uint8_t phase, uint8_t cycle_no, uint8_t frame_no,
+                             uint64_t cap_code, const char *message_bytes, size_t message_len)
+{
+    struct chan *ch = pager_flex_get_user(f);
+    flex_head(ch, "numeric", baud, phase, cycle_no, frame_no, cap_code);
+    fprintf(ch->out, "\"message\":\"");
+    for (size_t i = 0; i < message_len; i++) {
+        put_alnum_char(ch->out, message_bytes[i]);
+    }
+    fprintf(ch->out, "\"}\n");
+    fflush(ch->out);
+    return A_OK;
+}
+
+static aresult_t on_flex_siv(struct pager_flex *f, uint16_t baud, uint8_t phase, uint8_t cycle_no, uint8_t frame_no,
+                             uint64_t cap_code, uint8_t siv_msg_type, uint32_t data)
+{
+    struct chan *ch = pager_flex_get_user(f);
+    if (PAGER_FLEX_SIV_TEMP_ADDRESS_ACTIVATION == siv_msg_type) { /* the only one decoder.c prints (:253-260) */
+        flex_head(ch, "tempAddrActivation", baud, phase, cycle_no, frame_no, cap_code);
+        fprintf(ch->out, "\"startFrameNo\":%u,\"tempAddressId\":%u}\n", data & 0x7f, (data >> 7) & 0xf);
+    }
+    return A_OK;
+}
+
 static void usage(const char *app)
 {
     DEC_MSG(SEV_INFO, "USAGE",
             "%s -I [interpolate] -D [decimate] -F [filter file] -S [input sample rate] -f [center freq] [-c] "
-            "[-o output JSON file] [-b] [-p pole] [-i] [-m POCSAG] [-B block samples] [-g gpu] in_fifo [in_fifo ...]",
+            "[-o output JSON file] [-b] [-p pole] [-i] [-m FLEX|POCSAG] [-B block samples] [-g gpu] in_fifo [in_fifo ...]",
             app);
     exit(EXIT_SUCCESS);
 }
@@ -139,6 +200,7 @@ int main(int argc, char *const argv[])
     unsigned interpolate = 1, decimate = 1, input_sample_rate = 0, center_freq = 0, block = 1u << 18;
     int device = 0, arg;
     bool dc_blocker = false, invert = false, create_out = false;
+    enum proto proto = PROTO_FLEX;
     double dc_block_pole = 0.9999;
     const char *filter_file = NULL, *out_file_name = NULL;
 
@@ -175,8 +237,12 @@ int main(int argc, char *const argv[])
             invert = true;
             break;
         case 'm':
-            if (strncasecmp(optarg, "pocsag", 6)) {
-                DEC_MSG(SEV_ERROR, "UNKNOWN-PROTOCOL-TYPE", "Only POCSAG is built into decoder_amd (asked for: %s)", optarg);
+            if (!strncasecmp(optarg, "pocsag", 6)) {
+                proto = PROTO_POCSAG;
+            } else if (!strncasecmp(optarg, "flex", 4)) {
+                proto = PROTO_FLEX;
+            } else {
+                DEC_MSG(SEV_ERROR, "UNKNOWN-PROTOCOL-TYPE", "POCSAG and FLEX are built into decoder_amd (asked for: %s)", optarg);
                 exit(EXIT_FAILURE);
             }
             break;
@@ -249,9 +315,15 @@ int main(int argc, char *const argv[])
                 exit(EXIT_FAILURE);
             }
         }
-        TSL_BUG_IF_FAILED(pager_pocsag_new(&ch[c].pocsag, center_freq, on_num, on_alnum, false));
-        pager_pocsag_set_user(ch[c].pocsag, &ch[c]);
+        if (PROTO_POCSAG == proto) {
+            TSL_BUG_IF_FAILED(pager_pocsag_new(&ch[c].pocsag, center_freq, on_num, on_alnum, false));
+            pager_pocsag_set_user(ch[c].pocsag, &ch[c]);
+        } else {
+            TSL_BUG_IF_FAILED(pager_flex_new(&ch[c].flex, center_freq, on_flex_alnum, on_flex_num, on_flex_siv));
+            pager_flex_set_user(ch[c].flex, &ch[c]);
+        }
     }
+    DEC_MSG(SEV_INFO, "PROTOCOL", "%s", PROTO_POCSAG == proto ? "Using the POCSAG Pager Protocol." : "Using the Motorola FLEX pager protocol.");
 
     struct mfm_resampler *rs = NULL;
     struct mfm_pocsag *pg = NULL;
@@ -262,16 +334,37 @@ int main(int argc, char *const argv[])
         DEC_MSG(SEV_FATAL, "NO-RESAMPLER", "Cannot create the GPU resampler: %s", mfm_last_error());
         exit(EXIT_FAILURE);
     }
-    struct mfm_pocsag_config pc = { .abi_version = MFM_ABI_VERSION, .device = device, .nr_channels = nr_chan,
-        .max_in_samples = (uint32_t)mfm_resampler_max_out(rs), .max_events = 0, .flags = 0 };
-    if (mfm_pocsag_create(&pg, &pc)) {
-        DEC_MSG(SEV_FATAL, "NO-PAGER-STAGE", "Cannot create the GPU POCSAG stage: %s", mfm_last_error());
-        exit(EXIT_FAILURE);
+    const uint32_t max_pcm = (uint32_t)mfm_resampler_max_out(rs);
+    struct mfm_pocsag_event *events = NULL;
+    struct mfm_flex_event *fevents = NULL;
+    struct mfm_flex_frame_words *fframes = NULL;
+    struct mfm_flex *fx = NULL;
+    size_t max_events, max_frames = 0;
+    if (PROTO_POCSAG == proto) {
+        struct mfm_pocsag_config pc = { .abi_version = MFM_ABI_VERSION, .device = device, .nr_channels = nr_chan,
+            .max_in_samples = max_pcm, .max_events = 0, .flags = 0 };
+        if (mfm_pocsag_create(&pg, &pc)) {
+            DEC_MSG(SEV_FATAL, "NO-PAGER-STAGE", "Cannot create the GPU POCSAG stage: %s", mfm_last_error());
+            exit(EXIT_FAILURE);
+        }
+        max_events = (size_t)nr_chan * (max_pcm / 2048 + 16);
+        events = calloc(max_events, sizeof(*events));
+        TSL_BUG_ON(NULL == events);
+    } else {
+        struct mfm_flex_config fc = { .abi_version = MFM_ABI_VERSION, .device = device, .nr_channels = nr_chan,
+            .max_in_samples = max_pcm, .max_events = 0, .flags = 0 };
+        if (mfm_flex_create(&fx, &fc)) {
+            DEC_MSG(SEV_FATAL, "NO-PAGER-STAGE", "Cannot create the GPU FLEX stage: %s", mfm_last_error());
+            exit(EXIT_FAILURE);
+        }
+        max_events = (size_t)nr_chan * (max_pcm / 1024 + 8);
+        max_frames = (size_t)nr_chan * (max_pcm / 28672 + 2);
+        fevents = calloc(max_events, sizeof(*fevents));
+        fframes = calloc(max_frames, sizeof(*fframes));
+        TSL_BUG_ON(NULL == fevents || NULL == fframes);
     }
-    const size_t max_events = (size_t)nr_chan * (pc.max_in_samples / 2048 + 16);
-    struct mfm_pocsag_event *events = calloc(max_events, sizeof(*events));
     int16_t *pcm = calloc((size_t)nr_chan * block, sizeof(int16_t));
-    TSL_BUG_ON(NULL == events || NULL == pcm);
+    TSL_BUG_ON(NULL == pcm);
 
     size_t sample_count = 0;
     for (;;) {
@@ -292,17 +385,32 @@ int main(int argc, char *const argv[])
         int16_t *d_out = NULL;
         size_t out_stride = 0, nr_out = 0, nr_events = 0;
         TSL_BUG_ON(MFM_OK != mfm_resampler_process_host_to_device(rs, pcm, block, n, NULL, &d_out, &out_stride, &nr_out));
-        TSL_BUG_ON(MFM_OK != mfm_pocsag_process_device(pg, d_out, out_stride, nr_out, NULL));
-        TSL_BUG_ON(MFM_OK != mfm_pocsag_fetch_events(pg, events, max_events, &nr_events));
         /* events come grouped by channel, in stream order inside a channel */
-        size_t first = 0;
-        while (first < nr_events) {
-            size_t last = first;
-            while (last < nr_events && events[last].channel == events[first].channel) {
-                last++;
+        if (PROTO_POCSAG == proto) {
+            TSL_BUG_ON(MFM_OK != mfm_pocsag_process_device(pg, d_out, out_stride, nr_out, NULL));
+            TSL_BUG_ON(MFM_OK != mfm_pocsag_fetch_events(pg, events, max_events, &nr_events));
+            size_t first = 0;
+            while (first < nr_events) {
+                size_t last = first;
+                while (last < nr_events && events[last].channel == events[first].channel) {
+                    last++;
+                }
+                TSL_BUG_IF_FAILED(pager_pocsag_on_events(ch[events[first].channel].pocsag, &events[first], last - first));
+                first = last;
             }
-            TSL_BUG_IF_FAILED(pager_pocsag_on_events(ch[events[first].channel].pocsag, &events[first], last - first));
-            first = last;
+        } else {
+            size_t nr_frames = 0;
+            TSL_BUG_ON(MFM_OK != mfm_flex_process_device(fx, d_out, out_stride, nr_out, NULL));
+            TSL_BUG_ON(MFM_OK != mfm_flex_fetch_events(fx, fevents, max_events, &nr_events, fframes, max_frames, &nr_frames));
+            size_t first = 0;
+            while (first < nr_events) {
+                size_t last = first;
+                while (last < nr_events && fevents[last].channel == fevents[first].channel) {
+                    last++;
+                }
+                TSL_BUG_IF_FAILED(pager_flex_on_events(ch[fevents[first].channel].flex, &fevents[first], last - first, fframes));
+                first = last;
+            }
         }
         sample_count += n;
         if (n < block) {
@@ -312,15 +420,23 @@ int main(int argc, char *const argv[])
     DEC_MSG(SEV_INFO, "TERMINATING", "Terminating processing loop, processed %zu samples per channel", sample_count);
 
     mfm_pocsag_destroy(&pg);
+    mfm_flex_destroy(&fx);
     mfm_resampler_destroy(&rs);
     for (unsigned c = 0; c < nr_chan; c++) {
-        pager_pocsag_delete(&ch[c].pocsag);
+        if (NULL != ch[c].pocsag) {
+            pager_pocsag_delete(&ch[c].pocsag);
+        }
+        if (NULL != ch[c].flex) {
+            pager_flex_delete(&ch[c].flex);
+        }
         close(ch[c].fd);
         if (ch[c].out != stdout) {
             fclose(ch[c].out);
         }
     }
     free(events);
+    free(fevents);
+    free(fframes);
     free(pcm);
     free(ch);
     free(coeffs);

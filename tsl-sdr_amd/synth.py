@@ -417,17 +417,41 @@ def flex_frame_levels(coding, cycle, frame, phases, corrupt=None, fiw_flip=0, a_
     return runs
 
 
-def flex_pcm(frames, amplitude=9000, noise=0.0, lead=0, trail=0, seed=0, offset=0, gap=0):
-    """frames: list of flex_frame_levels() results, sent back to back (`gap` idle samples between them).
-    A level of +-3 is +-amplitude (sync 1 always uses the outer levels).  `offset` adds a DC error."""
+def flex_levels(frames, lead=0, trail=0, gap=0):
+    """frames -> one level per 16 kHz sample (0 outside the frames)"""
     parts = [np.zeros(lead)]
     for k, runs in enumerate(frames):
-        lv = np.repeat(np.array([r[0] for r in runs], dtype=np.float64), [r[1] for r in runs])
-        parts.append(lv * (amplitude / 3.0))
+        parts.append(np.repeat(np.array([r[0] for r in runs], dtype=np.float64), [r[1] for r in runs]))
         if gap and k + 1 < len(frames):
             parts.append(np.zeros(gap))
     parts.append(np.zeros(trail))
-    x = np.concatenate(parts) + offset
+    return np.concatenate(parts)
+
+
+def flex_pcm(frames, amplitude=9000, noise=0.0, lead=0, trail=0, seed=0, offset=0, gap=0, rate=FLEX_RATE):
+    """frames: list of flex_frame_levels() results, sent back to back (`gap` idle samples between them).
+    A level of +-3 is +-amplitude (sync 1 always uses the outer levels).  `offset` adds a DC error.  `rate`: output
+    sample rate (16 000 is what the decoder wants; 25 000 is what a multifm channel delivers)."""
+    lv = flex_levels(frames, lead, trail, gap)
+    if rate != FLEX_RATE:
+        n = lv.size * rate // FLEX_RATE
+        lv = lv[np.minimum((np.arange(n, dtype=np.int64) * FLEX_RATE) // rate, lv.size - 1)]
+    x = lv * (amplitude / 3.0) + offset
     if noise > 0:
         x = x + np.random.RandomState(seed).normal(0.0, noise, size=x.size)
     return np.clip(np.round(x), -32768, 32767).astype(np.int16)
+
+
+def flex_fm_iq(frames, sample_rate_hz, carrier_hz, deviation_hz=4800.0, amplitude=9000.0, lead=0, trail=0, noise=200.0, seed=0):
+    """2- / 4-level FSK at `carrier_hz` from the tuner centre: level +-3 -> +-deviation, +-1 -> +-deviation / 3
+    (a positive shift gives a positive discriminator output, i.e. a one).  lead / trail in 16 kHz samples."""
+    lv = flex_levels(frames, lead, trail)
+    n = int(lv.size * sample_rate_hz // FLEX_RATE)
+    idx = np.minimum((np.arange(n, dtype=np.int64) * FLEX_RATE) // int(sample_rate_hz), lv.size - 1)
+    f = lv[idx] * (deviation_hz / 3.0) + carrier_hz
+    ph = 2.0 * np.pi * np.cumsum(f) / sample_rate_hz
+    rng = np.random.RandomState(seed)
+    out = np.empty((n, 2), np.float64)
+    out[:, 0] = amplitude * np.cos(ph) + rng.normal(0.0, noise, size=n)
+    out[:, 1] = amplitude * np.sin(ph) + rng.normal(0.0, noise, size=n)
+    return out
