@@ -6,4 +6,4 @@ that tests/ and bench.py share.  The directory name has a hyphen, so load it wit
 `__graft_entry__.load_package()` (importlib), which registers it as `tsl_sdr_amd`.
 """
 from . import binding, dist, synth  # noqa: F401
-from .binding import Engine, F32Engine, Group, MfmError, MuellerMuller, Pocsag, Resampler, load_library  # noqa: F401
+from .binding import Engine, F32Engine, Flex, Group, MfmError, MuellerMuller, Pocsag, Resampler, load_library  # noqa: F401

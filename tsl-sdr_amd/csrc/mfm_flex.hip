@@ -43,8 +43,9 @@ namespace {
 
 constexpr uint32_t FX_HIST = 32768; /* samples of history per channel; a frame end looks back 28 560 + 1 440 of them */
 constexpr uint32_t FX_DEAD = 311;   /* first sample after a reset at r that can complete a BS1 register: r + 311 */
-constexpr uint32_t FX_MATCH_WORDS = 64; /* m words per workgroup of the match kernel */
-constexpr uint32_t FX_HALO_WORDS = 10;  /* 310 samples of look-back, rounded up to words */
+constexpr uint32_t FX_MATCH_WORDS = 256; /* m words per workgroup of the match kernel: one per thread */
+constexpr uint32_t FX_HALO_WORDS = 10;   /* 310 samples of look-back, rounded up to words */
+constexpr uint32_t FX_WALK_THREADS = 256; /* four waves per channel; all carry the same state, the frame gather is shared out */
 
 enum : uint32_t { FX_SEARCH = 0, FX_SYNC1 = 1, FX_FRAME = 2 };
 
@@ -71,41 +72,73 @@ struct FxIn {
 
 __device__ __forceinline__ int fx_sample(const FxIn &I, uint32_t c, uint64_t s)
 {
-    if (s >= I.base) {
-        return I.x[(size_t)c * I.stride + (size_t)(s - I.base)];
-    }
-    return I.hist[(size_t)c * FX_HIST + (size_t)(s & (FX_HIST - 1))];
+    /* one load either way: pick the address, not the value */
+    const int16_t *in_block = I.x + (size_t)c * I.stride + (size_t)(s - I.base);
+    const int16_t *in_ring = I.hist + (size_t)c * FX_HIST + (size_t)(s & (FX_HIST - 1));
+    return *(s >= I.base ? in_block : in_ring);
 }
 
 /* ---- m: one bit per sample, "the register this sample goes to now reads BS1" -------------------------------- */
 
-__global__ __launch_bounds__(256) void fx_match_kernel(const FxIn I, uint32_t *M, uint32_t mstride, uint64_t w0, uint32_t nwords)
+struct __attribute__((packed, aligned(2))) FxPcm8 {
+    int16_t v[8];
+};
+
+/* sign bits (sample >= 0, pager_flex.c:137) of the eight samples s .. s + 7, s a multiple of 8 */
+__device__ __forceinline__ uint32_t fx_sign8(const FxIn &I, uint32_t c, int64_t s)
 {
-    __shared__ uint32_t bits[FX_MATCH_WORDS + FX_HALO_WORDS + 2];
-    const uint32_t c = blockIdx.y, wb = blockIdx.x * FX_MATCH_WORDS;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    /* sign bits of samples [32 (w0 + wb - 10), 32 (w0 + wb + 64)): bit = (sample >= 0), pager_flex.c:137 */
-    const int64_t s_first = ((int64_t)(w0 + wb) - (int64_t)FX_HALO_WORDS) * 32;
-    for (uint32_t chunk = wave; chunk < (FX_MATCH_WORDS + FX_HALO_WORDS) / 2; chunk += 4) {
-        const int64_t s = s_first + (int64_t)chunk * 64 + lane;
-        bool b = false;
-        if (s >= 0 && (uint64_t)s < I.end) {
-            b = fx_sample(I, c, (uint64_t)s) >= 0;
+    uint32_t b = 0;
+    if (s >= (int64_t)I.base && (uint64_t)s + 8 <= I.end) {
+        /* the caller's block: any 2-byte alignment, one 16-byte load */
+        const FxPcm8 p = *reinterpret_cast<const FxPcm8 *>(I.x + (size_t)c * I.stride + (size_t)((uint64_t)s - I.base));
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            b |= (uint32_t)(p.v[i] >= 0) << i;
         }
-        const uint64_t bal = __ballot(b);
-        if (lane == 0) {
-            bits[2 * chunk] = (uint32_t)bal;
-            bits[2 * chunk + 1] = (uint32_t)(bal >> 32);
+    } else if (s >= 0 && (uint64_t)s + 8 <= I.base) {
+        /* the history ring: rows and s are multiples of 8, so the eight samples are contiguous and aligned */
+        const uint4 q = *reinterpret_cast<const uint4 *>(I.hist + (size_t)c * FX_HIST + (size_t)((uint64_t)s & (FX_HIST - 1)));
+        const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            b |= (uint32_t)((w[i] & 0x8000u) == 0) << (2 * i);
+            b |= (uint32_t)((w[i] & 0x80000000u) == 0) << (2 * i + 1);
+        }
+    } else {
+        /* a group that straddles the start of the stream, the ring / block seam or the end of the block */
+        for (int i = 0; i < 8; i++) {
+            const int64_t si = s + i;
+            if (si >= 0 && (uint64_t)si < I.end) {
+                b |= (uint32_t)(fx_sample(I, c, (uint64_t)si) >= 0) << i;
+            }
         }
     }
-    if (threadIdx.x == 0) {
+    return b;
+}
+
+/*
+ * M[c][i] covers samples 32 (w0 + i) .. + 31; bits at or beyond the end of the block are zero.  SUM[c][i / 64] bit
+ * (i % 64) says M[c][i] is not zero, so that the walk can step over 4096 words at a time.
+ */
+__global__ __launch_bounds__(256) void fx_match_kernel(const FxIn I, uint32_t *M, uint32_t mstride, uint64_t *SUM, uint32_t sstride,
+                                                       uint64_t w0, uint32_t nwords)
+{
+    __shared__ uint32_t bits[FX_MATCH_WORDS + FX_HALO_WORDS + 2];
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(bits);
+    const uint32_t c = blockIdx.y, wb = blockIdx.x * FX_MATCH_WORDS, t = threadIdx.x;
+    /* sign bits of samples [32 (w0 + wb - 10), 32 (w0 + wb + 256)), eight per byte */
+    const int64_t s_first = ((int64_t)(w0 + wb) - (int64_t)FX_HALO_WORDS) * 32;
+    for (uint32_t g = t; g < 4 * (FX_MATCH_WORDS + FX_HALO_WORDS); g += 256) {
+        bytes[g] = (uint8_t)fx_sign8(I, c, s_first + 8 * (int64_t)g);
+    }
+    if (t == 0) {
         bits[FX_MATCH_WORDS + FX_HALO_WORDS] = 0;
     }
     __syncthreads();
-    const uint32_t t = threadIdx.x;
-    if (t < FX_MATCH_WORDS && wb + t < nwords) {
+    uint32_t m = 0;
+    if (wb + t < nwords) {
         /* register bit k (k = 0 newest) is the sign bit 10 k samples back; BS1 wants a one at every odd k */
-        uint32_t m = 0xffffffffu;
+        m = 0xffffffffu;
 #pragma unroll
         for (uint32_t k = 0; k < 32; k++) {
             const uint32_t off = 32 * FX_HALO_WORDS + 32 * t - 10 * k;
@@ -117,6 +150,10 @@ __global__ __launch_bounds__(256) void fx_match_kernel(const FxIn I, uint32_t *M
             m &= (I.end > i0) ? (0xffffffffu >> (32 - (uint32_t)(I.end - i0))) : 0u;
         }
         M[(size_t)c * mstride + wb + t] = m;
+    }
+    const uint64_t any = __ballot(m != 0);
+    if ((t & 63) == 0 && wb + t < nwords) {
+        SUM[(size_t)c * sstride + ((wb + t) >> 6)] = any;
     }
 }
 
@@ -137,7 +174,8 @@ struct FxState {
 struct FxWalk {
     FxIn I;
     const uint32_t *M;
-    uint32_t mstride;
+    const uint64_t *SUM;
+    uint32_t mstride, sstride, nwords;
     uint64_t w0;
     FxState *st;
     mfm_flex_event *ev;
@@ -208,13 +246,19 @@ __device__ void fx_emit(const FxWalk &L, uint32_t c, uint32_t &nev, uint32_t typ
     nev++;
 }
 
-__global__ __launch_bounds__(64) void fx_walk_kernel(const FxWalk L)
+__global__ __launch_bounds__(FX_WALK_THREADS) void fx_walk_kernel(const FxWalk L)
 {
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x & 63;
     const FxIn &I = L.I;
     const uint64_t end = I.end;
     const uint32_t *M = L.M + (size_t)c * L.mstride;
+    const uint64_t *SUM = L.SUM + (size_t)c * L.sstride;
+    const uint32_t nsum = (L.nwords + 63) >> 6;
+    /* every wave runs the same walk on the same data (wave ballots and shuffles never cross waves); only the frame
+     * gather is divided among the threads.  Nobody may store the new state before everybody has the old one. */
+    __shared__ uint8_t sym[5632]; /* the sliced symbols of the frame being collected */
     FxState S = L.st[c];
+    __syncthreads();
     uint32_t nev = 0, nfw = 0;
 
     for (;;) {
@@ -222,22 +266,30 @@ __global__ __launch_bounds__(64) void fx_walk_kernel(const FxWalk L)
             bool opened = false;
             while (S.p < end) {
                 if (S.run == 0) {
-                    /* nothing open: skip to the next set bit of m, 64 words at a time */
-                    const uint64_t wbase = S.p >> 5, wlast = (end - 1) >> 5;
-                    const uint64_t w = wbase + lane;
-                    uint32_t v = (w <= wlast) ? M[w - L.w0] : 0u;
-                    if (lane == 0) {
-                        v &= 0xffffffffu << (S.p & 31);
+                    /* nothing open: go to the next set bit of m.  First the rest of the word p is in ... */
+                    const uint32_t i = (uint32_t)((S.p >> 5) - L.w0);
+                    const uint32_t head = M[i] & (0xffffffffu << (S.p & 31));
+                    if (head != 0) {
+                        S.p = (S.p & ~(uint64_t)31) + ((uint32_t)__ffs((int)head) - 1); /* < end: m is masked there */
+                    } else {
+                        /* ... then whole words through the summary, 64 x 64 words = 131 072 samples per step */
+                        const uint32_t j = i + 1, sj = j >> 6;
+                        uint64_t v = (sj + lane < nsum) ? SUM[sj + lane] : 0ull;
+                        if (lane == 0) {
+                            v &= ~0ull << (j & 63);
+                        }
+                        const uint64_t nz = __ballot(v != 0);
+                        if (nz == 0) {
+                            const uint64_t next = (L.w0 + (((uint64_t)sj + 64) << 6)) << 5;
+                            S.p = next < end ? next : end; /* what lies beyond `end` belongs to the next call */
+                            continue;
+                        }
+                        const uint32_t fl = (uint32_t)__ffsll((unsigned long long)nz) - 1;
+                        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)fl), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)fl);
+                        const uint64_t fv = (uint64_t)hi << 32 | lo;
+                        const uint32_t wi = ((sj + fl) << 6) + ((uint32_t)__ffsll((unsigned long long)fv) - 1);
+                        S.p = ((L.w0 + wi) << 5) + ((uint32_t)__ffs((int)M[wi]) - 1);
                     }
-                    const uint64_t nz = __ballot(v != 0);
-                    if (nz == 0) {
-                        const uint64_t next = (wbase + 64) << 5;
-                        S.p = next < end ? next : end; /* what lies beyond `end` belongs to the next call */
-                        continue;
-                    }
-                    const uint32_t fl = (uint32_t)__ffsll((unsigned long long)nz) - 1;
-                    const uint32_t fv = (uint32_t)__shfl((int)v, (int)fl);
-                    S.p = ((wbase + fl) << 5) + ((uint32_t)__ffs((int)fv) - 1); /* < end: m is masked there */
                 }
                 /* count the run on from p, one word at a time */
                 const uint32_t sh = (uint32_t)(S.p & 31);
@@ -361,18 +413,26 @@ __global__ __launch_bounds__(64) void fx_walk_kernel(const FxWalk L)
             if (nfw < L.max_fw && nev < L.max_ev) {
                 uint32_t *out = &L.fw[(size_t)c * L.max_fw + nfw].words[0][0];
                 const bool four = cd.levels == 4;
-                for (uint32_t item = lane; item < 4 * MFM_FLEX_PHASE_WORDS; item += 64) {
+                /* slice every symbol of the block once (consecutive threads take consecutive symbols, 10 or 20 bytes
+                 * apart) into one byte each ... */
+#pragma unroll 11
+                for (uint32_t k = threadIdx.x; k < cd.symbols; k += FX_WALK_THREADS) {
+                    const int v = fx_sample(I, c, first + (uint64_t)k * step);
+                    sym[k] = (uint8_t)(four ? fx_slice4(v, S.delta, S.range) : (uint32_t)(v >= 0)); /* 2-level: 1 == symbol (:1246) */
+                }
+                __syncthreads();
+                /* ... then build the words: bit jb of word 8 b + i of a phase is bit 256 b + 8 jb + i of that phase */
+                for (uint32_t item = threadIdx.x; item < 4 * MFM_FLEX_PHASE_WORDS; item += FX_WALK_THREADS) {
                     const uint32_t q = item / MFM_FLEX_PHASE_WORDS, w = item % MFM_FLEX_PHASE_WORDS;
                     /* which symbols phase q rides on (:1242-1285): every one or every second, and which bit of a 4-level one */
                     bool present;
-                    uint32_t mul = 1, add = 0;
-                    bool high_bit = false;
+                    uint32_t mul = 1, add = 0, sel = 0;
                     if (cd.nr_phases == 1) {
                         present = q == 0;
                     } else if (cd.nr_phases == 2) {
                         present = q == 0 || q == 2;
                         if (four) {
-                            high_bit = q == 0;
+                            sel = q == 0;
                         } else {
                             mul = 2;
                             add = q >> 1;
@@ -381,26 +441,19 @@ __global__ __launch_bounds__(64) void fx_walk_kernel(const FxWalk L)
                         present = true;
                         mul = 2;
                         add = q >> 1;
-                        high_bit = (q & 1) == 0;
+                        sel = (q & 1) == 0;
                     }
                     uint32_t word = 0;
                     if (present) {
                         const uint32_t n0 = (w >> 3) * 256 + (w & 7);
+#pragma unroll
                         for (uint32_t jb = 0; jb < 32; jb++) {
-                            const uint32_t sym = (n0 + 8 * jb) * mul + add;
-                            const int v = fx_sample(I, c, first + (uint64_t)sym * step);
-                            uint32_t bit;
-                            if (four) {
-                                const uint32_t s4 = fx_slice4(v, S.delta, S.range);
-                                bit = high_bit ? (s4 >> 1) : (s4 & 1u);
-                            } else {
-                                bit = v >= 0; /* 1 == symbol (:1246) */
-                            }
-                            word |= bit << jb;
+                            word |= (((uint32_t)sym[(n0 + 8 * jb) * mul + add] >> sel) & 1u) << jb;
                         }
                     }
                     out[item] = word;
                 }
+                __syncthreads();
             }
             fx_emit(L, c, nev, MFM_FLEX_EV_FRAME, e, S, 0, nfw);
             nfw++;
@@ -410,7 +463,7 @@ __global__ __launch_bounds__(64) void fx_walk_kernel(const FxWalk L)
         }
     }
 
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         L.st[c] = S;
         L.counts[2 * c] = nev;
         L.counts[2 * c + 1] = nfw;
@@ -444,9 +497,10 @@ thread_local char g_fx_error[256] = "";
 
 struct mfm_flex {
     mfm_flex_config cfg{};
-    uint32_t max_ev = 0, max_fw = 0, mstride = 0;
+    uint32_t max_ev = 0, max_fw = 0, mstride = 0, sstride = 0;
     int16_t *d_hist = nullptr;
     uint32_t *d_m = nullptr;
+    uint64_t *d_sum = nullptr;
     FxState *d_st = nullptr;
     mfm_flex_event *d_ev = nullptr;
     mfm_flex_frame_words *d_fw = nullptr;
@@ -487,12 +541,14 @@ int mfm_flex_create(struct mfm_flex **pf, const struct mfm_flex_config *cfg)
         f->max_fw = f->max_ev;
     }
     f->mstride = cfg->max_in_samples / 32 + 4;
+    f->sstride = f->mstride / 64 + 2;
     const size_t C = cfg->nr_channels;
     *pf = f;
     FX_TRY(hipSetDevice(cfg->device));
     FX_TRY(hipMalloc(&f->d_hist, C * FX_HIST * sizeof(int16_t)));
     FX_TRY(hipMemset(f->d_hist, 0, C * FX_HIST * sizeof(int16_t)));
     FX_TRY(hipMalloc(&f->d_m, C * f->mstride * sizeof(uint32_t)));
+    FX_TRY(hipMalloc(&f->d_sum, C * f->sstride * sizeof(uint64_t)));
     FX_TRY(hipMalloc(&f->d_st, C * sizeof(FxState)));
     {
         /* pager_flex_new (:1371): registers zero-filled "before sample 0", so the search opens at sample 310 */
@@ -522,6 +578,7 @@ void mfm_flex_destroy(struct mfm_flex **pf)
     (void)hipDeviceSynchronize();
     (void)hipFree(f->d_hist);
     (void)hipFree(f->d_m);
+    (void)hipFree(f->d_sum);
     (void)hipFree(f->d_st);
     (void)hipFree(f->d_ev);
     (void)hipFree(f->d_fw);
@@ -551,10 +608,10 @@ int mfm_flex_process_device(struct mfm_flex *f, const int16_t *d_pcm, size_t in_
     const uint64_t w0 = in.base >> 5;
     const uint32_t nwords = (uint32_t)(((in.end - 1) >> 5) - w0 + 1);
     hipLaunchKernelGGL(fx_match_kernel, dim3((nwords + FX_MATCH_WORDS - 1) / FX_MATCH_WORDS, C), dim3(256), 0, s, in, f->d_m,
-                       f->mstride, w0, nwords);
+                       f->mstride, f->d_sum, f->sstride, w0, nwords);
     FX_TRY(hipGetLastError());
-    const FxWalk W{ in, f->d_m, f->mstride, w0, f->d_st, f->d_ev, f->d_fw, f->d_counts, f->max_ev, f->max_fw, f->d_bch };
-    hipLaunchKernelGGL(fx_walk_kernel, dim3(C), dim3(64), 0, s, W);
+    const FxWalk W{ in, f->d_m, f->d_sum, f->mstride, f->sstride, nwords, w0, f->d_st, f->d_ev, f->d_fw, f->d_counts, f->max_ev, f->max_fw, f->d_bch };
+    hipLaunchKernelGGL(fx_walk_kernel, dim3(C), dim3(FX_WALK_THREADS), 0, s, W);
     FX_TRY(hipGetLastError());
     const uint32_t cnt = n < FX_HIST ? n : FX_HIST;
     hipLaunchKernelGGL(fx_hist_kernel, dim3((cnt + 255) / 256, C), dim3(256), 0, s, f->d_hist, d_pcm, in_stride, in.base, n);
