@@ -492,6 +492,7 @@ struct mfm_f32_engine; /* opaque */
 
 #define MFM_F32_WANT_IQ 1u /* also keep the derotated filtered samples (signalDebugFile analogue) */
 #define MFM_F32_PACKED_FMA 2u /* multiply with v_pk_fma_f32 instead of the fp32 matrix instructions (A/B timing) */
+#define MFM_F32_TILE_KERNEL 4u /* the round-1 kernel, one workgroup per tile, instead of the persistent one (A/B timing) */
 
 struct mfm_f32_config {
     uint32_t abi_version; /* MFM_ABI_VERSION */

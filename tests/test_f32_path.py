@@ -44,14 +44,15 @@ def test_oracle_f32_taps_and_int16_path_agree(pkg, ora):
     assert np.allclose(np.concatenate(parts), pcm, rtol=0, atol=1e-9)
 
 
-def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500.0, scale=1.0, packed_fma=False):
+def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500.0, scale=1.0, packed_fma=False,
+              tile_kernel=False, want_iq=True):
     lpf = pkg.synth.design_lpf(ntaps, cutoff, fs)
     offs = pkg.synth.channel_offsets(nch, fs)
     rng = np.random.RandomState(seed)
     gains = 0.5 + rng.rand(nch)
     active = list(range(0, nch, max(1, nch // 6)))[:6]
     iq = pkg.synth.synth_iq(nsamp, fs, [offs[a] for a in active], seed=seed).astype(np.float32) * np.float32(scale)
-    eng = pkg.F32Engine(fs, decim, max(chunks), device=0, want_iq=True, packed_fma=packed_fma)
+    eng = pkg.F32Engine(fs, decim, max(chunks), device=0, want_iq=want_iq, packed_fma=packed_fma, tile_kernel=tile_kernel)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), lpf, float(g))
     eng.commit()
@@ -62,7 +63,7 @@ def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500
         pf, pi, q = eng.process_host(iq[pos:pos + n])
         got_f.append(pf)
         got_i.append(pi)
-        got_q.append(q)
+        got_q.append(q if want_iq else np.zeros(pf.shape + (2,), np.float32))
         pos += n
         k += 1
     eng.close()
@@ -77,7 +78,7 @@ def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500
         ch.close()
     full = np.abs(ref_q).max()
     # FIR + derotation
-    assert np.abs(gq - ref_q).max() <= 1e-5 * full
+    assert not want_iq or np.abs(gq - ref_q).max() <= 1e-5 * full
     # discriminator
     d = _circ(gf.astype(np.float64) - ref_p)
     assert d[active].max() <= 1e-5 * 16384.0
@@ -99,6 +100,17 @@ def _run_case(pkg, ora, fs, decim, ntaps, nch, nsamp, chunks, seed, cutoff=12500
 ])
 def test_gpu_f32_path_matches_fp64_oracle(pkg, ora, fs, decim, ntaps, nch, chunks):
     _run_case(pkg, ora, fs, decim, ntaps, nch, 300000, chunks, seed=11)
+
+
+@pytest.mark.gpu
+def test_gpu_f32_path_without_debug_iq_and_round1_kernel(pkg, ora):
+    """Without MFM_F32_WANT_IQ the persistent kernel stores through its plain path (whole tiles, no per-column
+    predicates) - the way bench.py runs it; MFM_F32_TILE_KERNEL selects the round-1 kernel (one workgroup per tile)."""
+    _run_case(pkg, ora, 2400000, 96, 128, 64, 400000, [1 << 18, 9001], seed=12, want_iq=False)
+    _run_case(pkg, ora, 2400000, 96, 128, 70, 300000, [1 << 17], seed=13, want_iq=False)    # a partly filled channel group
+    _run_case(pkg, ora, 10000000, 400, 512, 20, 300000, [1 << 17], seed=14, want_iq=False)
+    _run_case(pkg, ora, 2400000, 96, 128, 64, 300000, [1 << 18], seed=11, tile_kernel=True)
+    _run_case(pkg, ora, 1200000, 25, 127, 3, 300000, [30001], seed=11, tile_kernel=True, want_iq=False)
 
 
 @pytest.mark.gpu

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--block-log2", type=int, default=24)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--tile-kernel", action="store_true", help="the round-1 kernel (MFM_F32_TILE_KERNEL)")
     args = ap.parse_args()
     import torch
     from __graft_entry__ import load_package
@@ -31,7 +32,7 @@ def main():
     base = pkg.synth.synth_iq(1 << 20, fs, offs[:: max(1, len(offs) // 8)][:8], seed=7)
     iq16 = np.tile(base, (blk // base.shape[0] + 1, 1))[:blk]
     d_f = torch.from_numpy(iq16.astype(np.float32).reshape(-1)).cuda()
-    eng = pkg.F32Engine(fs, decim, blk, device=0)
+    eng = pkg.F32Engine(fs, decim, blk, device=0, tile_kernel=args.tile_kernel)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))
     eng.commit()

@@ -36,6 +36,9 @@
 
 #include "../../include/multifm_hip.h"
 #include "mfm_taps.h"
+__device__ unsigned long long g_f32_trace[2 * 8 * 64 * 8];
+__device__ unsigned long long g_f32_span[1024 * 2];
+#define TR(slot) do { if ((blockIdx.x == 100u || blockIdx.x == 101u) && lane == 0 && it < 64) g_f32_trace[(((blockIdx.x - 100u) * 8 + wave) * 64 + it) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 extern "C" void mfm_internal_set_error(const char *msg);
 
@@ -437,11 +440,6 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel_p(const F32Lau
     for (uint32_t i = tid; i < 256u; i += F_NT) {
         lut_s[i] = L.lut[i];
     }
-    /* two waves of the workgroup share a SIMD and the arbiter favours the older one: without this the second wave of
-     * every pair trails and the other seven wait for it at each chunk's barrier */
-    if (wave >= 4u) {
-        __builtin_amdgcn_s_setprio(1);
-    }
 
     /* staging: thread (row0 = tid / 32, col = tid % 32) owns rows row0 + 16 j of every chunk */
     const uint32_t row0 = tid / P_KT, col = tid % P_KT;
@@ -509,7 +507,8 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel_p(const F32Lau
     stage_store(0);
     __syncthreads();
 
-    uint32_t buf = 0;
+    uint32_t buf = 0, it = 0;
+    if (tid == 0 && blockIdx.x < 1024) g_f32_span[2 * blockIdx.x] = __builtin_amdgcn_s_memtime();
     /* one tile: NG column groups of 16 (4 for a whole tile; the short tile that ends the run gets its own copy of the
      * code, outside the loop over the whole ones) */
     auto do_tile = [&](auto ng_const, const uint32_t tile) {
@@ -525,9 +524,11 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel_p(const F32Lau
                 ntile = tile + 1u;
             }
             const bool more = ntile < t_end;
+            TR(0);
             /* always the same number of loads, so that every path into the multiply phase has the same number of loads in flight
              * behind the A fragments (after the run's last chunk they fetch this chunk again and are dropped) */
             stage_load(more ? ntile : tile, more ? nckk : ck);
+            TR(1);
             /* ---- multiply: acc[row][col] += sum_k W[row][k] * e[col][k] over the chunk, quad-major ---- */
             {
                 const uint32_t baddr = (uint32_t)(uintptr_t)(xs0 + buf * (P_BUF / 8u) + n * P_PITCH) + 16u * kg;
@@ -536,12 +537,16 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel_p(const F32Lau
                 const float4 *anext = afrag_w + (size_t)nckk * P_NQ * 64u;
                 p_phase<NG>(std::make_integer_sequence<uint32_t, NG * P_NQ>{}, a, macc, b_even, b_odd, baddr, anext);
             }
+            TR(2);
             if (more) {
                 stage_store(buf ^ 1u);
             }
+            TR(3);
             __syncthreads();
+            TR(4);
             buf ^= 1u;
             if (ck + 1u < nck) {
+                it++;
                 continue;
             }
 
@@ -633,6 +638,8 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel_p(const F32Lau
                     }
                 }
             }
+            TR(5);
+            it++;
         }
     };
 
@@ -659,6 +666,7 @@ __global__ __launch_bounds__(F_NT, 4) void mfm_f32_channel_kernel_p(const F32Lau
             break;
         }
     }
+    if (tid == 0 && blockIdx.x < 1024) g_f32_span[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
 
 /* what this call leaves unconsumed: samples pos_end .. pos_end + new_tail of the virtual stream */
@@ -1028,3 +1036,12 @@ int mfm_f32_process_host(struct mfm_f32_engine *e, const float *iq, size_t nr_sa
 }
 
 } /* extern "C" */
+
+extern "C" int mfm_f32_debug_trace(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f32_trace), sizeof(g_f32_trace)) == hipSuccess ? 0 : -1;
+}
+extern "C" int mfm_f32_debug_span(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f32_span), sizeof(g_f32_span)) == hipSuccess ? 0 : -1;
+}

@@ -127,6 +127,7 @@ class F32Block(C.Structure):
 
 MFM_F32_WANT_IQ = 1
 MFM_F32_PACKED_FMA = 2
+MFM_F32_TILE_KERNEL = 4
 
 
 class MmConfig(C.Structure):
@@ -560,11 +561,13 @@ class Resampler:
 class F32Engine:
     """mfm_f32_*: the channel path on float32 IQ (FIR, derotation, discriminator in fp32)."""
 
-    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, want_iq=False, packed_fma=False):
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, want_iq=False, packed_fma=False,
+                 tile_kernel=False):
         self.lib = load_library()
         self.h = C.c_void_p()
         cfg = F32Config(MFM_ABI_VERSION, device, sample_rate_hz, decimation, max_block_samples,
-                        (MFM_F32_WANT_IQ if want_iq else 0) | (MFM_F32_PACKED_FMA if packed_fma else 0))
+                        (MFM_F32_WANT_IQ if want_iq else 0) | (MFM_F32_PACKED_FMA if packed_fma else 0) |
+                        (MFM_F32_TILE_KERNEL if tile_kernel else 0))
         rc = self.lib.mfm_f32_create(C.byref(self.h), C.byref(cfg))
         if rc < 0:
             raise MfmError(rc, "mfm_f32_create", self.lib.mfm_strerror(rc).decode())
