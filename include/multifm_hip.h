@@ -263,7 +263,11 @@ struct mfm_resampler_config {
     uint32_t invert;         /* decoder -i: negate the input samples (decoder.c:621-626) */
     uint32_t dc_block;       /* decoder -b */
     double dc_pole;          /* decoder -p, only with dc_block */
+    uint32_t flags;          /* MFM_RS_* */
+    uint32_t reserved;       /* 0 */
 };
+
+#define MFM_RS_FORCE_DOT2 1u /* the v_dot2 kernel even where the matrix-core form applies (A/B timing; same bits out) */
 
 /* coeffs are the Q14 int16 taps (decoder.c:530-533 quantises lpfCoeffs with (int16_t)(c * 16384)) */
 int mfm_resampler_create(struct mfm_resampler **pr, const struct mfm_resampler_config *cfg, const int16_t *coeffs,

@@ -81,6 +81,36 @@ def test_gpu_resampler_matches_oracle(pkg, ora, interp, decim, ntaps, nch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("interp,decim,ntaps", [(16, 25, 821), (4, 5, 81), (16, 25, 400), (8, 5, 200), (2, 3, 96), (1, 2, 120)])
+def test_gpu_resampler_matrix_form_wraps_like_the_reference(pkg, ora, interp, decim, ntaps):
+    """The matrix-core form (16 D / I integer) splits taps and samples into bytes; full-scale taps up to +-32639 and
+    full-scale samples make the int32 sums wrap (filter/utils.c:94-103) - it must wrap identically, block after block,
+    and give the same bits as the v_dot2 form (MFM_RS_FORCE_DOT2).  One tap beyond +-32639 (32767): the engine must
+    fall back to v_dot2 by itself."""
+    rng = np.random.RandomState(ntaps)
+    nch, n = 4, 150000
+    x = rng.randint(-32768, 32768, size=(nch, n)).astype(np.int16)
+    x[1] = 32767
+    x[2] = -32768
+    for big in (32639, 32767):
+        taps = rng.randint(-32639, 32640, size=ntaps).astype(np.int16)
+        taps[rng.randint(ntaps)] = big
+        taps[rng.randint(ntaps)] = -32639
+        refs = [ora.Resampler(taps, interp, decim) for _ in range(nch)]
+        want = np.stack([r.feed(x[c]) for c, r in enumerate(refs)])
+        for force in (False, True):
+            gpu = pkg.Resampler(nch, taps, interp, decim, 65536, device=0, force_dot2=force)
+            got, pos = [], 0
+            for m in (65536, 3, 40001, 65536):
+                got.append(gpu.process_host(x[:, pos:pos + m]))
+                pos += m
+            gpu.close()
+            got = np.concatenate(got, axis=1)
+            assert got.shape == want[:, :got.shape[1]].shape and got.shape[1] > 0
+            assert np.array_equal(got, want[:, :got.shape[1]]), f"big={big} force_dot2={force}"
+
+
+@pytest.mark.gpu
 def test_gpu_chain_engine_to_resampler_stays_on_device(pkg, ora):
     """BASELINE configs[3] front half: etc/pocsag_rtlsdr.json values (fs 1.2 MS/s, D 25 -> 48 kS/s PCM, channel 0
     with dBGain 4.0), then 4/5 to the 38 400 Hz the POCSAG decoder wants; PCM goes from the channel kernel to

@@ -112,7 +112,11 @@ MFM_FLEX_EV_FRAME, MFM_FLEX_EV_BAD_BAUD, MFM_FLEX_EV_BAD_FIW = 1, 2, 3
 class ResamplerConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("nr_channels", C.c_uint32),
                 ("interpolate", C.c_uint32), ("decimate", C.c_uint32), ("max_in_samples", C.c_uint32),
-                ("invert", C.c_uint32), ("dc_block", C.c_uint32), ("dc_pole", C.c_double)]
+                ("invert", C.c_uint32), ("dc_block", C.c_uint32), ("dc_pole", C.c_double), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+MFM_RS_FORCE_DOT2 = 1
 
 
 class F32Config(C.Structure):
@@ -513,11 +517,12 @@ class Resampler:
     """mfm_resampler: rational resampler (+ optional DC blocker) for all channels of a PCM block."""
 
     def __init__(self, nr_channels, coeffs_q14, interpolate, decimate, max_in_samples, device=0, invert=False,
-                 dc_pole=None):
+                 dc_pole=None, force_dot2=False):
         self.lib = load_library()
         self.h = C.c_void_p()
         cfg = ResamplerConfig(MFM_ABI_VERSION, device, nr_channels, interpolate, decimate, max_in_samples,
-                              int(invert), int(dc_pole is not None), float(dc_pole or 0.0))
+                              int(invert), int(dc_pole is not None), float(dc_pole or 0.0),
+                              MFM_RS_FORCE_DOT2 if force_dot2 else 0, 0)
         co = np.ascontiguousarray(coeffs_q14, dtype=np.int16)
         rc = self.lib.mfm_resampler_create(C.byref(self.h), C.byref(cfg), _i16p(co), co.size)
         if rc < 0:

@@ -12,6 +12,18 @@
  * funnel shift per pair).  When 256 * D is a multiple of I - 4/5 for POCSAG, 16/25 for FLEX - a thread's four
  * outputs share one phase and its coefficient pairs stay in registers; otherwise they are read from LDS.
  * HBM traffic: 2 bytes in + 2 * I / D bytes out per PCM sample.
+ *
+ * Matrix-core form (round 2; used when 16 D / I is an integer - 4/5 and 16/25 both - and the window fits 256 bytes).
+ * The v_dot2 form is bound by the vector ALU, not by memory: 16/25 with the reference's 821 taps is 26 coefficient
+ * pairs = 78 instructions per output, 0.11 ms per block for 64 channels where the channel kernel in front of it takes
+ * 0.125.  Sixteen consecutive outputs consume exactly R = 16 D / I samples and their phases repeat from block to
+ * block, so  y[16 m + q] = sum_s G[q][s] x[R m + s]  with ONE 16 x K matrix G (row q = the phase of output q shifted
+ * to where its window starts, zero elsewhere; one G per value of the carried phase) - a GEMM with M = 16 = the matrix
+ * instruction's M, columns = blocks of 16 outputs.  int16 x int16 -> wrapping int32 is done exactly as in the channel
+ * kernel (mfm_kernel_mfma.hip): W = 256 Wh + Wl, x = 256 Xh + Xl + 128, four v_mfma_i32_16x16x64_i8 per 64 elements.
+ * The input lies in LDS as two byte planes in rows of R samples padded to 16-byte multiples (zero coefficients over
+ * the padding), so that a lane's B operand is one aligned ds_read_b128: the window of block m is rows m, m+1, ...
+ * A lane ends up with four consecutive outputs of one block: one 8-byte store.
  * The DC blocker is a sequential IIR with a truncating shift in the loop (not associative): one thread
  * per channel.
  */
@@ -148,6 +160,126 @@ __global__ void mfm_rs_tail_kernel(const RsLaunch L)
     }
 }
 
+/* ---- matrix-core form ------------------------------------------------------------------------------------- */
+
+typedef int rs_v4i __attribute__((ext_vector_type(4)));
+
+struct RsMLaunch {
+    RsLaunch b;
+    const rs_v4i *gfrag; /* [2 planes: Wh, Wl][KS][64 lanes] A fragments of G for this call's carried phase */
+    const int32_t *krow; /* [16]: 128 * sum of row q of G (the x = ... + 128 term) */
+    uint32_t R;          /* samples per block of 16 outputs = 16 D / I */
+    uint32_t rp;         /* bytes per row in LDS: R rounded up to a multiple of 16 */
+    uint32_t plane;      /* bytes per byte plane in LDS */
+};
+
+constexpr uint32_t RSM_NT = 256;  /* threads per workgroup (4 waves) */
+constexpr uint32_t RSM_NB = 256;  /* blocks of 16 outputs per workgroup: each wave does four column groups of 16 blocks */
+
+struct __attribute__((packed, aligned(2))) RsPcm8 {
+    int16_t v[8];
+};
+
+template <int KS>
+__global__ __launch_bounds__(RSM_NT) void mfm_resample_mfma_kernel(const RsMLaunch M)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t rs_smem[];
+    const RsLaunch &L = M.b;
+    uint8_t *const pl_h = rs_smem, *const pl_l = rs_smem + M.plane;
+    const uint32_t c = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b0 = blockIdx.x * RSM_NB;                  /* first block of this workgroup */
+    const uint32_t nrows = RSM_NB + (64u * KS + M.rp - 1u) / M.rp; /* image rows: the last block's window is 64 KS bytes long */
+    const uint32_t v0 = b0 * M.R;
+
+    /* ---- stage: a work item = eight samples of one row, as two 8-byte LDS writes (one per byte plane).  The last
+     * group of a row runs into the padding (8 ceil(R / 8) <= rp) and carries the next row's first samples there -
+     * G is zero over the padding ---- */
+    const uint32_t g8 = (M.R + 7u) / 8u;                       /* groups per row */
+    for (uint32_t it = tid; it < nrows * g8; it += RSM_NT) {
+        const uint32_t row = it / g8, grp = it - row * g8;
+        const uint32_t v = v0 + row * M.R + 8u * grp;
+        uint32_t w[4];
+        if (v >= L.tail_len && v + 8u <= L.tail_len + L.nr_in) {
+            const RsPcm8 p = *reinterpret_cast<const RsPcm8 *>(L.pcm + (size_t)c * L.in_stride + (v - L.tail_len));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                w[i] = mfm_pack16(p.v[2 * i], p.v[2 * i + 1]);
+            }
+            if (L.invert) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    w[i] = mfm_pack16(-(int32_t)p.v[2 * i], -(int32_t)p.v[2 * i + 1]); /* decoder.c:624 on int16 storage */
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { /* the tail of the previous call, the seam, zeros past the end */
+                w[i] = mfm_pack16(rs_sample(L, c, v + 2u * (uint32_t)i), rs_sample(L, c, v + 2u * (uint32_t)i + 1u));
+            }
+        }
+        uint2 lo, hi;
+        lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u) ^ 0x80808080u; /* Xl = (x & 255) - 128 */
+        lo.y = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u) ^ 0x80808080u;
+        hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x07050301u);                /* Xh = x >> 8 */
+        hi.y = __builtin_amdgcn_perm(w[3], w[2], 0x07050301u);
+        const uint32_t at = row * M.rp + 8u * grp;
+        *reinterpret_cast<uint2 *>(pl_l + at) = lo;
+        *reinterpret_cast<uint2 *>(pl_h + at) = hi;
+    }
+    __syncthreads();
+
+    /* ---- multiply: lane (kg, n) reads 16 bytes of column (block) n at element 64 ks + 16 kg ---- */
+    const uint32_t kg = lane >> 4, n = lane & 15u;
+    rs_v4i a_h[KS], a_l[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        a_h[ks] = M.gfrag[(0 * KS + ks) * 64 + lane];
+        a_l[ks] = M.gfrag[(1 * KS + ks) * 64 + lane];
+    }
+    rs_v4i kr;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        kr[i] = M.krow[4u * kg + (uint32_t)i];
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+        const uint32_t blk = wave * 64u + g * 16u + n;          /* block within the workgroup */
+        const uint32_t off = blk * M.rp + 16u * kg;
+        rs_v4i hh = { 0, 0, 0, 0 }, md = hh, ll = hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const rs_v4i b_h = *reinterpret_cast<const rs_v4i *>(pl_h + off + 64u * ks);
+            const rs_v4i b_l = *reinterpret_cast<const rs_v4i *>(pl_l + off + 64u * ks);
+            hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[ks], b_h, hh, 0, 0, 0);
+            md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[ks], b_l, md, 0, 0, 0);
+            ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[ks], b_l, ll, 0, 0, 0);
+            md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[ks], b_h, md, 0, 0, 0);
+        }
+        /* rows 4 kg .. 4 kg + 3 of column n = outputs 16 (b0 + blk) + 4 kg + i */
+        const uint32_t j = 16u * (b0 + blk) + 4u * kg;
+        int32_t y[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t acc = (uint32_t)ll[i] + ((uint32_t)md[i] << 8) + ((uint32_t)hh[i] << 16) + (uint32_t)kr[i];
+            y[i] = mfm_r14_wide((int32_t)acc); /* utils.c:112 */
+        }
+        int16_t *dst = L.y + (size_t)c * L.out_cap + j;
+        if (j + 4u <= L.n_out) {
+            uint2 w;
+            w.x = mfm_pack16(y[0], y[1]);
+            w.y = mfm_pack16(y[2], y[3]);
+            *reinterpret_cast<uint2 *>(dst) = w; /* out_cap and j are multiples of 4: 8-byte aligned */
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (j + (uint32_t)i < L.n_out) {
+                    dst[i] = (int16_t)y[i];
+                }
+            }
+        }
+    }
+}
+
 struct DcState {
     int32_t x_n_1, y_n_1, acc;
 };
@@ -190,6 +322,11 @@ struct mfm_resampler {
     uint32_t tail = 0; /* unconsumed samples in d_x[cur] */
     uint32_t phase_id = 0;
     int16_t *d_stage = nullptr; /* process_host_to_device: [C][max_in_samples] */
+    /* matrix-core form */
+    bool use_mfma = false;
+    uint32_t m_ks = 0, m_R = 0, m_rp = 0, m_plane = 0, m_lds = 0;
+    rs_v4i *d_gfrag = nullptr; /* [I][2][KS][64] */
+    int32_t *d_krow = nullptr; /* [I][16] */
 };
 
 #define RS_TRY(expr)                                                                                         \
@@ -239,6 +376,7 @@ int mfm_resampler_create(struct mfm_resampler **pr, const struct mfm_resampler_c
     }
     r->in_cap = cfg->max_in_samples + plen + 64;
     r->out_cap = (uint32_t)(((uint64_t)r->in_cap * cfg->interpolate) / cfg->decimate + 8);
+    r->out_cap = (r->out_cap + 3u) & ~3u; /* rows of the output start 8-byte aligned (the matrix-core form stores four outputs at once) */
     if ((uint64_t)r->out_cap * cfg->decimate >= (1ull << 32)) {
         delete r;
         return MFM_E_INVAL;
@@ -272,6 +410,64 @@ int mfm_resampler_create(struct mfm_resampler **pr, const struct mfm_resampler_c
         RS_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_resample_kernel<0>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
+    /* ---- matrix-core form: y[16 m + q] = sum_s G[q][s] x[R m + s], one G per carried phase (see the head of the file) ---- */
+    {
+        const uint32_t I = cfg->interpolate, D = cfg->decimate;
+        bool ok = (16u * D) % I == 0u && !(cfg->flags & MFM_RS_FORCE_DOT2);
+        const uint32_t R = ok ? 16u * D / I : 0u;
+        const uint32_t rp = (R + 15u) & ~15u;
+        /* output q of a block starts its window floor((phi + q D) / I) samples into the block, phi < I */
+        const uint32_t max_off = (I - 1u + 15u * D) / I;
+        uint32_t K = 0;
+        if (ok) {
+            const uint32_t last = max_off + plen - 1u;                  /* last sample index (from the block's first) with a coefficient */
+            K = (last / R) * rp + last % R + 1u;                        /* its byte position in the padded rows, + 1 */
+            K = (K + 63u) & ~63u;
+            ok = K <= 256u && R <= 240u;
+        }
+        for (size_t i = 0; ok && i < ph.size(); i++) {
+            ok = ph[i] >= -32639 && ph[i] <= 32639;                     /* W = 256 Wh + Wl with both in [-128, 127] */
+        }
+        if (ok) {
+            const uint32_t KS = K / 64u;
+            std::vector<int8_t> frag((size_t)I * 2u * KS * 64u * 16u, 0);
+            std::vector<int32_t> krow((size_t)I * 16u, 0);
+            for (uint32_t phi = 0; phi < I; phi++) {
+                for (uint32_t q = 0; q < 16; q++) {
+                    const uint32_t t = phi + q * D, off = t / I, phq = t % I;
+                    uint32_t sum = 0;
+                    for (uint32_t kk = 0; kk < K; kk++) {
+                        const uint32_t row = kk / rp, col = kk % rp;
+                        int32_t w = 0;
+                        if (col < R) {
+                            const int64_t tap = (int64_t)(row * R + col) - (int64_t)off;
+                            if (tap >= 0 && tap < (int64_t)plen) {
+                                w = ph[(size_t)phq * plen + (size_t)tap];
+                            }
+                        }
+                        sum += (uint32_t)w;
+                        const int32_t wl = (int8_t)(w & 0xff), wh = (w - wl) >> 8;
+                        /* v_mfma_i32_16x16x64_i8 A operand: lane (kg = lane >> 4, i = lane & 15) holds row i, elements 64 ks + 16 kg + j */
+                        const uint32_t ks = kk / 64u, kgq = (kk % 64u) / 16u, j = kk % 16u, ln = kgq * 16u + q;
+                        frag[((((size_t)phi * 2u + 0u) * KS + ks) * 64u + ln) * 16u + j] = (int8_t)wh;
+                        frag[((((size_t)phi * 2u + 1u) * KS + ks) * 64u + ln) * 16u + j] = (int8_t)wl;
+                    }
+                    krow[(size_t)phi * 16u + q] = (int32_t)(128u * sum);
+                }
+            }
+            r->use_mfma = true;
+            r->m_ks = KS;
+            r->m_R = R;
+            r->m_rp = rp;
+            const uint32_t nrows = RSM_NB + (K + rp - 1u) / rp;
+            r->m_plane = (nrows * rp + 63u) & ~63u;
+            r->m_lds = 2u * r->m_plane;
+            RS_TRY(hipMalloc(&r->d_gfrag, frag.size()));
+            RS_TRY(hipMemcpy(r->d_gfrag, frag.data(), frag.size(), hipMemcpyHostToDevice));
+            RS_TRY(hipMalloc(&r->d_krow, krow.size() * 4));
+            RS_TRY(hipMemcpy(r->d_krow, krow.data(), krow.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     RS_TRY(hipMalloc(&r->d_y, (size_t)cfg->nr_channels * r->out_cap * 2));
     RS_TRY(hipMalloc(&r->d_dc, (size_t)cfg->nr_channels * sizeof(DcState)));
     RS_TRY(hipMemset(r->d_dc, 0, (size_t)cfg->nr_channels * sizeof(DcState)));
@@ -293,6 +489,8 @@ void mfm_resampler_destroy(struct mfm_resampler **pr)
     (void)hipFree(r->d_y);
     (void)hipFree(r->d_dc);
     (void)hipFree(r->d_stage);
+    (void)hipFree(r->d_gfrag);
+    (void)hipFree(r->d_krow);
     delete r;
     *pr = nullptr;
 }
@@ -330,7 +528,18 @@ int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, 
     const uint32_t new_tail = total - pos_end;
     RsLaunch L{ r->d_x[r->cur], d_pcm, r->d_y, r->d_phase, r->d_x[r->cur ^ 1], in_stride, r->tail, (uint32_t)nr_in, r->tail_cap,
                 r->out_cap, n_out, r->plen, I, D, r->phase_id, C, r->cfg.invert, pos_end, new_tail };
-    if (n_out) {
+    if (n_out && r->use_mfma) {
+        RsMLaunch M{ L, r->d_gfrag + (size_t)r->phase_id * 2u * r->m_ks * 64u, r->d_krow + (size_t)r->phase_id * 16u, r->m_R, r->m_rp,
+                     r->m_plane };
+        const dim3 grid((n_out + 16u * RSM_NB - 1u) / (16u * RSM_NB), C);
+        switch (r->m_ks) {
+        case 1: hipLaunchKernelGGL(mfm_resample_mfma_kernel<1>, grid, dim3(RSM_NT), r->m_lds, s, M); break;
+        case 2: hipLaunchKernelGGL(mfm_resample_mfma_kernel<2>, grid, dim3(RSM_NT), r->m_lds, s, M); break;
+        case 3: hipLaunchKernelGGL(mfm_resample_mfma_kernel<3>, grid, dim3(RSM_NT), r->m_lds, s, M); break;
+        default: hipLaunchKernelGGL(mfm_resample_mfma_kernel<4>, grid, dim3(RSM_NT), r->m_lds, s, M); break;
+        }
+        RS_TRY(hipGetLastError());
+    } else if (n_out) {
         const dim3 grid((n_out + RS_OPB - 1) / RS_OPB, C);
         const uint32_t np4 = r->reg_coef ? (r->plen / 2u + 3u) / 4u : 0u; /* register variant: pairs rounded up to 4 */
         switch (np4) {
@@ -345,6 +554,8 @@ int mfm_resampler_process_device(struct mfm_resampler *r, const int16_t *d_pcm, 
         default: hipLaunchKernelGGL(mfm_resample_kernel<0>, grid, dim3(RS_NT), r->lds_bytes, s, L); break;
         }
         RS_TRY(hipGetLastError());
+    }
+    if (n_out) {
         if (r->cfg.dc_block) {
             hipLaunchKernelGGL(mfm_dc_block_kernel, dim3((C + 63) / 64), dim3(64), 0, s, r->d_y, r->out_cap, n_out, C,
                                r->dc_p, r->d_dc);
