@@ -20,12 +20,13 @@
  *           and bit n of a phase is a fixed symbol of the block (de-interleave: word 8 b + i, bit q  <-  bit
  *           256 b + 8 q + i of the phase).
  *
- * So per channel one wave walks from event to event (fx_walk_kernel): scan m for the next run (64 words = 2048
- * samples per step while nothing matches), gather the 112 sync samples with two ballots, reduce the swing, check
- * the A code and the FIW (BCH table of the POCSAG stage), then gather the 88 x phases words of the frame straight
- * from the PCM - each lane builds whole words from 32 strided samples - and jump to the frame's end.  Samples
- * come from the caller's block or, for the part of a frame that arrived with earlier calls, from a 32 768-sample
- * history ring per channel (fx_hist_kernel refreshes it after the walk).
+ * So per channel one wave walks from event to event (fx_walk_kernel): scan m for the next run (a summary bit per word
+ * lets it step over 131 072 idle samples at a time), gather the 112 sync samples with two ballots, reduce the swing,
+ * check the A code and the FIW (BCH table of the POCSAG stage, copied to LDS on first use) and jump to the frame's end,
+ * leaving a descriptor (first symbol's sample, coding, swing).  The words of all frames found in the call are then built
+ * in parallel (fx_gather_kernel, one workgroup per frame): every symbol is sliced once into an LDS byte, the 88 x
+ * phases words are assembled from LDS.  Samples come from the caller's block or, for the part of a frame that arrived
+ * with earlier calls, from a 32 768-sample history ring per channel (fx_hist_kernel refreshes it last).
  */
 #include <hip/hip_runtime.h>
 
@@ -45,7 +46,7 @@ constexpr uint32_t FX_HIST = 32768; /* samples of history per channel; a frame e
 constexpr uint32_t FX_DEAD = 311;   /* first sample after a reset at r that can complete a BS1 register: r + 311 */
 constexpr uint32_t FX_MATCH_WORDS = 256; /* m words per workgroup of the match kernel: one per thread */
 constexpr uint32_t FX_HALO_WORDS = 10;   /* 310 samples of look-back, rounded up to words */
-constexpr uint32_t FX_WALK_THREADS = 256; /* four waves per channel; all carry the same state, the frame gather is shared out */
+constexpr uint32_t FX_GATHER_THREADS = 256; /* one workgroup per frame builds its 88 x phases words */
 
 enum : uint32_t { FX_SEARCH = 0, FX_SYNC1 = 1, FX_FRAME = 2 };
 
@@ -171,6 +172,14 @@ struct FxState {
     uint32_t cycle, frame, pad;
 };
 
+/* a collected frame, as the walk leaves it for the gather kernel */
+struct FxFrameDesc {
+    uint64_t first;    /* sample of the block's first symbol */
+    uint32_t coding;
+    int32_t range, delta;
+    uint32_t pad;
+};
+
 struct FxWalk {
     FxIn I;
     const uint32_t *M;
@@ -180,6 +189,7 @@ struct FxWalk {
     FxState *st;
     mfm_flex_event *ev;
     mfm_flex_frame_words *fw;
+    struct FxFrameDesc *fd; /* [channel][max_fw]: what fx_gather_kernel needs to build fw */
     uint32_t *counts;  /* [channel][2]: events, frames of this call */
     uint32_t max_ev, max_fw;
     const MfmBchTables *bch;
@@ -246,19 +256,18 @@ __device__ void fx_emit(const FxWalk &L, uint32_t c, uint32_t &nev, uint32_t typ
     nev++;
 }
 
-__global__ __launch_bounds__(FX_WALK_THREADS) void fx_walk_kernel(const FxWalk L)
+__global__ __launch_bounds__(64) void fx_walk_kernel(const FxWalk L)
 {
-    const uint32_t c = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
     const FxIn &I = L.I;
     const uint64_t end = I.end;
     const uint32_t *M = L.M + (size_t)c * L.mstride;
     const uint64_t *SUM = L.SUM + (size_t)c * L.sstride;
     const uint32_t nsum = (L.nwords + 63) >> 6;
-    /* every wave runs the same walk on the same data (wave ballots and shuffles never cross waves); only the frame
-     * gather is divided among the threads.  Nobody may store the new state before everybody has the old one. */
-    __shared__ uint8_t sym[5632]; /* the sliced symbols of the frame being collected */
+    /* the BCH tables, copied on the first frame information word of the call (an idle channel never pays for it) */
+    __shared__ MfmBchTables bch_s;
+    bool have_bch = false;
     FxState S = L.st[c];
-    __syncthreads();
     uint32_t nev = 0, nfw = 0;
 
     for (;;) {
@@ -379,7 +388,15 @@ __global__ __launch_bounds__(FX_WALK_THREADS) void fx_walk_kernel(const FxWalk L
                 S.range = (int16_t)(high - low);
                 S.delta = (int16_t)(high - S.range / 2);
                 uint32_t bad;
-                S.fiw = mfm_bch_fix(L.bch, S.fiw_raw & 0x7fffffffu, &bad); /* :1319-1327 */
+                if (!have_bch) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(L.bch);
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(&bch_s);
+                    for (uint32_t i = lane; i < sizeof(MfmBchTables) / 4u; i += 64u) {
+                        dst[i] = src[i];
+                    }
+                    have_bch = true; /* one wave: its LDS writes are visible to its later reads in program order */
+                }
+                S.fiw = mfm_bch_fix(&bch_s, S.fiw_raw & 0x7fffffffu, &bad); /* :1319-1327 */
                 if (bad) {
                     rc = 1;
                 } else if (fx_checksum(S.fiw) != 0xfu) {
@@ -410,50 +427,9 @@ __global__ __launch_bounds__(FX_WALK_THREADS) void fx_walk_kernel(const FxWalk L
             if (e >= end) {
                 break;
             }
-            if (nfw < L.max_fw && nev < L.max_ev) {
-                uint32_t *out = &L.fw[(size_t)c * L.max_fw + nfw].words[0][0];
-                const bool four = cd.levels == 4;
-                /* slice every symbol of the block once (consecutive threads take consecutive symbols, 10 or 20 bytes
-                 * apart) into one byte each ... */
-#pragma unroll 11
-                for (uint32_t k = threadIdx.x; k < cd.symbols; k += FX_WALK_THREADS) {
-                    const int v = fx_sample(I, c, first + (uint64_t)k * step);
-                    sym[k] = (uint8_t)(four ? fx_slice4(v, S.delta, S.range) : (uint32_t)(v >= 0)); /* 2-level: 1 == symbol (:1246) */
-                }
-                __syncthreads();
-                /* ... then build the words: bit jb of word 8 b + i of a phase is bit 256 b + 8 jb + i of that phase */
-                for (uint32_t item = threadIdx.x; item < 4 * MFM_FLEX_PHASE_WORDS; item += FX_WALK_THREADS) {
-                    const uint32_t q = item / MFM_FLEX_PHASE_WORDS, w = item % MFM_FLEX_PHASE_WORDS;
-                    /* which symbols phase q rides on (:1242-1285): every one or every second, and which bit of a 4-level one */
-                    bool present;
-                    uint32_t mul = 1, add = 0, sel = 0;
-                    if (cd.nr_phases == 1) {
-                        present = q == 0;
-                    } else if (cd.nr_phases == 2) {
-                        present = q == 0 || q == 2;
-                        if (four) {
-                            sel = q == 0;
-                        } else {
-                            mul = 2;
-                            add = q >> 1;
-                        }
-                    } else {
-                        present = true;
-                        mul = 2;
-                        add = q >> 1;
-                        sel = (q & 1) == 0;
-                    }
-                    uint32_t word = 0;
-                    if (present) {
-                        const uint32_t n0 = (w >> 3) * 256 + (w & 7);
-#pragma unroll
-                        for (uint32_t jb = 0; jb < 32; jb++) {
-                            word |= (((uint32_t)sym[(n0 + 8 * jb) * mul + add] >> sel) & 1u) << jb;
-                        }
-                    }
-                    out[item] = word;
-                }
-                __syncthreads();
+            if (nfw < L.max_fw && nev < L.max_ev && lane == 0) {
+                /* the words are built by fx_gather_kernel, one workgroup per frame, behind this kernel */
+                L.fd[(size_t)c * L.max_fw + nfw] = FxFrameDesc{ first, S.coding, S.range, S.delta, 0u };
             }
             fx_emit(L, c, nev, MFM_FLEX_EV_FRAME, e, S, 0, nfw);
             nfw++;
@@ -463,10 +439,67 @@ __global__ __launch_bounds__(FX_WALK_THREADS) void fx_walk_kernel(const FxWalk L
         }
     }
 
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         L.st[c] = S;
         L.counts[2 * c] = nev;
         L.counts[2 * c + 1] = nfw;
+    }
+}
+
+/*
+ * The words of the frames the walk found: grid (max_fw, channels), one workgroup per frame.  Every symbol of the block
+ * is sliced once (consecutive threads take consecutive symbols, 10 or 20 bytes apart) into one LDS byte, then the
+ * 88 x phases words are built from LDS: bit jb of word 8 b + i of a phase is bit 256 b + 8 jb + i of that phase.
+ */
+__global__ __launch_bounds__(FX_GATHER_THREADS) void fx_gather_kernel(const FxWalk L)
+{
+    __shared__ uint8_t sym[5632];
+    const uint32_t c = blockIdx.y, f = blockIdx.x;
+    const uint32_t nfw = L.counts[2 * c + 1] < L.max_fw ? L.counts[2 * c + 1] : L.max_fw;
+    if (f >= nfw) {
+        return;
+    }
+    const FxFrameDesc d = L.fd[(size_t)c * L.max_fw + f];
+    const FxCoding cd = fx_codings[d.coding];
+    const uint32_t step = cd.skip + 1u;
+    const bool four = cd.levels == 4;
+    uint32_t *out = &L.fw[(size_t)c * L.max_fw + f].words[0][0];
+#pragma unroll 11
+    for (uint32_t k = threadIdx.x; k < cd.symbols; k += FX_GATHER_THREADS) {
+        const int v = fx_sample(L.I, c, d.first + (uint64_t)k * step);
+        sym[k] = (uint8_t)(four ? fx_slice4(v, d.delta, d.range) : (uint32_t)(v >= 0)); /* 2-level: 1 == symbol (:1246) */
+    }
+    __syncthreads();
+    for (uint32_t item = threadIdx.x; item < 4 * MFM_FLEX_PHASE_WORDS; item += FX_GATHER_THREADS) {
+        const uint32_t q = item / MFM_FLEX_PHASE_WORDS, w = item % MFM_FLEX_PHASE_WORDS;
+        /* which symbols phase q rides on (:1242-1285): every one or every second, and which bit of a 4-level one */
+        bool present;
+        uint32_t mul = 1, add = 0, sel = 0;
+        if (cd.nr_phases == 1) {
+            present = q == 0;
+        } else if (cd.nr_phases == 2) {
+            present = q == 0 || q == 2;
+            if (four) {
+                sel = q == 0;
+            } else {
+                mul = 2;
+                add = q >> 1;
+            }
+        } else {
+            present = true;
+            mul = 2;
+            add = q >> 1;
+            sel = (q & 1) == 0;
+        }
+        uint32_t word = 0;
+        if (present) {
+            const uint32_t n0 = (w >> 3) * 256 + (w & 7);
+#pragma unroll
+            for (uint32_t jb = 0; jb < 32; jb++) {
+                word |= (((uint32_t)sym[(n0 + 8 * jb) * mul + add] >> sel) & 1u) << jb;
+            }
+        }
+        out[item] = word;
     }
 }
 
@@ -504,6 +537,7 @@ struct mfm_flex {
     FxState *d_st = nullptr;
     mfm_flex_event *d_ev = nullptr;
     mfm_flex_frame_words *d_fw = nullptr;
+    FxFrameDesc *d_fd = nullptr;
     uint32_t *d_counts = nullptr;
     MfmBchTables *d_bch = nullptr;
     uint64_t total = 0;
@@ -562,6 +596,7 @@ int mfm_flex_create(struct mfm_flex **pf, const struct mfm_flex_config *cfg)
     }
     FX_TRY(hipMalloc(&f->d_ev, C * f->max_ev * sizeof(mfm_flex_event)));
     FX_TRY(hipMalloc(&f->d_fw, C * f->max_fw * sizeof(mfm_flex_frame_words)));
+    FX_TRY(hipMalloc(&f->d_fd, C * f->max_fw * sizeof(FxFrameDesc)));
     FX_TRY(hipMalloc(&f->d_counts, C * 2 * sizeof(uint32_t)));
     FX_TRY(hipMemset(f->d_counts, 0, C * 2 * sizeof(uint32_t)));
     FX_TRY(hipDeviceSynchronize());
@@ -582,6 +617,7 @@ void mfm_flex_destroy(struct mfm_flex **pf)
     (void)hipFree(f->d_st);
     (void)hipFree(f->d_ev);
     (void)hipFree(f->d_fw);
+    (void)hipFree(f->d_fd);
     (void)hipFree(f->d_counts);
     delete f;
     *pf = nullptr;
@@ -610,8 +646,11 @@ int mfm_flex_process_device(struct mfm_flex *f, const int16_t *d_pcm, size_t in_
     hipLaunchKernelGGL(fx_match_kernel, dim3((nwords + FX_MATCH_WORDS - 1) / FX_MATCH_WORDS, C), dim3(256), 0, s, in, f->d_m,
                        f->mstride, f->d_sum, f->sstride, w0, nwords);
     FX_TRY(hipGetLastError());
-    const FxWalk W{ in, f->d_m, f->d_sum, f->mstride, f->sstride, nwords, w0, f->d_st, f->d_ev, f->d_fw, f->d_counts, f->max_ev, f->max_fw, f->d_bch };
-    hipLaunchKernelGGL(fx_walk_kernel, dim3(C), dim3(FX_WALK_THREADS), 0, s, W);
+    const FxWalk W{ in, f->d_m, f->d_sum, f->mstride, f->sstride, nwords, w0, f->d_st, f->d_ev, f->d_fw, f->d_fd, f->d_counts, f->max_ev, f->max_fw, f->d_bch };
+    hipLaunchKernelGGL(fx_walk_kernel, dim3(C), dim3(64), 0, s, W);
+    FX_TRY(hipGetLastError());
+    /* the frames' words: reads the same samples, so it runs before the history ring is refreshed */
+    hipLaunchKernelGGL(fx_gather_kernel, dim3(f->max_fw, C), dim3(FX_GATHER_THREADS), 0, s, W);
     FX_TRY(hipGetLastError());
     const uint32_t cnt = n < FX_HIST ? n : FX_HIST;
     hipLaunchKernelGGL(fx_hist_kernel, dim3((cnt + 255) / 256, C), dim3(256), 0, s, f->d_hist, d_pcm, in_stride, in.base, n);
