@@ -94,3 +94,20 @@ def test_commit_without_gpu_fails_loudly(pkg):
     with pytest.raises(pkg.MfmError) as ei:
         e.commit()
     assert ei.value.code == pkg.binding.MFM_E_DEVICE
+
+
+def test_stages_without_gpu_fail_loudly(pkg):
+    """no CPU path anywhere: resampler, POCSAG, FLEX, Mueller-Muller and the float engine refuse to exist without a device"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    b = pkg.binding
+    for make in (lambda: b.Resampler(2, np.array([16384], np.int16), 1, 1, 1024),
+                 lambda: b.Pocsag(2, 4096),
+                 lambda: b.Flex(2, 4096),
+                 lambda: b.F32Engine(2400000, 96, 1 << 16)):
+        with pytest.raises(pkg.MfmError) as ei:
+            make()
+        assert ei.value.code == b.MFM_E_DEVICE
+    with pytest.raises(pkg.MfmError):
+        b.bch3121_decode(np.zeros(4, np.uint32))

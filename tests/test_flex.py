@@ -434,6 +434,29 @@ def test_gpu_flex_many_channels_and_strides(ora, pkg):
         pkg.binding.Flex(0, 100)
 
 
+@pytest.mark.gpu
+def test_gpu_flex_event_list_limits(ora, pkg):
+    """a caller-chosen max_events that is too small is reported (MFM_E_STATE), never a silent loss or an overrun; bad
+    arguments are refused"""
+    sy = pkg.synth
+    alt = sy.flex_frame_levels(0, 2, 9, {0: sy.flex_phase_words([], idle=(0, 0x1FFFFF))})   # an unknown-baud event every 1120 samples
+    pcm = sy.flex_pcm([alt], lead=5, trail=100, noise=300, seed=1)[None, :]
+    fx = pkg.binding.Flex(1, pcm.shape[1], max_events=3)
+    with pytest.raises(pkg.MfmError) as ei:
+        fx.process_host(pcm)
+    assert ei.value.code == pkg.binding.MFM_E_STATE
+    fx.close()
+    fx = pkg.binding.Flex(1, pcm.shape[1])
+    ev, fw = fx.process_host(pcm)
+    want, _ = ora.Flex().feed(pcm[0])
+    assert len(ev) == len(want) > 10
+    with pytest.raises(pkg.MfmError):
+        fx.process_host(np.zeros((1, pcm.shape[1] + 1), np.int16))     # more than max_in_samples
+    fx.close()
+    with pytest.raises(pkg.MfmError):
+        pkg.binding.Flex(1, (1 << 26) + 1)
+
+
 # ---- the decoder-shaped driver ---------------------------------------------------------------------------------
 
 def _esc(text):
