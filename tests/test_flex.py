@@ -439,8 +439,8 @@ def test_gpu_flex_event_list_limits(ora, pkg):
     """a caller-chosen max_events that is too small is reported (MFM_E_STATE), never a silent loss or an overrun; bad
     arguments are refused"""
     sy = pkg.synth
-    alt = sy.flex_frame_levels(0, 2, 9, {0: sy.flex_phase_words([], idle=(0, 0x1FFFFF))})   # an unknown-baud event every 1120 samples
-    pcm = sy.flex_pcm([alt], lead=5, trail=100, noise=300, seed=1)[None, :]
+    tone = [(3 if (k & 1) == 0 else -3, 10) for k in range(3000)]   # 800 Hz: an unknown-mode event every 1120 samples
+    pcm = sy.flex_pcm([tone], lead=5, trail=100, noise=300, seed=1)[None, :]
     fx = pkg.binding.Flex(1, pcm.shape[1], max_events=3)
     with pytest.raises(pkg.MfmError) as ei:
         fx.process_host(pcm)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--resampler-taps", type=int, default=821)
     ap.add_argument("--resampler-dot2", action="store_true", help="the v_dot2 resampler kernel (MFM_RS_FORCE_DOT2)")
+    ap.add_argument("--dc-block", action="store_true", help="decoder -b: the DC blocker behind the resampler (pole 0.9999)")
     args = ap.parse_args()
     import torch
     from __graft_entry__ import load_package
@@ -49,7 +50,8 @@ def main():
         b.copy_(torch.from_numpy(host))
     rt = sy.design_lpf(args.resampler_taps, 0.45 / 25, 1.0) * 16
     rtaps = np.array([int(t * 16384.0) for t in rt], dtype=np.int16)
-    rs = pkg.Resampler(C, rtaps, 16, 25, block // decim + 8, device=0, force_dot2=args.resampler_dot2)
+    rs = pkg.Resampler(C, rtaps, 16, 25, block // decim + 8, device=0, force_dot2=args.resampler_dot2,
+                       dc_pole=0.9999 if args.dc_block else None)
     fx = pkg.Flex(C, rs.max_out(), device=0)
     st = torch.cuda.ExternalStream(eng.stream)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.iters)]
