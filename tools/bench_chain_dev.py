@@ -4,7 +4,7 @@
 821-tap filter, etc/resampler_filter.json) -> FLEX stage.  Everything is queued on the engine's stream; per-stage times from
 events on that stream; the only host traffic is the event list of the last block.
 
-    python tools/bench_chain_flex.py [--channels 64] [--block-log2 26] [--iters 20] [--busy]
+    python tools/bench_chain_dev.py [--channels 64] [--block-log2 26] [--iters 20] [--busy]
 
 --busy: every channel carries back-to-back FLEX frames (FM carriers synthesised once for 2^21 samples and tiled - frames
 repeat, so sync and the frame gather run on every channel); default: eight FM carriers with a tone, i.e. the FLEX stage
@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--resampler-taps", type=int, default=821)
     ap.add_argument("--resampler-dot2", action="store_true", help="the v_dot2 resampler kernel (MFM_RS_FORCE_DOT2)")
+    ap.add_argument("--proto", default="flex", choices=["flex", "pocsag"],
+                    help="pocsag: etc/pocsag_rtlsdr.json geometry (1.2 MS/s, D = 25 -> 48 kS/s) -> 4/5 (81 taps) -> POCSAG stage")
     ap.add_argument("--dc-block", action="store_true", help="decoder -b: the DC blocker behind the resampler (pole 0.9999)")
     args = ap.parse_args()
     import torch
@@ -34,7 +36,10 @@ def main():
     pkg = load_package()
     sy = pkg.synth
     C = args.channels
-    fs, decim, taps, offs, gains = sy.plan("cfg2_64ch" if C <= 64 else "cfg3_1024ch", nr_channels=C)
+    if args.proto == "pocsag":
+        fs, decim, taps, offs, gains = sy.plan("pocsag_rtlsdr", nr_channels=C)
+    else:
+        fs, decim, taps, offs, gains = sy.plan("cfg2_64ch" if C <= 64 else "cfg3_1024ch", nr_channels=C)
     block = 1 << args.block_log2
     lib = pkg.load_library()
     in_bytes = lib.mfm_engine_input_bytes(block, len(taps))
@@ -48,11 +53,12 @@ def main():
     host = np.tile(base, (-(-(in_bytes // 4) // base.shape[0]), 1))[: in_bytes // 4].reshape(-1)
     for b in bufs:
         b.copy_(torch.from_numpy(host))
-    rt = sy.design_lpf(args.resampler_taps, 0.45 / 25, 1.0) * 16
+    ri, rd, rn = (4, 5, 81) if args.proto == "pocsag" else (16, 25, args.resampler_taps)
+    rt = sy.design_lpf(rn, 0.45 / max(ri, rd), 1.0) * ri
     rtaps = np.array([int(t * 16384.0) for t in rt], dtype=np.int16)
-    rs = pkg.Resampler(C, rtaps, 16, 25, block // decim + 8, device=0, force_dot2=args.resampler_dot2,
+    rs = pkg.Resampler(C, rtaps, ri, rd, block // decim + 8, device=0, force_dot2=args.resampler_dot2,
                        dc_pole=0.9999 if args.dc_block else None)
-    fx = pkg.Flex(C, rs.max_out(), device=0)
+    fx = pkg.Pocsag(C, rs.max_out(), device=0) if args.proto == "pocsag" else pkg.Flex(C, rs.max_out(), device=0)
     st = torch.cuda.ExternalStream(eng.stream)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.iters)]
 
@@ -80,16 +86,17 @@ def main():
         nout, ny = step(ev[i])
     eng.sync()
     torch.cuda.synchronize()
-    events, frames = fx.fetch_events()
+    events = fx.fetch_events()
+    events = events[0] if isinstance(events, tuple) else events
     t = np.array([[e[0].elapsed_time(e[k]) for k in (1, 2, 3)] for e in ev])
     stage = np.diff(np.concatenate([np.zeros((args.iters, 1)), t], 1), axis=1)
     med = np.median(stage, 0)
     total = float(np.median(t[:, 2]))
-    print(json.dumps({"chain": "IQ (HBM) -> engine (D 96, 128 taps) -> resampler 16/25 (%d taps) -> FLEX stage" % args.resampler_taps,
-                      "channels": C, "block_samples": block, "pcm_25k_per_channel": int(nout), "pcm_16k_per_channel": int(ny),
-                      "ms_engine": round(float(med[0]), 4), "ms_resampler": round(float(med[1]), 4), "ms_flex": round(float(med[2]), 4),
+    print(json.dumps({"chain": "IQ (HBM) -> engine (D %d, %d taps) -> resampler %d/%d (%d taps) -> %s stage" % (decim, len(taps), ri, rd, rn, args.proto.upper()),
+                      "channels": C, "block_samples": block, "pcm_in_per_channel": int(nout), "pcm_out_per_channel": int(ny),
+                      "ms_engine": round(float(med[0]), 4), "ms_resampler": round(float(med[1]), 4), "ms_pager": round(float(med[2]), 4),
                       "ms_per_block": round(total, 4), "msamp_per_s_x_channels": round(block * C / total / 1e3, 1),
-                      "flex_events_last_block": int(len(events)), "kernel": eng.stats()["kernel_variant"]}))
+                      "events_last_block": int(len(events)), "kernel": eng.stats()["kernel_variant"]}))
     eng.close()
     rs.close()
     fx.close()
