@@ -435,6 +435,37 @@ def test_gpu_flex_many_channels_and_strides(ora, pkg):
 
 
 @pytest.mark.gpu
+def test_gpu_flex_full_block_of_busy_channels(ora, pkg):
+    """the block the headline chain hands over (64 channels x 447 392 samples = one 2^26-sample IQ block at 16 kHz), every
+    channel full of back-to-back frames of the four codings at its own offset: about 900 frames in one call, then the same
+    stream again in two calls - events and words against the oracle, channel by channel"""
+    sy = pkg.synth
+    C_, n = 64, 447392
+    recs = [dict(kind="alnum", capcode=1000 + i, text="THE QUICK BROWN FOX JUMPS OVER THE LAZY DOG %d" % i) for i in range(4)]
+    frames = []
+    for k in range(4):
+        ph = {p: sy.flex_phase_words(recs) for p in sy.FLEX_CODINGS[k]["phases"]}
+        frames.append(sy.flex_pcm([sy.flex_frame_levels(k, 1, k, ph)], noise=300, seed=k))
+    pcm = np.stack([np.concatenate([frames[c % 4]] * (n // 30000 + 2))[(c * 977) % 30000:][:n] for c in range(C_)])
+    fx = pkg.binding.Flex(C_, n)
+    ev, fw = fx.process_host(pcm)
+    ev2, fw2 = fx.process_host(pcm[:, :200001])
+    ev3, fw3 = fx.process_host(pcm[:, 200001:])
+    fx.close()
+    frames_seen = 0
+    for c in range(C_):
+        o = ora.Flex()
+        w1, _ = o.feed(pcm[c])
+        w2, _ = o.feed(pcm[c, :200001])
+        w3, _ = o.feed(pcm[c, 200001:])
+        _check_channel(ora, sy, ev[ev["channel"] == c], fw, w1, f"channel {c}")
+        _check_channel(ora, sy, ev2[ev2["channel"] == c], fw2, w2, f"channel {c}, second pass, first call")
+        _check_channel(ora, sy, ev3[ev3["channel"] == c], fw3, w3, f"channel {c}, second pass, second call")
+        frames_seen += sum(int(e["type"]) == 1 for e in w1)
+    assert frames_seen >= 850
+
+
+@pytest.mark.gpu
 def test_gpu_flex_event_list_limits(ora, pkg):
     """a caller-chosen max_events that is too small is reported (MFM_E_STATE), never a silent loss or an overrun; bad
     arguments are refused"""
