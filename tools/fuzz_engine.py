@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle runs of the channel engine: random sample rate / decimation / filter length / channel set /
+gains / block sizes / kernel selection, random full-scale or FM input; PCM (and, half the time, the filtered IQ) must be
+bit-exact.  Exit code 1 on the first difference.
+
+    python tools/fuzz_engine.py [--seconds 300] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def case(pkg, ora, rng):
+    b = pkg.binding
+    decim = int(rng.choice([25, 32, 40, 64, 96, 96, 96, 100, 128, 400, int(rng.randint(6, 200))]))
+    fs = int(rng.choice([1000000, 1200000, 2400000, 10000000]))
+    ntaps = int(rng.choice([decim, 128, 128, 129, 200, 256, 512, decim + int(rng.randint(0, 100))]))
+    ntaps = max(ntaps, decim)
+    if ntaps > 600:
+        ntaps = 512 if decim <= 512 else decim
+    nch = int(rng.choice([1, 2, 5, 8, 9, 16, 33, 64, 65, 130, int(rng.randint(1, 300))]))
+    taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
+    offs = rng.randint(-fs // 2, fs // 2, size=nch)
+    offs[: min(nch, 4)] = [0, 25000, -37500, 3125][: min(nch, 4)]
+    gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
+    kernel = str(rng.choice(["auto", "auto", "mfma1", "dot2"]))
+    want_iq = bool(rng.rand() < 0.5)
+    n = int(rng.randint(ntaps, 400000))
+    if rng.rand() < 0.5:
+        iq = pkg.synth.random_iq(n, seed=int(rng.randint(1 << 30)))
+    else:
+        iq = pkg.synth.synth_iq(n, fs, offs[: min(nch, 6)], seed=int(rng.randint(1 << 30)))
+    max_block = int(rng.choice([n, 65536, 8192, 100000]))
+    flags = (b.MFM_F_FORCE_DOT2 if kernel == "dot2" else 0) | (b.MFM_F_FORCE_MFMA_V1 if kernel == "mfma1" else 0)
+    try:
+        eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
+        for o, g in zip(offs, gains):
+            eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
+        eng.commit()
+    except pkg.MfmError as e:
+        return None, "refused: %s" % e
+    variant = eng.stats()["kernel_variant"]
+    cre = np.stack([eng.get_channel(c)[0] for c in range(nch)])
+    cim = np.stack([eng.get_channel(c)[1] for c in range(nch)])
+    incr = np.stack([eng.get_channel(c)[2] for c in range(nch)])
+    # ragged blocks
+    outs, outq, pos = [], [], 0
+    while pos < n:
+        m = min(int(rng.randint(1, max_block + 1)), n - pos)
+        pcm, q = eng.run(iq[pos:pos + m], m)
+        outs.append(pcm)
+        outq.append(q)
+        pos += m
+    eng.close()
+    got = np.concatenate(outs, axis=1)
+    ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=8, want_iq=want_iq)
+    desc = "fs %d D %d T %d C %d kernel %s/%d n %d max_block %d iq %s" % (fs, decim, ntaps, nch, kernel, variant, n, max_block, want_iq)
+    if got.shape != ref.shape or not np.array_equal(got, ref):
+        return "PCM differs: " + desc, desc
+    qs = [q for q in outq if q is not None]
+    if want_iq and refq is not None and refq.shape[1] > 0 and (not qs or not np.array_equal(np.concatenate(qs, axis=1), refq)):
+        return "filtered IQ differs: " + desc, desc
+    return None, variant
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    from __graft_entry__ import load_package
+    import oracle_lib as ora
+    pkg = load_package()
+    rng = np.random.RandomState(args.seed)
+    t0 = time.time()
+    counts = {}
+    while time.time() - t0 < args.seconds:
+        err, info = case(pkg, ora, rng)
+        if err:
+            print("FAIL", err, "after", counts)
+            return 1
+        key = info if isinstance(info, (int, np.integer)) else "refused"
+        counts[int(key) if key != "refused" else key] = counts.get(int(key) if key != "refused" else key, 0) + 1
+    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2)", counts)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
