@@ -53,7 +53,7 @@ extern "C" {
 #define MFM_E_STATE (-5)  /* call not valid in this state (e.g. add_channel after commit) */
 #define MFM_E_DONE (-6)   /* nothing to fetch (A_E_DONE analogue) */
 
-#define MFM_ABI_VERSION 1
+#define MFM_ABI_VERSION 2 /* 2: mfm_resampler_config grew flags + reserved; mfm_flex_*, mfm_group_* added */
 
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFM_LIB") or os.path.join(_HERE, "libmultifm_hip.so")
 
 MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_DONE = 0, -1, -2, -3, -4, -5, -6
-MFM_ABI_VERSION = 1
+MFM_ABI_VERSION = 2
 MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
 MFM_F_FORCE_DOT2 = 0x4
