@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the float32-IQ comparison line")
+    ap.add_argument("--no-chain", action="store_true", help="skip the device-resident FLEX chain line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
@@ -132,6 +133,55 @@ def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
             "msamp_per_s_one_channel_one_core": one_core,
             "sample": f"{passes} passes over {n} IQ samples x {nch} channels, {how}, {threads} threads "
                       f"thread-per-channel, {dt:.1f} s"}
+
+
+def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
+    """SURVEY.md 8f rows behind the headline kernel, on the same block and channels, nothing leaving HBM: channel engine ->
+    16/25 resampler with 821 taps (what the reference's decoder runs in front of FLEX) -> FLEX stage; per-stage times from
+    events on the engine's stream.  Outside the timed region, never part of `value`."""
+    lib = pkg.load_library()
+    in_bytes = lib.mfm_engine_input_bytes(block, len(taps))
+    bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+    eng = pkg.Engine(fs, decim, block, device=torch.cuda.current_device(), flags=pkg.binding.MFM_F_DEVICE_ONLY,
+                     ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    base = pkg.synth.synth_iq(1 << 22, fs, offs[:: max(1, len(offs) // 8)][:8], seed=7)
+    host = np.tile(base, (-(-(in_bytes // 4) // base.shape[0]), 1))[: in_bytes // 4].reshape(-1)
+    for b in bufs:
+        b.copy_(torch.from_numpy(host))
+    rt = pkg.synth.design_lpf(821, 0.45 / 25, 1.0) * 16
+    rs = pkg.Resampler(len(offs), np.array([int(t * 16384.0) for t in rt], dtype=np.int16), 16, 25, block // decim + 8,
+                       device=torch.cuda.current_device())
+    fx = pkg.Flex(len(offs), rs.max_out(), device=torch.cuda.current_device())
+    st = torch.cuda.ExternalStream(eng.stream)
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
+    ny = 0
+    for i in range(-40, iters):
+        eng.acquire_input()
+        if i >= 0:
+            marks[i][0].record(st)
+        eng.submit(block, producer_stream=0, wait_producer=False)
+        dptr, stride, nout, _ = eng.last_output_device()
+        if i >= 0:
+            marks[i][1].record(st)
+        yptr, ystride, ny = rs.process_device(dptr, stride, nout, stream=eng.stream)
+        if i >= 0:
+            marks[i][2].record(st)
+        fx.process_device(yptr, ystride, ny, stream=eng.stream)
+        if i >= 0:
+            marks[i][3].record(st)
+    eng.sync()
+    torch.cuda.synchronize()
+    t = np.array([[m[0].elapsed_time(m[k]) for k in (1, 2, 3)] for m in marks])
+    med = np.median(np.diff(np.concatenate([np.zeros((iters, 1)), t], 1), axis=1), 0)
+    total = float(np.median(t[:, 2]))
+    for o in (eng, rs, fx):
+        o.close()
+    return {"chain": "engine -> resampler 16/25 (821 taps) -> FLEX stage, device resident", "block_samples": block,
+            "pcm_16k_per_channel": int(ny), "ms_engine": float(med[0]), "ms_resampler": float(med[1]), "ms_flex": float(med[2]),
+            "ms_per_block": total, "value": block * len(offs) / total / 1e3, "unit": "MSamp/s x channels"}
 
 
 def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=24, iters=30):
@@ -352,6 +402,8 @@ def main():
         # reported next to the headline (never part of `value`)
         line["fp32_iq_path"] = fp32_path(pkg, torch, fs, decim, taps, offs, gains, line["roofline"]["kernel_ms"],
                                          block)
+    if rank == 0 and world == 1 and not args.no_chain and decim == 96:
+        line["flex_chain"] = flex_chain(pkg, torch, fs, decim, taps, offs, gains, block)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

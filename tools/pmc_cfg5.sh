@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc5; rm -rf $O; mkdir -p $O
-P="python3 bench.py --config cfg5_airspy --channels-per-gpu 256 --steps 8 --warmup 3 --settle-seconds 0.3 --no-cpu-baseline --no-fp32"
+P="python3 bench.py --config cfg5_airspy --channels-per-gpu 256 --steps 8 --warmup 3 --settle-seconds 0.3 --no-cpu-baseline --no-fp32 --no-chain"
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/p1 -o p -- $P > $O/p1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/p2 -o p -- $P > $O/p2.log 2>&1
 python3 - <<'PY'

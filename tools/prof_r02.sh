@@ -4,7 +4,7 @@
 # FETCH_SIZE, WRITE_SIZE each on its own).  Outputs under gpurun_out/r02/; tools/collect_r02.py turns them into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02; rm -rf $O; mkdir -p $O
-B="--no-fp32"
+B="--no-fp32 --no-chain"
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driverflags.json 2> $O/bench_driverflags.err
 timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 for k in mfma1 dot2; do
