@@ -266,3 +266,28 @@ def test_multifm_driver_on_file_input(tmp_path, pkg, ora, fmt, gpu_unpack):
     for c in range(2):
         assert pcm[c].shape == ref[c].shape and np.array_equal(pcm[c], ref[c]), f"channel {c} PCM differs"
     assert np.array_equal(q, refq[0])
+
+
+def test_decoder_driver_refuses_loudly_without_a_gpu_and_unknown_protocols(tmp_path):
+    """decoder_amd: -m AIS is not built (exit 1, UNKNOWN-PROTOCOL-TYPE); without a device the FLEX (default) and POCSAG
+    paths stop at the resampler with a message instead of falling back to anything on the CPU"""
+    import json
+    import subprocess
+    tool = os.path.join(os.path.dirname(HOST_SO), "decoder_amd")
+    if not os.path.exists(tool):
+        pytest.fail(f"{tool} missing: run make -C tsl-sdr_amd")
+    (tmp_path / "f.json").write_text(json.dumps({"lpfCoeffs": [0.25, 0.5, 0.25]}))
+    (tmp_path / "in.pcm").write_bytes(np.zeros(4096, np.int16).tobytes())
+    base = [tool, "-I", "1", "-D", "1", "-S", "16000", "-F", str(tmp_path / "f.json"), "-f", "929612500"]
+    r = subprocess.run(base + ["-m", "AIS", str(tmp_path / "in.pcm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "UNKNOWN-PROTOCOL-TYPE" in r.stderr
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    for proto in ([], ["-m", "FLEX"], ["-m", "POCSAG"]):
+        r = subprocess.run(base + proto + [str(tmp_path / "in.pcm")], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "NO-RESAMPLER" in r.stderr, r.stderr[-500:]
