@@ -56,6 +56,56 @@ KERNEL(k_a32, F8(A) F8(A) F8(A) F8(A))
 
 typedef void (*kfn_t)(int, float *);
 static float *d_out;
+
+// ---- two roles on one SIMD: waves with (wave / 4) even run 4 MFMA per trip, the others 16 fillers: do a matrix-only
+//      wave and a VALU-only wave overlap (time = max) or add up (time = sum)?  role 1 both, 2 MFMA waves only, 3 VALU only ----
+#define ROLES(NAME, FILL)                                                                                    \
+    __global__ __launch_bounds__(1024) void NAME(int iters, int role, float *out)                            \
+    {                                                                                                        \
+        const int wave = threadIdx.x >> 6;                                                                   \
+        float a = (float)threadIdx.x, b = 1.0f + blockIdx.x;                                                 \
+        v4f c0 = { 0, 0, 0, 0 }, c1 = c0, c2 = c0, c3 = c0;                                                  \
+        float r0 = threadIdx.x, r1 = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, r6 = 6, r7 = 7;                      \
+        float k = 3.0f, k2 = 0.5f;                                                                           \
+        const bool mf = ((wave >> 2) & 1) == 0;                                                              \
+        for (int i = 0; i < iters; i++) {                                                                    \
+            if (mf) {                                                                                        \
+                if (role != 3) {                                                                             \
+                    asm volatile(MF(0) MF(1) MF(2) MF(3)                                                     \
+                                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), \
+                                   "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)                                    \
+                                 : "v"(a), "v"(b), "v"(k), "v"(k2) : "vcc");                                 \
+                }                                                                                            \
+            } else if (role != 2) {                                                                          \
+                asm volatile(F8(FILL) F8(FILL)                                                               \
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3),     \
+                               "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)                                        \
+                             : "v"(a), "v"(b), "v"(k), "v"(k2) : "vcc");                                     \
+            }                                                                                                \
+        }                                                                                                    \
+        out[blockIdx.x * 1024 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; \
+    }
+ROLES(k_roles_add, A)
+ROLES(k_roles_fma, M)
+ROLES(k_roles_cnd, C)
+typedef void (*rfn_t)(int, int, float *);
+static void run_roles(const char *name, rfn_t fn, int wps, int role, const char *what)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int iters = 10000;
+    hipLaunchKernelGGL(fn, dim3(256), dim3(256 * wps), 0, 0, iters, role, d_out);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(fn, dim3(256), dim3(256 * wps), 0, 0, iters, role, d_out);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-10s waves/SIMD=%d role=%d: %7.2f ns per trip | %s\n", name, wps, role, ms * 1e6 / iters, what);
+}
+
 static void run(const char *name, kfn_t fn, int wps, const char *what)
 {
     hipEvent_t e0, e1;
@@ -88,6 +138,15 @@ int main()
         for (auto &x : t) {
             run(x.n, x.f, wps, x.w);
         }
+    }
+    for (int wps : { 2, 4 }) {
+        run_roles("roles add", k_roles_add, wps, 2, "MFMA waves only (half of the waves, 4 MFMA per trip)");
+        run_roles("roles add", k_roles_add, wps, 3, "v_add waves only (the other half, 16 per trip)");
+        run_roles("roles add", k_roles_add, wps, 1, "both");
+        run_roles("roles fma", k_roles_fma, wps, 3, "v_fma_f32 waves only (16 per trip)");
+        run_roles("roles fma", k_roles_fma, wps, 1, "both");
+        run_roles("roles cnd", k_roles_cnd, wps, 3, "v_cndmask waves only (16 per trip)");
+        run_roles("roles cnd", k_roles_cnd, wps, 1, "both");
     }
     return 0;
 }
