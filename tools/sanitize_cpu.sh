@@ -7,13 +7,13 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g"
 cd "$ROOT/tsl-sdr_amd/host"
-for f in mfm_tsl mfm_config mfm_receiver mfm_file_if mfm_pager_pocsag; do
+for f in mfm_tsl mfm_config mfm_receiver mfm_file_if mfm_pager_pocsag mfm_pager_flex; do
   gcc -std=gnu11 $SAN -fPIC -D_GNU_SOURCE -I. -I../../include -c -o $T/$f.o $f.c
 done
 gcc -shared $SAN -o $T/libmfm_host.so $T/*.o -L.. -lmultifm_hip -Wl,-rpath,$ROOT/tsl-sdr_amd -lpthread -lm
 cd "$ROOT/oracle"
 gcc -std=gnu11 $SAN -march=x86-64-v3 -ffp-contract=off -fwrapv -fPIC -D_GNU_SOURCE -shared -o $T/liboracle.so \
-    mfm_oracle.c pocsag_oracle.c f32_oracle.c -lm -lpthread
+    mfm_oracle.c pocsag_oracle.c f32_oracle.c flex_oracle.c -lm -lpthread
 cp "$ROOT/tsl-sdr_amd/host/libmfm_host.so" $T/host.orig; cp "$ROOT/oracle/liboracle.so" $T/oracle.orig
 trap 'cp $T/host.orig "$ROOT/tsl-sdr_amd/host/libmfm_host.so"; cp $T/oracle.orig "$ROOT/oracle/liboracle.so"' EXIT
 cp $T/libmfm_host.so "$ROOT/tsl-sdr_amd/host/libmfm_host.so"; cp $T/liboracle.so "$ROOT/oracle/liboracle.so"
