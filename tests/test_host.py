@@ -146,6 +146,30 @@ def test_deliver_never_blocks_and_a_stalled_device_drops_at_the_pool(tmp_path):
     assert res["worst_deliver_ns_stalled"] < 100_000, res
 
 
+def test_receiver_threads_are_race_free_under_tsan(tmp_path):
+    """the same scenario (front end's thread, submit thread, drain thread, a device double that stalls and recovers) built
+    with -fsanitize=thread: the ring, the failure flag, the shutdown flags and the counters are C11 atomics, buffers change
+    hands through the ring / the pool's mutex - ThreadSanitizer must have nothing to report"""
+    host = os.path.join(ROOT, "tsl-sdr_amd", "host")
+    exe = tmp_path / "stall_tsan"
+    srcs = [os.path.join(host, f) for f in ("mfm_tsl.c", "mfm_config.c", "mfm_receiver.c")]
+    srcs += [os.path.join(ROOT, "tests", "hoststub", f) for f in ("stub_group.c", "stall_main.c")]
+    r = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-D_GNU_SOURCE", "-I" + host,
+                        "-I" + os.path.join(ROOT, "include"), "-o", str(exe)] + srcs + ["-lpthread", "-lm"],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr
+    sink = tmp_path / "pcm.out"
+    sink.write_bytes(b"")
+    r = subprocess.run([str(exe), str(sink)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0"))
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["delivered"] == 9 and res["dropped"] == 32 and res["pushed"] == 9 and res["pool_back"] == 1
+
+
 REF_FILE_IF = "/root/reference/multifm/file_if.c"
 
 

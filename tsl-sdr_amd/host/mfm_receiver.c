@@ -244,8 +244,7 @@ aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *bu
     const size_t head = rx->ring_head;
     TSL_BUG_ON(head - rx->ring_tail >= rx->ring_slots); /* more buffers in flight than the pool holds */
     rx->ring[head % rx->ring_slots] = buf;
-    atomic_thread_fence(memory_order_release);
-    rx->ring_head = head + 1;
+    rx->ring_head = head + 1; /* publishes the slot */
     rx->nr_bufs_delivered++;
     const uint64_t dt = tsl_get_clock_monotonic() - t0;
     if (dt > rx->max_deliver_ns) {
@@ -274,8 +273,7 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
             usleep(200);
             continue;
         }
-        atomic_thread_fence(memory_order_acquire);
-        struct sample_buf *buf = rx->ring[tail % rx->ring_slots];
+        struct sample_buf *buf = rx->ring[tail % rx->ring_slots]; /* the load of ring_head above acquired it */
         if (!rx->failed) {
             for (;;) {
                 const int rc = mfm_group_push(rx->group, buf->data_buf, buf->nr_samples, _format_of(buf));

@@ -17,6 +17,8 @@
  */
 #pragma once
 
+#include <stdatomic.h>
+
 #include "mfm_config.h"
 #include "mfm_tsl.h"
 
@@ -91,7 +93,7 @@ struct receiver {
     bool muted;
     struct list_entry demod_threads;
     size_t nr_demod_threads;
-    size_t nr_samp_buf_alloc_fails;
+    _Atomic size_t nr_samp_buf_alloc_fails; /* written by the front end, read by whoever reports */
     struct frame_alloc *samp_alloc;
     struct worker_thread wthr;
     receiver_cleanup_func_t cleanup_func;
@@ -104,12 +106,14 @@ struct receiver {
     struct sample_buf **ring;     /* delivered, not yet submitted buffers: single producer (front end), single
                                      consumer (submit thread); as many slots as the pool has frames, so it never fills */
     size_t ring_slots;
-    volatile size_t ring_head, ring_tail;
-    volatile bool input_done;     /* front end reached end of input */
-    volatile int failed;          /* a device error stopped the submit or the drain thread (A_E_DEVICE from then on) */
-    volatile size_t nr_bufs_delivered, nr_bufs_submitted;
-    size_t nr_blocks_drained;
-    uint64_t max_deliver_ns;      /* longest receiver_sample_buf_deliver() call so far */
+    /* shared between the front end's thread, the submit thread and the drain thread: C11 atomics (sequentially
+     * consistent by default; a slot of `ring` is published by the store to ring_head that follows it) */
+    _Atomic size_t ring_head, ring_tail;
+    _Atomic bool input_done;      /* front end reached end of input */
+    _Atomic int failed;           /* a device error stopped the submit or the drain thread (A_E_DEVICE from then on) */
+    _Atomic size_t nr_bufs_delivered, nr_bufs_submitted;
+    _Atomic size_t nr_blocks_drained;
+    _Atomic uint64_t max_deliver_ns; /* longest receiver_sample_buf_deliver() call so far */
 };
 
 aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,

@@ -8,6 +8,7 @@
  */
 #pragma once
 
+#include <stdatomic.h>
 #include <pthread.h>
 #include <stdbool.h>
 #include <stddef.h>
@@ -115,7 +116,7 @@ typedef aresult_t (*worker_thread_func_t)(struct worker_thread *thr);
 struct worker_thread {
     pthread_t thr;
     worker_thread_func_t fn;
-    volatile bool running;
+    _Atomic bool running; /* cleared by whoever asks the thread to stop */
     bool started;
 };
 
