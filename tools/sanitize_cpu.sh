@@ -20,3 +20,11 @@ cp $T/libmfm_host.so "$ROOT/tsl-sdr_amd/host/libmfm_host.so"; cp $T/liboracle.so
 cd "$ROOT"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
   UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests -x -q -m "not gpu"
+# ThreadSanitizer: the receiver's threads against the stalling device double (the same build tests/test_host.py runs)
+cd "$ROOT"
+H=tsl-sdr_amd/host
+gcc -std=gnu11 -O1 -g -fsanitize=thread -D_GNU_SOURCE -I$H -Iinclude -o $T/stall_tsan $H/mfm_tsl.c $H/mfm_config.c $H/mfm_receiver.c \
+    tests/hoststub/stub_group.c tests/hoststub/stall_main.c -lpthread -lm
+: > $T/pcm.out
+TSAN_OPTIONS="halt_on_error=1 report_signal_unsafe=0" $T/stall_tsan $T/pcm.out
+echo "ThreadSanitizer: clean"
