@@ -650,7 +650,9 @@ int mfm_flex_process_device(struct mfm_flex *f, const int16_t *d_pcm, size_t in_
     hipLaunchKernelGGL(fx_walk_kernel, dim3(C), dim3(64), 0, s, W);
     FX_TRY(hipGetLastError());
     /* the frames' words: reads the same samples, so it runs before the history ring is refreshed */
-    hipLaunchKernelGGL(fx_gather_kernel, dim3(f->max_fw, C), dim3(FX_GATHER_THREADS), 0, s, W);
+    /* a call of n samples cannot end more than n / 28 672 + 2 frames per channel */
+    const uint32_t fw_now = n / 28672u + 2u < f->max_fw ? n / 28672u + 2u : f->max_fw;
+    hipLaunchKernelGGL(fx_gather_kernel, dim3(fw_now, C), dim3(FX_GATHER_THREADS), 0, s, W);
     FX_TRY(hipGetLastError());
     const uint32_t cnt = n < FX_HIST ? n : FX_HIST;
     hipLaunchKernelGGL(fx_hist_kernel, dim3((cnt + 255) / 256, C), dim3(256), 0, s, f->d_hist, d_pcm, in_stride, in.base, n);
