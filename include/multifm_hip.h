@@ -459,15 +459,19 @@ struct mfm_mm_config {
     uint32_t abi_version; /* MFM_ABI_VERSION */
     int32_t device;
     uint32_t nr_channels;
-    uint32_t max_in_samples;
-    float kw, km, samples_per_bit, error_min, error_max; /* mm_init's arguments */
+    uint32_t max_in_samples; /* < 2^22: the reference's float sample position stays a whole number it holds exactly */
+    float kw, km, samples_per_bit, error_min, error_max; /* mm_init's arguments; MFM_E_INVAL unless kw is finite,
+                                                          * error_min <= error_max, error_min - |km| * 32768 >= 1 (a
+                                                          * step cannot reach zero) and error_max + |km| * 32768 < 2^20 */
 };
 
 int mfm_mm_create(struct mfm_mm **pm, const struct mfm_mm_config *cfg);
 void mfm_mm_destroy(struct mfm_mm **pm);
 size_t mfm_mm_max_decisions(const struct mfm_mm *m);
 /* decisions: [channel][*dec_stride] int16 (the samples picked, :71), counts: [channel] decisions of this call;
- * both in device memory, valid until the next call; queued on `stream`. */
+ * both in device memory, valid until the next call; queued on `stream`.  A row holds mfm_mm_max_decisions()
+ * decisions (sized so that no configuration create accepts can exceed it); what lies behind them in the row is
+ * scratch. */
 int mfm_mm_process_device(struct mfm_mm *m, const int16_t *d_pcm, size_t in_stride, size_t nr_in, void *stream,
                           int16_t **d_decisions, size_t *dec_stride, uint32_t **d_counts);
 /* Host convenience: synchronous; MFM_E_NOMEM if a channel produced more than dec_stride decisions. */

@@ -123,3 +123,49 @@ def test_gpu_mueller_muller_more_channels_than_a_wave(pkg, ora):
     for c in range(nch):
         mm = ora.MuellerMuller(KW, KM, float(SPB), float(SPB - MARGIN), float(SPB + MARGIN))
         assert np.array_equal(mm.process(buf[c], 0, n), got[c]), f"channel {c}"
+
+
+@pytest.mark.gpu
+def test_gpu_mueller_muller_ragged_calls(pkg, ora):
+    """Calls of 1 .. 5000 samples, with and without the look-ahead sample, on 19 channels (two workgroups, the second
+    one partly filled): the chunked ring (1024-sample chunks, rows shorter than one 16-byte vector, the partial
+    vector at a row's end) and the carried state against the oracle, call by call."""
+    rng = np.random.RandomState(11)
+    nch = 19
+    base = [_transmission(pkg, 20 + k, lead=300 + 91 * k, nbatches_msgs=1)[0] for k in range(3)]
+    total = 60000
+    buf = np.zeros((nch, total + 1), np.int16)
+    for c in range(nch):
+        buf[c, :total] = np.clip(np.roll(np.resize(base[c % 3], total), 53 * c) + rng.randint(-200, 200, total),
+                                 -32768, 32767)
+    buf[:, total] = buf[:, total - 1]
+    sizes = [1, 2, 7, 8, 9, 3, 1023, 1024, 1025, 17, 2048, 4999, 5, 5000, 1, 1, 31, 4096, 2047]
+    while sum(sizes) < total - 5000:
+        sizes.append(int(rng.randint(1, 5001)))
+    gpu = pkg.MuellerMuller(nch, KW, KM, float(SPB), float(SPB - MARGIN), float(SPB + MARGIN), 5000, device=0)
+    mms = [ora.MuellerMuller(KW, KM, float(SPB), float(SPB - MARGIN), float(SPB + MARGIN)) for _ in range(nch)]
+    off = 0
+    for k, it in enumerate(sizes):
+        ahead = k % 3 != 0  # every third call hands over exactly nr_in columns: the last sample stands in
+        view = np.ascontiguousarray(buf[:, off:off + it + (1 if ahead else 0)])
+        got = gpu.process_host(view, it)
+        for c in range(nch):
+            src = buf[c] if ahead else np.concatenate([buf[c, :off + it], buf[c, off + it - 1:off + it]])
+            assert np.array_equal(mms[c].process(src, off, it), got[c]), f"call {k} ({it} samples), channel {c}"
+        off += it
+    gpu.close()
+
+
+def test_mueller_muller_create_refuses_what_the_float_position_cannot_hold(pkg):
+    """The reference keeps the sample position in a float (mueller_muller.c:58-66, :96); the stage refuses the
+    configurations where that float would stop holding whole numbers exactly, or where a step can fall below one
+    sample - before it looks for a device, so this runs without one."""
+    spb = float(SPB)
+    for kw, km, emin, emax, max_in in ((KW, KM, spb - 0.05, spb + 0.05, 1 << 22),        # block too long
+                                       (KW, 0.001, spb - 0.05, spb + 0.05, 5000),         # step can reach zero
+                                       (float("inf"), KM, spb - 0.05, spb + 0.05, 5000),  # gain not finite
+                                       (KW, KM, spb - 0.05, 2.0e6, 5000),                 # step too long
+                                       (KW, KM, spb + 0.05, spb - 0.05, 5000)):           # bounds the wrong way round
+        with pytest.raises(pkg.MfmError) as e:
+            pkg.MuellerMuller(1, kw, km, spb, emin, emax, max_in, device=0)
+        assert e.value.code == pkg.binding.MFM_E_INVAL

@@ -669,6 +669,15 @@ class MuellerMuller:
             raise MfmError(rc, "mfm_mm_process_host", self.lib.mfm_strerror(rc).decode())
         return [dec[c, :cnt[c]].copy() for c in range(self.nr_channels)]
 
+    def process_device(self, d_pcm, in_stride, nr_in, stream=None):
+        """resident PCM -> (device pointer of the decisions, their row stride, device pointer of the counts)"""
+        d_dec, stride, d_cnt = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        rc = self.lib.mfm_mm_process_device(self.h, C.c_void_p(d_pcm), in_stride, nr_in, C.c_void_p(stream or 0),
+                                            C.byref(d_dec), C.byref(stride), C.byref(d_cnt))
+        if rc < 0:
+            raise MfmError(rc, "mfm_mm_process_device", self.lib.mfm_strerror(rc).decode())
+        return d_dec.value, stride.value, d_cnt.value
+
 
 class Pocsag:
     """mfm_pocsag: POCSAG slicer / sync / batch collection + BCH(31,21) for all channels of a 38 400 Hz PCM block."""
