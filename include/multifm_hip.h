@@ -63,6 +63,9 @@ extern "C" {
 #define MFM_F_FORCE_MFMA_V1 0x8u /* where both matrix-core kernels apply, run the first-generation one (31-output column
                                   blocks, 2-byte PCM stores) instead of the second (64-output tiles, 8-byte stores) */
 
+#define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
+                                  matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
+
 struct mfm_engine_config {
     uint32_t abi_version;       /* MFM_ABI_VERSION */
     int32_t device;             /* HIP device ordinal */
@@ -100,6 +103,7 @@ struct mfm_stats {
     uint64_t rot_table_entries;
     uint32_t kernel_variant;   /* 0 = v_dot2 kernel, 1 = int8-MFMA (FIR-as-GEMM) kernel, 2 = its second generation */
     uint32_t pending_blocks;   /* finished or in-flight blocks not yet fetched + released */
+    uint64_t launches_8bit;    /* of `launches`: those that read an 8-bit block as bytes (mfm_engine_push_bytes) */
 };
 
 /* Size in bytes of one input staging buffer for this configuration and tap count. */
@@ -155,6 +159,11 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples);
                                last one is stored without the subtraction (multifm/file_if.c:113-157) */
 #define MFM_IN_RTLSDR_U8 3  /* unsigned bytes, (b - 127) << 7 (multifm/rtl_sdr_if.c:146-158) */
 int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format);
+/* The same for a producer on the device (a collective, a capture card's DMA): where the next block's BYTES go, two per
+ * sample, when the engine's kernel can read them as they are - the second-generation matrix kernel, and no history of
+ * another format in front (MFM_E_STATE otherwise: widen the block as the reference does and use
+ * mfm_engine_acquire_input).  Then mfm_engine_submit() as for int16 blocks; a cu8 block must be of even length. */
+int mfm_engine_acquire_input_bytes(struct mfm_engine *e, int format, void **d_dst, size_t *capacity_samples);
 
 /* Oldest finished block, in submit order (blocks with zero outputs are skipped).  Waits for the
  * device.  MFM_E_DONE when nothing is pending.  The block stays valid until release(). */

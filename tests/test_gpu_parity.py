@@ -405,3 +405,90 @@ def test_gpu_ingest_of_8bit_formats(pkg, ora, fmt):
     want, _ = ora.run_channels(iq, cre, cim, incr, decim)
     got = np.concatenate(got, axis=1)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, max_block, flags=0):
+    """push_bytes a list of (raw uint8 [m][2], MFM_IN_* format) blocks; returns (PCM, oracle PCM, stats)"""
+    eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
+    for o in offs:
+        eng.add_channel(int(o), taps, 1.0)
+    eng.commit()
+    iq, got = [], []
+    for blk, fmt in blocks:
+        if fmt == 0:
+            iq.append(blk.astype(np.int16).reshape(-1, 2))
+        else:
+            iq.append(ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+        while True:
+            rc = eng.push(blk.reshape(-1)) if fmt == 0 else eng.push_bytes(blk, fmt)
+            if rc == 0:
+                break
+            assert rc == pkg.binding.MFM_E_BUSY
+            got.append(eng.fetch()[1])
+    eng.sync()
+    while True:
+        b = eng.fetch()
+        if b is None:
+            break
+        got.append(b[1])
+    st = eng.stats()
+    eng.close()
+    iq = np.concatenate(iq)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[0] for o in offs])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[1] for o in offs])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    return np.concatenate(got, axis=1), want, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+@pytest.mark.parametrize("geom", ["d96_t128", "d32_t32", "d64_t64", "d128_t128"])
+def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom):
+    """Where the second-generation matrix kernel runs, an 8-bit block stays bytes in HBM and the kernel's GEMM takes
+    the one sample plane as it is (mfm_kernel_v3.hip, IN8): the PCM must equal the oracle run on the reference's
+    host-side widening (rtl_sdr_if.c:146-158, file_if.c:66-157), block sizes ragged, the history crossing blocks as
+    bytes.  Full-range bytes (0x00, 0x7f, 0x80, 0xff all occur)."""
+    fs = 2400000
+    decim, ntaps = {"d96_t128": (96, 128), "d32_t32": (32, 32), "d64_t64": (64, 64), "d128_t128": (128, 128)}[geom]
+    taps = pkg.synth.design_lpf(ntaps, 9000.0, fs)
+    offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-9, 10)]
+    rng = np.random.RandomState(40 + fmt)
+    sizes = [65536, 4096, 30000, 2, 8, 96, 50000, 65536, 12346, 332]
+    if fmt == 2:
+        sizes = [m + (m & 1) for m in sizes]  # cu8 blocks of odd length go the int16 way (next test)
+    blocks = []
+    for m in sizes:
+        raw = rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+        raw[:4] = [[0, 255], [127, 128], [128, 127], [255, 0]][:min(4, m)]
+        blocks.append((raw, fmt))
+    got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536)
+    assert st["kernel_variant"] == 2
+    assert st["launches_8bit"] == st["launches"] > 0
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # the same through the widening pass: same bits, no byte launches
+    got2, _, st2 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536, flags=pkg.binding.MFM_F_WIDEN_8BIT)
+    assert st2["launches_8bit"] == 0 and np.array_equal(got2, want)
+
+
+@pytest.mark.gpu
+def test_gpu_8bit_stream_changes_format_mid_way(pkg, ora):
+    """A history kept as bytes in front of a block of another format (int16, another 8-bit form, a cu8 block of odd
+    length) is widened on the device and the stream goes on as int16; after a block that leaves no history - or an
+    engine reset - bytes are read directly again."""
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 9000.0, fs)
+    offs = [-300000, 12500, 412500]
+    rng = np.random.RandomState(77)
+
+    def raw(m):
+        return rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+
+    def s16(m):
+        return rng.randint(-32768, 32768, size=(m, 2)).astype(np.int16)
+
+    blocks = [(raw(20000), 3), (raw(20001), 3), (s16(7777), 0), (raw(9000), 3), (raw(4096), 1), (raw(4097), 2),
+              (raw(4098), 2), (raw(10), 1), (s16(96 * 50), 0), (raw(30000), 1)]
+    got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 32768)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert 2 <= st["launches_8bit"] < st["launches"]

@@ -18,12 +18,14 @@ MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
 MFM_F_FORCE_DOT2 = 0x4
 MFM_F_FORCE_MFMA_V1 = 0x8
+MFM_F_WIDEN_8BIT = 0x10
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
 ABI_SYMBOLS = [
     "mfm_engine_input_bytes", "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
     "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
+    "mfm_engine_acquire_input_bytes",
     "mfm_engine_submit", "mfm_engine_push", "mfm_engine_push_bytes", "mfm_engine_fetch", "mfm_engine_release",
     "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
     "mfm_engine_stream", "mfm_engine_get_launch_ms", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
@@ -75,7 +77,8 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("nr_channels", C.c_uint32), ("nr_taps", C.c_uint32),
                 ("outputs_per_tile", C.c_uint32), ("lds_bytes", C.c_uint32), ("grid_last", C.c_uint32),
                 ("tail_samples", C.c_uint32), ("rot_table_entries", C.c_uint64),
-                ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32)]
+                ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32),
+                ("launches_8bit", C.c_uint64)]
 
 
 class PocsagConfig(C.Structure):
@@ -162,6 +165,7 @@ def load_library():
     lib.mfm_engine_get_channel.argtypes = [vp, C.c_uint32, i16p, i16p, i16p]
     lib.mfm_engine_commit.argtypes = [vp]
     lib.mfm_engine_acquire_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.mfm_engine_acquire_input_bytes.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.mfm_engine_submit.argtypes = [vp, C.c_size_t, vp, C.c_int]
     lib.mfm_engine_push.argtypes = [vp, i16p, C.c_size_t]
     lib.mfm_engine_push_bytes.argtypes = [vp, vp, C.c_size_t, C.c_int]
@@ -328,6 +332,14 @@ class Engine:
     def acquire_input(self):
         ptr, cap = C.c_void_p(), C.c_size_t()
         self._chk(self.lib.mfm_engine_acquire_input(self.h, C.byref(ptr), C.byref(cap)), "mfm_engine_acquire_input")
+        return ptr.value, cap.value
+
+    def acquire_input_bytes(self, fmt):
+        """where the next block goes as 8-bit IQ bytes (two per sample); MfmError(MFM_E_STATE) when the engine cannot
+        read that format as bytes now"""
+        ptr, cap = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.mfm_engine_acquire_input_bytes(self.h, fmt, C.byref(ptr), C.byref(cap)),
+                  "mfm_engine_acquire_input_bytes")
         return ptr.value, cap.value
 
     def submit(self, nr_samples, producer_stream=None, wait_producer=None):

@@ -161,6 +161,8 @@ struct mfm_engine {
              v_within[4] = { 0, 0, 0, 0 };
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
+    int32_t *d_krow8[4] = { nullptr, nullptr, nullptr, nullptr }; /* [MFM_IN_*]: row constants of the 8-bit input forms */
+    bool v_raw8 = false; /* the second-generation kernel can read 8-bit input as it is (mfm_kernel_v3.hip, IN8) */
 
     /* device tables */
     uint32_t *d_coef = nullptr, *d_tapoff = nullptr;
@@ -181,6 +183,12 @@ struct mfm_engine {
     hipEvent_t in_ready = nullptr;
     int cur_in = 0;
     uint32_t tail = 0; /* samples of history at the front of d_in[cur_in] */
+    /* 8-bit blocks may sit in the input buffers as they came off the wire (2 bytes per sample, push_bytes): the format of
+     * what was staged into each buffer, and of the history at the front of d_in[cur_in] */
+    int in_fmt[2] = { MFM_IN_CS16, MFM_IN_CS16 };
+    int tail_fmt = MFM_IN_CS16;
+    uint16_t *d_tailtmp = nullptr; /* a history kept as bytes is widened through here when an int16 block follows it */
+    uint64_t launches_8bit = 0;
 
     /* outputs */
     OutSlot slots[kOutSlots];
@@ -241,6 +249,12 @@ void free_device(mfm_engine *e)
     (void)hipFree(e->d_tapoff);
     (void)hipFree(e->d_afrag);
     (void)hipFree(e->d_krow);
+    for (int i = 0; i < 4; i++) {
+        (void)hipFree(e->d_krow8[i]);
+        e->d_krow8[i] = nullptr;
+    }
+    (void)hipFree(e->d_tailtmp);
+    e->d_tailtmp = nullptr;
     (void)hipFree(e->d_info);
     (void)hipFree(e->d_rot);
     (void)hipFree(e->d_lut);
@@ -366,7 +380,8 @@ __device__ __forceinline__ uint32_t mfm_widen_pair(uint32_t two_bytes, int forma
     return mfm_pack16(a, b);
 }
 
-__global__ __launch_bounds__(256) void mfm_unpack_kernel(const uint16_t *raw, uint32_t *dst, uint32_t nr_samples, int format)
+__global__ __launch_bounds__(256) void mfm_unpack_kernel(const uint16_t *raw, uint32_t *dst, uint32_t nr_samples, int format,
+                                                         int cu8_odd_tail)
 {
     const uint32_t ngroups = nr_samples / 8;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(256) void mfm_unpack_kernel(const uint16_t *raw, ui
     const uint32_t s = ngroups * 8 + t;
     if (s < nr_samples) {
         uint32_t out = mfm_widen_pair(raw[s], format);
-        if (format == MFM_IN_CU8 && (nr_samples & 1u) && s == nr_samples - 1) {
+        if (cu8_odd_tail && format == MFM_IN_CU8 && (nr_samples & 1u) && s == nr_samples - 1) {
             const uint32_t two = raw[s]; /* file_if.c:146-150: the remainder loop stores the bare cast */
             out = mfm_pack16((int8_t)(two & 0xffu), (int8_t)(two >> 8));
         }
@@ -889,6 +904,23 @@ static int commit_locked(struct mfm_engine *e)
         HIP_TRY(hipMalloc(&e->d_krow, krow.size() * 4));
         HIP_TRY(hipMemcpy(e->d_krow, krow.data(), krow.size() * 4, hipMemcpyHostToDevice));
     }
+    /* 8-bit input read as it is (mfm_kernel_v3.hip, IN8): x = alpha * s + beta with s the byte as int8, so the row
+     * constant is (beta * sum(W) + 8192) / alpha - exact for all three forms.  krow = 128 * sum(W) + 8192. */
+    e->v_raw8 = e->use_v3 && (e->v_nstage4 / 2u + 511u) / 512u <= 4u && !(e->cfg.flags & MFM_F_WIDEN_8BIT);
+    if (e->v_raw8) {
+        std::vector<int32_t> k8(krow.size());
+        for (int fmt = MFM_IN_CS8; fmt <= MFM_IN_RTLSDR_U8; fmt++) {
+            for (size_t i = 0; i < krow.size(); i++) {
+                const uint32_t sum = (uint32_t)(((int64_t)krow[i] - 8192) / 128); /* |sum(W)| < 2^24: no wrap in krow */
+                k8[i] = fmt == MFM_IN_RTLSDR_U8 ? (int32_t)(sum + 64u)                  /* (128 * sum + 8192) / 128 */
+                        : fmt == MFM_IN_CU8     ? (int32_t)(8192u - 127u * sum)           /* beta = -127 */
+                                                : 8192;                                    /* cs8: beta = 0 */
+            }
+            HIP_TRY(hipMalloc(&e->d_krow8[fmt], k8.size() * 4));
+            HIP_TRY(hipMemcpy(e->d_krow8[fmt], k8.data(), k8.size() * 4, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMalloc(&e->d_tailtmp, ((size_t)T + D + 16u) * 2u));
+    }
     HIP_TRY(hipMalloc(&e->d_info, info.size() * sizeof(mfm_chan_info)));
     HIP_TRY(hipMemcpy(e->d_info, info.data(), info.size() * sizeof(mfm_chan_info), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&e->d_rot, rot.size() * sizeof(uint2)));
@@ -958,9 +990,46 @@ int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacit
     if (e->in_free_wait[e->cur_in]) {
         HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
     }
+    e->in_fmt[e->cur_in] = MFM_IN_CS16; /* what a device producer writes; mfm_engine_stage() says otherwise for raw bytes */
     *d_dst = e->d_in[e->cur_in] + e->tail;
     if (capacity_samples) {
         *capacity_samples = e->cap_in - e->tail;
+    }
+    return MFM_OK;
+}
+
+/* would the engine keep an 8-bit block of this format as bytes now?  (mfm_engine_internal.h) */
+int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_samples)
+{
+    /* not a cu8 block of odd length (file_if.c:146-150 widens its last sample differently), not behind a history of
+     * another format */
+    return e && e->committed && e->v_raw8 && (format == MFM_IN_CS8 || format == MFM_IN_CU8 || format == MFM_IN_RTLSDR_U8) &&
+           !(format == MFM_IN_CU8 && (nr_samples & 1u)) && (0 == e->tail || e->tail_fmt == format);
+}
+
+int mfm_engine_acquire_input_bytes(struct mfm_engine *e, int format, void **d_dst, size_t *capacity_samples)
+{
+    if (!e || !d_dst) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (format != MFM_IN_CS8 && format != MFM_IN_CU8 && format != MFM_IN_RTLSDR_U8) {
+        return fail(MFM_E_INVAL, "not an 8-bit sample format: %d", format);
+    }
+    if (!mfm_engine_can_take_bytes(e, format, 0)) {
+        return fail(MFM_E_STATE, "this engine cannot read format %d as bytes now (kernel variant, or a history of another "
+                                 "format): widen the block and use mfm_engine_acquire_input", format);
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (e->in_free_wait[e->cur_in]) {
+        HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
+    }
+    e->in_fmt[e->cur_in] = format;
+    *d_dst = reinterpret_cast<uint8_t *>(e->d_in[e->cur_in]) + (size_t)e->tail * 2;
+    if (capacity_samples) {
+        *capacity_samples = e->cap_in - e->tail; /* the block limit is that of int16 blocks */
     }
     return MFM_OK;
 }
@@ -989,6 +1058,13 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
     const int cur = e->cur_in;
     const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
     const uint32_t n_new = n_avail >= T ? (n_avail - T) / D + 1 : 0;
+    const int fmt = e->in_fmt[cur];
+    const bool raw8 = fmt != MFM_IN_CS16;
+    if (raw8 && !mfm_engine_can_take_bytes(e, fmt, nr_samples)) {
+        e->in_fmt[cur] = MFM_IN_CS16;
+        return fail(MFM_E_INVAL, "a block of %zu samples of format %d cannot be read as bytes here (cu8 blocks must be of "
+                                 "even length)", nr_samples, fmt);
+    }
 
     OutSlot *slot = nullptr;
     int slot_idx = -1;
@@ -1003,6 +1079,15 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
     if (wait_producer) {
         HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
         HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
+    }
+
+    if (!raw8 && e->tail && e->tail_fmt != MFM_IN_CS16) {
+        /* the history at the front of this buffer is bytes, the block behind it int16: widen it where it stands (the
+         * kernel that wrote it is ahead of this on the compute stream; the block's own samples start 4 * tail bytes in) */
+        HIP_TRY(hipMemcpyAsync(e->d_tailtmp, e->d_in[cur], (size_t)e->tail * 2, hipMemcpyDeviceToDevice, e->s_compute));
+        hipLaunchKernelGGL(mfm_unpack_kernel, dim3((e->tail / 8u + 256u) / 256u), dim3(256), 0, e->s_compute, e->d_tailtmp,
+                           e->d_in[cur], e->tail, e->tail_fmt, 0);
+        HIP_TRY(hipGetLastError());
     }
 
     bool tail_in_kernel = false;
@@ -1094,6 +1179,15 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             V.lut = e->d_lut;
             V.pcm = slot->d_pcm;
             V.iq_dbg = L.iq_dbg;
+            if (raw8) {
+                /* the buffer holds 2-byte samples: twice as many fit, a 16-byte chunk is 8 of them */
+                V.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
+                V.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
+                V.krow = e->d_krow8[fmt];
+                V.nstage4 = e->v_nstage4 / 2u;
+                V.x_last4 = (2u * e->cap_in - 8u) & ~7u;
+                e->launches_8bit++;
+            }
             const uint32_t grid = std::min(V.nitems, slots);
             HIP_TRY(mfm_launch_channel_kernel_v3(&V, e->any_iq ? 1 : 0, e->v_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */
@@ -1158,8 +1252,9 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
     const uint32_t consumed = n_new * D;
     const uint32_t new_tail = n_avail - consumed;
     if (new_tail && !tail_in_kernel) {
-        HIP_TRY(hipMemcpyAsync(e->d_in[cur ^ 1], e->d_in[cur] + consumed, (size_t)new_tail * 4,
-                               hipMemcpyDeviceToDevice, e->s_compute));
+        const size_t ss = raw8 ? 2 : 4;
+        HIP_TRY(hipMemcpyAsync(e->d_in[cur ^ 1], reinterpret_cast<const uint8_t *>(e->d_in[cur]) + (size_t)consumed * ss,
+                               (size_t)new_tail * ss, hipMemcpyDeviceToDevice, e->s_compute));
     }
     /* Every event record is a packet the command processor handles between two kernels (about 4 us each on
      * MI355X).  When the kernel carried the tail itself and its end is already stamped by the timing event, that
@@ -1195,6 +1290,8 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
     }
 
     e->tail = new_tail;
+    e->tail_fmt = fmt;
+    e->in_fmt[cur] = MFM_IN_CS16;
     e->cur_in = cur ^ 1;
     e->samples_in += nr_samples;
     return MFM_OK;
@@ -1220,7 +1317,7 @@ static int check_output_room(struct mfm_engine *e, size_t nr_samples)
  * the next submit() expects them, by work queued on the engine's copy stream.  *d_dst is that device address - what a
  * device group broadcasts to its other members before every member submits.
  */
-int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, int format, void **d_dst)
+int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, int format, int allow_raw, void **d_dst)
 {
     if (!e || !data) {
         return fail(MFM_E_INVAL, "NULL argument");
@@ -1249,7 +1346,15 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
         HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cfg.max_block_samples * 4, hipHostMallocDefault));
     }
     /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
-    if (format == MFM_IN_CS16) {
+    if (allow_raw && mfm_engine_can_take_bytes(e, format, nr_samples)) {
+        /* the matrix kernel reads the bytes themselves (mfm_kernel_v3.hip, IN8): half the HBM bytes, half the matrix
+         * instructions, no widening pass.  Everything else goes the int16 way below. */
+        uint8_t *raw = reinterpret_cast<uint8_t *>(e->d_in[cur]) + (size_t)e->tail * 2;
+        memcpy(e->h_in[cur], data, nr_samples * 2);
+        HIP_TRY(hipMemcpyAsync(raw, e->h_in[cur], nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
+        e->in_fmt[cur] = format;
+        dst = raw;
+    } else if (format == MFM_IN_CS16) {
         memcpy(e->h_in[cur], data, nr_samples * 4);
         HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
     } else {
@@ -1262,7 +1367,7 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
         uint32_t blocks = (uint32_t)((nr_samples / 8 + 255) / 256);
         blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
         hipLaunchKernelGGL(mfm_unpack_kernel, dim3(blocks), dim3(256), 0, e->s_in, e->d_raw[cur],
-                           static_cast<uint32_t *>(dst), (uint32_t)nr_samples, format);
+                           static_cast<uint32_t *>(dst), (uint32_t)nr_samples, format, 1);
         HIP_TRY(hipGetLastError());
     }
     if (d_dst) {
@@ -1286,13 +1391,13 @@ int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples)
 
 int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
 {
-    const int rc = mfm_engine_stage(e, iq, nr_samples, MFM_IN_CS16, nullptr);
+    const int rc = mfm_engine_stage(e, iq, nr_samples, MFM_IN_CS16, 0, nullptr);
     return rc != MFM_OK ? rc : mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 
 int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format)
 {
-    const int rc = mfm_engine_stage(e, bytes, nr_samples, format, nullptr);
+    const int rc = mfm_engine_stage(e, bytes, nr_samples, format, 1, nullptr);
     return rc != MFM_OK ? rc : mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 
@@ -1399,6 +1504,8 @@ int mfm_engine_reset(struct mfm_engine *e)
     e->fetch_seq = e->submit_seq = 0;
     e->last_slot = -1;
     e->tail = 0;
+    e->tail_fmt = MFM_IN_CS16;
+    e->in_fmt[0] = e->in_fmt[1] = MFM_IN_CS16;
     e->cur_in = 0;
     e->outputs = 0;
     e->samples_in = 0;
@@ -1430,6 +1537,7 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     {
         std::lock_guard<std::mutex> guard(e->mu);
         st->pending_blocks = (uint32_t)(e->submit_seq - e->fetch_seq);
+        st->launches_8bit = e->launches_8bit;
     }
     st->grid_last = e->grid_last;
     st->tail_samples = e->tail;

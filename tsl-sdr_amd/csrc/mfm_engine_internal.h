@@ -11,9 +11,13 @@ struct mfm_engine;
 
 extern "C" {
 /* stage one block (MFM_IN_* format) into the engine's next input buffer on its copy stream, without submitting;
- * MFM_E_BUSY when the output ring has no free slot for it.  *d_dst = device address of the staged samples. */
+ * MFM_E_BUSY when the output ring has no free slot for it.  *d_dst = device address of the staged samples: int16 pairs,
+ * unless allow_raw is set and the engine chose to keep an 8-bit block as bytes for its matrix kernel (then the next
+ * submit of THIS engine knows; nobody else can use the address). */
 __attribute__((visibility("hidden"))) int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples,
-                                                           int format, void **d_dst);
+                                                           int format, int allow_raw, void **d_dst);
+/* 1 when the engine would keep a block of nr_samples 8-bit samples of this format as bytes now */
+__attribute__((visibility("hidden"))) int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_samples);
 /* the stream mfm_engine_stage() queues its work on (hipStream_t) */
 __attribute__((visibility("hidden"))) void *mfm_engine_copy_stream(struct mfm_engine *e);
 /* MFM_OK when a block of nr_samples would find a free output slot, MFM_E_BUSY otherwise */

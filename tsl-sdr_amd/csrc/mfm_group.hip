@@ -340,8 +340,13 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
             return rc;
         }
     }
+    /* an 8-bit block crosses the links as bytes when every member's kernel can read it so (half the exchange) */
+    bool raw = format != MFM_IN_CS16;
+    for (size_t i = 0; i < S && raw; i++) {
+        raw = 0 != mfm_engine_can_take_bytes(g->eng[i], format, nr_samples);
+    }
     void *d_root = nullptr;
-    int rc = mfm_engine_stage(g->eng[0], data, nr_samples, format, &d_root); /* MFM_E_BUSY: nothing staged yet */
+    int rc = mfm_engine_stage(g->eng[0], data, nr_samples, format, raw ? 1 : 0, &d_root); /* MFM_E_BUSY: nothing staged yet */
     if (rc != MFM_OK) {
         return rc;
     }
@@ -349,7 +354,8 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
     dst[0] = d_root;
     for (size_t i = 1; i < S; i++) {
         size_t cap = 0;
-        rc = mfm_engine_acquire_input(g->eng[i], &dst[i], &cap);
+        rc = raw ? mfm_engine_acquire_input_bytes(g->eng[i], format, &dst[i], &cap)
+                 : mfm_engine_acquire_input(g->eng[i], &dst[i], &cap);
         if (rc != MFM_OK) {
             return rc;
         }
@@ -359,7 +365,7 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
     }
     /* the wideband block, as bytes, from the root's input buffer into every member's input buffer (the root's own
      * broadcast is in place).  One thread drives all devices: the calls sit in one RCCL group. */
-    const size_t bytes = nr_samples * 4;
+    const size_t bytes = nr_samples * (raw ? 2 : 4);
     int nrc = g->rccl.GroupStart();
     for (size_t i = 0; i < S && nrc == 0; i++) {
         nrc = g->rccl.Broadcast(d_root, dst[i], bytes, kNcclInt8, 0, g->comm[i], g->xs[i]);

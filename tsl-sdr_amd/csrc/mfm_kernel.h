@@ -139,7 +139,7 @@ struct mfm_launch_v3 {
     uint32_t sp_pitch;    /* bytes between the four sub-planes (rows = 0,1,2,3 mod 4) of a byte plane */
     uint32_t plane_pitch; /* bytes between the high-byte and the low-byte plane = 4 * sp_pitch */
     uint32_t buf_pitch;   /* bytes between the two staging buffers = 2 * plane_pitch */
-    uint32_t nstage4;     /* 16-byte chunks (4 samples) staged per tile: (LEAD + 64 + extra rows) * D / 4 */
+    uint32_t nstage4;     /* 16-byte chunks (4 samples; 8 with in8) staged per tile: (LEAD + 64 + extra rows) * D / 4 */
     uint32_t lut_off, sta_off;
     uint32_t cross[4];    /* per k-step: rows between an output's first sample and the k-step's first element */
     uint32_t within[4];   /* per k-step: byte offset of that element inside its row (for kg = 0) */
@@ -150,6 +150,10 @@ struct mfm_launch_v3 {
     uint32_t nitems;      /* chunks rounded up to a multiple of 8, times slices */
     uint32_t nchan, out_stride, ah_mask;
     uint32_t tail_src, tail_n;
+    uint32_t in8;         /* 0: x is packed int16 IQ.  7 / 14: x is 8-bit IQ off the wire (2 bytes per sample; n_avail,
+                             x_last4, tail_* count samples all the same), the value is the first rounding's shift and
+                             krow the matching row constants (mfm_kernel_v3.hip) */
+    uint32_t in8_xor;     /* 0x80808080 when the bytes are unsigned (RTL-SDR), else 0 */
     uint32_t *tail_dst;
     const uint32_t *afrag;
     const int32_t *krow;

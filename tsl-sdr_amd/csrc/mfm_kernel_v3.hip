@@ -31,6 +31,9 @@
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 
 #define MFM3_NT 512u
+#ifndef MFM3_EARLY16
+#define MFM3_EARLY16 1 /* 0: A/B builds - the int16 form requests the next image at the top of a tile, as before */
+#endif
 #define MFM3_SCHED_ALL_BUT_VMEM 0x38F
 
 /* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 (left to itself the compiler makes it two shifts and a three-operand
@@ -56,6 +59,22 @@ static __device__ __forceinline__ void mfm3_round_pack2(const uint32_t re_b[2], 
         "s_nop 0"
         : "=&v"(p0), "=&v"(p1)
         : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]));
+    p[0] = p0;
+    p[1] = p1;
+}
+
+/* the same with the shift as a template argument (8-bit input: the sums are 128 times smaller for the RTL-SDR scaling) */
+template <int SH>
+static __device__ __forceinline__ void mfm3_round_pack2_sh(const uint32_t re_b[2], const uint32_t im_b[2], uint32_t p[2])
+{
+    uint32_t p0, p1;
+    asm("v_lshrrev_b32_sdwa %0, %6, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, %6, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %0, %6, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, %6, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(p0), "=&v"(p1)
+        : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]), "n"(SH));
     p[0] = p0;
     p[1] = p1;
 }
@@ -345,7 +364,16 @@ static constexpr uint32_t mfm3_row_stride(uint32_t decim)
  * DFIX > 0: the decimation as a compile-time constant with the sub-planes at the fixed 4096-byte pitch - every B-fragment
  * address is then "lane register + instruction immediate" (ds_read has no SGPR operand: with run-time geometry each of
  * the 32 reads of a tile costs a v_add). */
-template <int KQ, bool DBG_IQ, int NCH, int AHM, int DFIX>
+/* IN8 > 0: the input is 8-bit IQ as it came off the wire (RTL-SDR, cs8 / cu8 files: multifm/rtl_sdr_if.c:146-148,
+ * multifm/file_if.c:66-157), two bytes per sample, and IN8 is the shift of the first rounding.  The reference widens
+ * such a sample to x = alpha * s + beta (s the byte as int8, after ^ 0x80 for the RTL-SDR's unsigned bytes; alpha = 128,
+ * beta = 128 there, alpha = 1, beta = 0 / -127 for cs8 / cu8), so
+ *     sum W * x = alpha * (256 * sum Wh * s + sum Wl * s) + beta * sum W      (mod 2^32)
+ * - ONE byte plane of samples, which is the wire format itself: the image is a 16-byte copy, a k-step is two MFMAs
+ * instead of four (6 instead of 12 for the decimation-96 geometry), the recombination one shift-add instead of two.  The
+ * per-row constant (L.krow) carries beta * sum W and the rounding bias, divided by alpha: for alpha = 128 bits 29:14 of
+ * the reference's sum are bits 22:7 of (hh << 8) + ll, IN8 = 7. */
+template <int KQ, bool DBG_IQ, int NCH, int AHM, int DFIX, int IN8>
 __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_launch_v3 L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -374,7 +402,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-        const uint32_t p8 = (tid + (uint32_t)j * MFM3_NT) * 8u;
+        const uint32_t p8 = (tid + (uint32_t)j * MFM3_NT) * (IN8 ? 16u : 8u); /* plane bytes in front of the chunk */
         const uint32_t row = p8 / row_bytes, colb = p8 % row_bytes;
         sta_s[j * MFM3_NT + tid] = (row & 3u) * sp_pitch + (row >> 2) * rs + colb;
     }
@@ -399,13 +427,19 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
          * tile 0 (replaced by the carried sample), samples past n_avail only outputs >= n_new (never stored) or
          * zero-padded taps.  Chunks past the image all read the tile's first line (one cache line per wave). */
         const uint32_t q = tid + (uint32_t)j * MFM3_NT;
-        int gs = (int)(tile * MFM_V3_OT * D) - (int)(MFM_V3_LEAD * D) + 4 * (int)(q < L.nstage4 ? q : 0u);
+        int gs = (int)(tile * MFM_V3_OT * D) - (int)(MFM_V3_LEAD * D) + (IN8 ? 8 : 4) * (int)(q < L.nstage4 ? q : 0u);
         gs = gs < 0 ? 0 : gs;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
-        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
+        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << (IN8 ? 1 : 2)));
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
-        if (tid + (uint32_t)j * MFM3_NT < L.nstage4) {
+        if (IN8) {
+            if (tid + (uint32_t)j * MFM3_NT < L.nstage4) {
+                const uint32_t m = L.in8_xor; /* 0x80808080: unsigned bytes -> int8 */
+                *reinterpret_cast<uint4 *>(smem + buf * buf_pitch + sta_s[j * MFM3_NT + tid]) =
+                    make_uint4(v.x ^ m, v.y ^ m, v.z ^ m, v.w ^ m);
+            }
+        } else if (tid + (uint32_t)j * MFM3_NT < L.nstage4) {
             uint2 hi, lo;
             hi.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
             hi.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
@@ -420,7 +454,11 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     /* the unconsumed samples at the end of this block are the head of the next one */
     if (blockIdx.x == 0) {
         for (uint32_t i = tid; i < L.tail_n; i += MFM3_NT) {
-            L.tail_dst[i] = L.x[L.tail_src + i];
+            if (IN8) {
+                reinterpret_cast<uint16_t *>(L.tail_dst)[i] = reinterpret_cast<const uint16_t *>(L.x)[L.tail_src + i];
+            } else {
+                L.tail_dst[i] = L.x[L.tail_src + i];
+            }
         }
     }
 
@@ -465,24 +503,49 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     uint32_t hist[2] = { 0, 0 };  /* lanes n = 0: filtered sample of the output in front of this tile */
     bool ch_ok[2] = { false, false };
 
-    while (true) {
-        /* what follows this tile in the workgroup's stream: the next tile of the chunk, or the first tile of the
-         * workgroup's next item; its image is requested now and written to the other buffer at the end */
-        uint32_t n_item = item, n_chunk = chunk, n_slice = slice, n_tile = tile + 1u, n_tend = tend;
-        bool n_first = false, n_valid = true;
-        if (n_tile >= tend) {
-            n_item = item + gridDim.x;
-            n_valid = mfm3_decode_item(L, n_item, &n_chunk, &n_slice);
-            n_tile = (uint32_t)(((uint64_t)n_chunk * L.ntiles) / L.nchunks);
-            n_tend = (uint32_t)(((uint64_t)(n_chunk + 1u) * L.ntiles) / L.nchunks);
-            n_first = true;
+    /* what follows a tile in the workgroup's stream: the next tile of the chunk, or the first tile of the workgroup's
+     * next item */
+    auto advance = [&](uint32_t &it, uint32_t &ch, uint32_t &sl, uint32_t &ti, uint32_t &te, bool &first) -> bool {
+        ti += 1u;
+        first = false;
+        if (ti >= te) {
+            it += gridDim.x;
+            const bool v = mfm3_decode_item(L, it, &ch, &sl);
+            ti = (uint32_t)(((uint64_t)ch * L.ntiles) / L.nchunks);
+            te = (uint32_t)(((uint64_t)(ch + 1u) * L.ntiles) / L.nchunks);
+            first = true;
+            return v;
         }
-        uint4 pre[NCH];
+        return true;
+    };
+    /* EARLY (the 8-bit form has the registers for it): the image of the tile after next is requested as soon as the
+     * staging registers are free - behind the barrier in the middle of a tile - and so has the epilogue and the next
+     * matrix phase to arrive, instead of one matrix phase.  (Knock-out builds put the wait for the image at a fifth of
+     * the int16 kernel's time, profiles/r02_knockout_v3.txt.) */
+    constexpr bool EARLY = IN8 != 0 || MFM3_EARLY16;
+    uint4 pre[NCH];
+    if (EARLY) {
+        uint32_t a_item = item, a_chunk = chunk, a_slice = slice, a_tile = tile, a_tend = tend;
+        bool a_first = false;
+        const bool a_valid = advance(a_item, a_chunk, a_slice, a_tile, a_tend, a_first);
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
-            pre[j] = stage_load(n_valid ? n_tile : tile, j);
+            pre[j] = stage_load(a_valid ? a_tile : tile, j);
         }
-        __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
+    }
+
+    while (true) {
+        /* its image is written to the other buffer between this tile's matrix phase and its epilogue */
+        uint32_t n_item = item, n_chunk = chunk, n_slice = slice, n_tile = tile, n_tend = tend;
+        bool n_first = false;
+        const bool n_valid = advance(n_item, n_chunk, n_slice, n_tile, n_tend, n_first);
+        if (!EARLY) {
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                pre[j] = stage_load(n_valid ? n_tile : tile, j);
+            }
+            __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
+        }
 
         const uint32_t rb = slice * 8u + wave;
         const bool rb_valid = rb < L.nrb; /* wave uniform */
@@ -516,6 +579,26 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             /* one column group: 16 rows x 16 columns x 64*KQ elements, four byte-plane products (acc = hh, md, ll) */
             auto mfma_chain = [&](const uint32_t (&o)[KQ], mfm_v4i (&acc)[3]) {
                 mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = *krow_s;
+                if constexpr (IN8 != 0) {
+                    /* one sample plane: hh = sum Wh * s, ll = sum Wl * s + row constant */
+                    mfm_v4i b[2];
+                    b[0] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[0]);
+#pragma unroll
+                    for (int kq = 0; kq < KQ; kq++) {
+                        const int cb = kq & 1, nb = cb ^ 1;
+                        if (kq + 1 < KQ) {
+                            b[nb] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[kq + 1]);
+                        }
+                        if ((ah_mask >> kq) & 1u) {
+                            hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b[cb], hh, 0, 0, 0);
+                        }
+                        ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b[cb], ll, 0, 0, 0);
+                    }
+                    acc[0] = hh;
+                    acc[1] = md;
+                    acc[2] = ll;
+                    return;
+                }
                 mfm_v4i bh[2], bl[2];
                 bh[0] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[0]);
                 bl[0] = *reinterpret_cast<const mfm_v4i *>(img + lb + o[0] + plane_pitch);
@@ -540,6 +623,15 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             /* recombination and the first Q14 rounding -> packed filtered samples of the lane's two channels */
             auto finish = [&](const mfm_v4i (&acc)[3], uint32_t fout[2]) {
                 uint32_t a_re[2], a_im[2];
+                if constexpr (IN8 != 0) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_re[c]) : "v"(acc[0][2 * c]), "v"(acc[2][2 * c]));
+                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_im[c]) : "v"(acc[0][2 * c + 1]), "v"(acc[2][2 * c + 1]));
+                    }
+                    mfm3_round_pack2_sh<IN8 ? IN8 : 14>(a_re, a_im, fout);
+                    return;
+                }
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     a_re[c] = mfm3_combine(acc[0][2 * c], acc[1][2 * c], acc[2][2 * c]);
@@ -608,7 +700,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 }
             }
 
-            if constexpr (DFIX == 96 && KQ == 4 && AHM == 0x6) {
+            if constexpr (DFIX == 96 && KQ == 4 && AHM == 0x6 && IN8 == 0) {
                 /* ---- the four column groups as hand-scheduled blocks (mfm3_group_d96): software pipelined by one group,
                  *      B fragments requested two k-steps ahead ---- */
                 constexpr int RS = (int)mfm3_row_stride(96), SP = 4096;
@@ -690,6 +782,16 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             stage_store(cur ^ 1u, j, pre[j]);
         }
         __syncthreads();
+        if (EARLY) {
+            uint32_t a_item = n_item, a_chunk = n_chunk, a_slice = n_slice, a_tile = n_tile, a_tend = n_tend;
+            bool a_first = false;
+            const bool a_valid = n_valid && advance(a_item, a_chunk, a_slice, a_tile, a_tend, a_first);
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                pre[j] = stage_load(a_valid ? a_tile : tile, j);
+            }
+            __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
+        }
         if (rb_valid) {
             const uint32_t ch0 = rb * 8u + 2u * kg;
             /* ---- one channel after the other (register pressure): derotation, discriminator, stores ---- */
@@ -805,10 +907,10 @@ extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int d
     if (nch < 1 || nch > MFM_V3_CH_MAX) {
         return hipErrorInvalidValue;
     }
-#define MFM3_LAUNCH(KQ_, DBG_, NCH_, AHM_) MFM3_LAUNCH_F(KQ_, DBG_, NCH_, AHM_, 0)
-#define MFM3_LAUNCH_F(KQ_, DBG_, NCH_, AHM_, DFIX_)                                                          \
+#define MFM3_LAUNCH(KQ_, DBG_, NCH_, AHM_) MFM3_LAUNCH_F(KQ_, DBG_, NCH_, AHM_, 0, 0)
+#define MFM3_LAUNCH_F(KQ_, DBG_, NCH_, AHM_, DFIX_, IN8_)                                                    \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_v3<KQ_, DBG_, NCH_, AHM_, DFIX_>;                                      \
+        auto kfn = mfm_channel_kernel_v3<KQ_, DBG_, NCH_, AHM_, DFIX_, IN8_>;                                \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
         if (e_ != hipSuccess) {                                                                              \
@@ -837,12 +939,48 @@ extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int d
             MFM3_LAUNCH_N(KQ_, false, AHM_);                                                                 \
         }                                                                                                    \
     } while (0)
+    /* 8-bit input (L->in8 = 7 or 14, the first rounding's shift; the engine only asks when dbg_iq is off): half the
+     * staging chunks per thread (16 bytes are 8 samples), run-time tap-plane mask except for the fixed geometry */
+#define MFM3_LAUNCH_8(KQ_, IN8_)                                                                             \
+    do {                                                                                                     \
+        switch (nch) {                                                                                       \
+        case 1: MFM3_LAUNCH_F(KQ_, false, 1, -1, 0, IN8_); break;                                            \
+        case 2: MFM3_LAUNCH_F(KQ_, false, 2, -1, 0, IN8_); break;                                            \
+        case 3: MFM3_LAUNCH_F(KQ_, false, 3, -1, 0, IN8_); break;                                            \
+        default: MFM3_LAUNCH_F(KQ_, false, 4, -1, 0, IN8_); break;                                           \
+        }                                                                                                    \
+    } while (0)
+#define MFM3_LAUNCH_8K(IN8_)                                                                                 \
+    do {                                                                                                     \
+        if (L->decim == 96 && L->kq == 4 && nch == 2 && L->ah_mask == 0x6u && L->rs == mfm3_row_stride(96) &&      \
+            L->sp_pitch == 4096u) {                                                                          \
+            MFM3_LAUNCH_F(4, false, 2, 0x6, 96, IN8_);                                                       \
+        } else {                                                                                             \
+            switch (L->kq) {                                                                                 \
+            case 1: MFM3_LAUNCH_8(1, IN8_); break;                                                           \
+            case 2: MFM3_LAUNCH_8(2, IN8_); break;                                                           \
+            case 4: MFM3_LAUNCH_8(4, IN8_); break;                                                           \
+            default: return hipErrorInvalidValue;                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+    if (L->in8) {
+        if (dbg_iq || nch > 4 || (L->in8 != 7u && L->in8 != 14u)) {
+            return hipErrorInvalidValue;
+        }
+        if (L->in8 == 7u) {
+            MFM3_LAUNCH_8K(7);
+        } else {
+            MFM3_LAUNCH_8K(14);
+        }
+        return hipGetLastError();
+    }
     /* the 2.4 MS/s -> 25 kS/s geometry of the reference's configurations (decimation 96, 128-tap low-pass whose
      * outer k-steps fit one byte) with every address a compile-time constant */
 #ifndef MFM3_NO_FIX
     if (L->decim == 96 && L->kq == 4 && nch == 4 && !dbg_iq && L->ah_mask == 0x6u && L->rs == mfm3_row_stride(96) &&
         L->sp_pitch == 4096u) {
-        MFM3_LAUNCH_F(4, false, 4, 0x6, 96);
+        MFM3_LAUNCH_F(4, false, 4, 0x6, 96, 0);
         return hipGetLastError();
     }
 #endif
@@ -859,6 +997,8 @@ extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int d
     default: return hipErrorInvalidValue;
     }
 #undef MFM3_LAUNCH_D
+#undef MFM3_LAUNCH_8K
+#undef MFM3_LAUNCH_8
 #undef MFM3_LAUNCH_N
 #undef MFM3_LAUNCH
     return hipGetLastError();
