@@ -492,3 +492,89 @@ def test_gpu_8bit_stream_changes_format_mid_way(pkg, ora):
     got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 32768)
     assert got.shape == want.shape and np.array_equal(got, want)
     assert 2 <= st["launches_8bit"] < st["launches"]
+
+
+@pytest.mark.gpu
+def test_gpu_device_producer_hands_over_bytes(pkg, ora):
+    """mfm_engine_acquire_input_bytes: a producer on the device (here a device-to-device copy standing in for a
+    collective) writes 8-bit IQ where the engine says, submit() as for int16 blocks.  Refused with MFM_E_STATE when the
+    history in front is of another format, and a cu8 block of odd length is refused at submit."""
+    import ctypes as C
+    import torch
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 9000.0, fs)
+    offs = [-300000, 12500, 412500, 25000]
+    rng = np.random.RandomState(3)
+    b = pkg.binding
+    eng = pkg.Engine(fs, decim, 1 << 15, device=0)
+    for o in offs:
+        eng.add_channel(int(o), taps, 1.0)
+    eng.commit()
+    iq, got = [], []
+    for m in (30000, 32768, 1000, 20002):
+        raw = rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+        iq.append(ora.unpack_bytes(raw, 2).reshape(-1, 2))
+        src = torch.from_numpy(raw).to("cuda:0")
+        ptr, cap = eng.acquire_input_bytes(b.MFM_IN_CU8)
+        assert cap >= m
+        assert rt.hipMemcpy(ptr, src.data_ptr(), 2 * m, 3) == 0
+        eng.submit(m, producer_stream=0)
+        eng.sync()
+        got.append(eng.fetch()[1])
+    # the history is cu8 bytes now: another format cannot be taken as bytes, and an odd cu8 block not at all
+    with pytest.raises(b.MfmError) as ei:
+        eng.acquire_input_bytes(b.MFM_IN_RTLSDR_U8)
+    assert ei.value.code == b.MFM_E_STATE
+    ptr, _ = eng.acquire_input_bytes(b.MFM_IN_CU8)
+    with pytest.raises(b.MfmError) as ei:
+        eng.submit(777, producer_stream=0)
+    assert ei.value.code == b.MFM_E_INVAL
+    # ... and the stream is still usable: the same 777 samples widened by the caller, the int16 way
+    raw = rng.randint(0, 256, size=(777, 2)).astype(np.uint8)
+    wide = ora.unpack_bytes(raw, 2).reshape(-1, 2)
+    iq.append(wide)
+    assert eng.push(wide.reshape(-1)) == 0
+    eng.sync()
+    got.append(eng.fetch()[1])
+    st = eng.stats()
+    eng.close()
+    assert st["launches_8bit"] == 4 and st["launches"] == 5
+    iq = np.concatenate(iq)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[0] for o in offs])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[1] for o in offs])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    got = np.concatenate(got, axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [1, 3])
+def test_gpu_8bit_bytes_on_the_reference_geometry(pkg, ora, fmt):
+    """The 2.4 MS/s -> 25 kS/s plan of the headline configuration (64 channels, decimation 96, 128 taps whose outer
+    k-steps fit one byte: the kernel instance with compile-time geometry) fed with bytes."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch")
+    rng = np.random.RandomState(50 + fmt)
+    eng = pkg.Engine(fs, decim, 1 << 18, device=0)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    iq, got = [], []
+    for m in (1 << 18, 100000, 96 * 64 * 7, 262143):
+        raw = rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+        iq.append(ora.unpack_bytes(raw, fmt).reshape(-1, 2))
+        assert eng.push_bytes(raw, fmt) == 0
+        eng.sync()
+        got.append(eng.fetch()[1])
+    st = eng.stats()
+    eng.close()
+    assert st["kernel_variant"] == 2 and st["launches_8bit"] == 4
+    iq = np.concatenate(iq)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
+    got = np.concatenate(got, axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)

@@ -89,6 +89,47 @@ def test_group_on_one_device_matches_oracle(pkg, ora, exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["direct", "rccl"])
+def test_group_exchanges_8bit_blocks_as_bytes(pkg, ora, exchange):
+    """RTL-SDR bytes through the group: where every member's kernel can read them as they are the block is staged,
+    broadcast (RCCL path: half the bytes of an int16 block) and consumed as bytes; a stream that turns to int16 goes
+    on through the widening.  PCM against the oracle on the reference's host-side widening."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=24)
+    rng = np.random.RandomState(9)
+    b = pkg.binding
+    grp = b.Group(fs, decim, 1 << 16, devices=(0,), exchange=b.MFM_X_RCCL if exchange == "rccl" else b.MFM_X_AUTO)
+    for o, g in zip(offs, gains):
+        grp.add_channel(int(o), taps, float(g))
+    grp.commit()
+    blocks = [(rng.randint(0, 256, size=(m, 2)).astype(np.uint8), 3) for m in (65536, 30001, 4096, 50000)]
+    blocks.append((rng.randint(-32768, 32768, size=(20000, 2)).astype(np.int16), 0))
+    blocks.append((rng.randint(0, 256, size=(40000, 2)).astype(np.uint8), 3))
+    iq, parts = [], []
+    for blk, fmt in blocks:
+        iq.append(blk.reshape(-1, 2) if fmt == 0 else ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+        while grp.push(blk, fmt) == b.MFM_E_BUSY:
+            parts.append(grp.fetch()[1])
+    grp.sync()
+    while True:
+        got = grp.fetch()
+        if got is None:
+            break
+        parts.append(got[1])
+    st = grp.stats(0)
+    _, nblk, moved = grp.exchange_info()
+    grp.close()
+    assert st["launches_8bit"] == 4 and st["launches"] == 6
+    assert moved == 0 and (nblk == 6) == (exchange == "rccl")
+    iq = np.concatenate(iq)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
+    pcm = np.concatenate(parts, axis=1)
+    assert pcm.shape == ref.shape and np.array_equal(pcm, ref)
+
+
+@pytest.mark.gpu
 def test_group_with_more_devices_than_the_box_has_fails_cleanly(pkg):
     import torch
     n = torch.cuda.device_count()

@@ -519,6 +519,11 @@ class Group:
     def sync(self):
         self._chk(self.lib.mfm_group_sync(self.h), "mfm_group_sync")
 
+    def stats(self, shard):
+        st = Stats()
+        self._chk(self.lib.mfm_group_get_stats(self.h, shard, C.byref(st)), "mfm_group_get_stats")
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
     def exchange_info(self):
         u, b, x = C.c_int(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.mfm_group_exchange_info(self.h, C.byref(u), C.byref(b), C.byref(x)), "mfm_group_exchange_info")
