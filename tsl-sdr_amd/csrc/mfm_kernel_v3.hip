@@ -353,6 +353,95 @@ static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, 
     tP[3] = t3;
 }
 
+/*
+ * The same for 8-bit input (IN8): one sample plane, so a column group is 6 MFMAs - ll over k-steps 0..3, hh over k-steps
+ * 1, 2 - and the recombination of the previous group one shift-add per sum.  Twelve shadow slots, and what wants them:
+ * four fragment reads, four shift-adds, four SDWA shifts - but the previous group's last MFMA wrote ll, and a VALU read
+ * of an MFMA result wants three MFMAs in between, so the recombination starts behind the third MFMA and its last two
+ * shifts are paid for at the end of the block.  Fragment buffers b0, b1, b2 rotate as above (in: k-steps 0, 1 of this
+ * group in b0, b1; out: k-steps 0, 1 of the next in b1, b2, in flight).  acc = {hh, -, ll}; SH = the first rounding's
+ * shift.
+ */
+#define MFM3_SHN0(d, a) "v_lshrrev_b32_sdwa %[" #d "], %[sh], %[" #a "] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+#define MFM3_SHN1(d, a) "v_lshrrev_b32_sdwa %[" #d "], %[sh], %[" #a "] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+
+template <bool HAS_PREV, bool HAS_NEXT, int SH, int O2, int O3, int N0, int N1>
+static __device__ __forceinline__ void mfm3_group_d96_b8(uint32_t lb, uint32_t ka, const mfm_v4i &al0, const mfm_v4i &al1,
+                                                         const mfm_v4i &al2, const mfm_v4i &al3, const mfm_v4i &ah1,
+                                                         const mfm_v4i &ah2, mfm_v4i &b0, mfm_v4i &b1, mfm_v4i &b2,
+                                                         const mfm_v4i (&accP)[3], mfm_v4i (&acc)[3], uint32_t (&tP)[4])
+{
+    mfm_v4i hh, ll;
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    asm volatile(
+        "ds_read_b128 %[ll], %[ka]\n\t"                                      /* sum(W)-constant + rounding bias of the lane's rows */
+        MFM3_RD(b2, o2)                                                      /* k-step 2 */
+        "s_waitcnt lgkmcnt(1)\n\t"                                           /* b0, b1 (requested by the previous block), the constant */
+        MFM3_MF(ll, al0, b0, "%[ll]")
+        MFM3_RD(b0, o3)                                                      /* k-step 3 replaces k-step 0 */
+        MFM3_MF(hh, ah1, b1, "0")
+        MFM3_MF(ll, al1, b1, "%[ll]")
+        : [hh] "=&v"(hh), [ll] "=&v"(ll), [b2] "=&v"(b2), [b0] "+v"(b0)
+        : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [b1] "v"(b1), [o2] "n"(O2), [o3] "n"(O3)
+        : "memory");
+    if (HAS_PREV && HAS_NEXT) {
+        asm volatile(
+            MFM3_RD(b1, n0)                                                  /* the next group's k-step 0 */
+            MFM3_LA(t0, h0, l0)
+            "s_waitcnt lgkmcnt(2)\n\t"                                       /* b2 = k-step 2 */
+            MFM3_MF(hh, ah2, b2, "%[hh]")
+            MFM3_LA(t1, h1, l1) MFM3_LA(t2, h2, l2)
+            MFM3_MF(ll, al2, b2, "%[ll]")
+            MFM3_RD(b2, n1)                                                  /* the next group's k-step 1 */
+            MFM3_LA(t3, h3, l3)
+            "s_waitcnt lgkmcnt(2)\n\t"                                       /* b0 = k-step 3 */
+            MFM3_MF(ll, al3, b0, "%[ll]")
+            MFM3_SHN0(t0, t0) MFM3_SHN0(t2, t2)
+            MFM3_SHN1(t0, t1) MFM3_SHN1(t2, t3)
+            : [hh] "+v"(hh), [ll] "+v"(ll), [b1] "=&v"(b1), [b2] "+v"(b2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+              [t3] "=&v"(t3)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0] "v"(b0), [h0] "v"(accP[0][0]),
+              [h1] "v"(accP[0][1]), [h2] "v"(accP[0][2]), [h3] "v"(accP[0][3]), [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]),
+              [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]), [n0] "n"(N0), [n1] "n"(N1), [sh] "n"(SH)
+            : "memory");
+    } else if (HAS_NEXT) {
+        asm volatile(
+            MFM3_RD(b1, n0)
+            "s_waitcnt lgkmcnt(2)\n\t"
+            MFM3_MF(hh, ah2, b2, "%[hh]")
+            MFM3_MF(ll, al2, b2, "%[ll]")
+            MFM3_RD(b2, n1)
+            "s_waitcnt lgkmcnt(2)\n\t"
+            MFM3_MF(ll, al3, b0, "%[ll]")
+            : [hh] "+v"(hh), [ll] "+v"(ll), [b1] "=&v"(b1), [b2] "+v"(b2)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0] "v"(b0), [n0] "n"(N0), [n1] "n"(N1)
+            : "memory");
+    } else {
+        asm volatile(
+            MFM3_LA(t0, h0, l0)
+            "s_waitcnt lgkmcnt(1)\n\t"                                       /* b2; nothing is requested for a next group */
+            MFM3_MF(hh, ah2, b2, "%[hh]")
+            MFM3_LA(t1, h1, l1) MFM3_LA(t2, h2, l2)
+            MFM3_MF(ll, al2, b2, "%[ll]")
+            MFM3_LA(t3, h3, l3)
+            "s_waitcnt lgkmcnt(0)\n\t"
+            MFM3_MF(ll, al3, b0, "%[ll]")
+            MFM3_SHN0(t0, t0) MFM3_SHN0(t2, t2)
+            MFM3_SHN1(t0, t1) MFM3_SHN1(t2, t3)
+            : [hh] "+v"(hh), [ll] "+v"(ll), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+            : [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b2] "v"(b2), [b0] "v"(b0), [h0] "v"(accP[0][0]),
+              [h1] "v"(accP[0][1]), [h2] "v"(accP[0][2]), [h3] "v"(accP[0][3]), [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]),
+              [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]), [sh] "n"(SH)
+            : "memory");
+    }
+    acc[0] = hh;
+    acc[2] = ll;
+    tP[0] = t0;
+    tP[1] = t1;
+    tP[2] = t2;
+    tP[3] = t3;
+}
+
 /* LDS row stride of a decimation: 2 * D plane bytes rounded up to an odd multiple of 32 (the engine's rule) */
 static constexpr uint32_t mfm3_row_stride(uint32_t decim)
 {
@@ -736,6 +825,45 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 f[2][1] = t[2];
                 /* rotator entries of this tile, four consecutive ones per channel: requested at the end of the matrix phase
                  * (its registers are all taken until here), needed behind the staging stores and the barrier */
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
+                    rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
+                    rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                settle();
+                finish(acc1, f[3]);
+#undef MFM3_OFS
+            } else if constexpr (DFIX == 96 && KQ == 4 && AHM == 0x6 && IN8 != 0) {
+                /* ---- the same pipeline for one sample plane (mfm3_group_d96_b8) ---- */
+                constexpr int RS = (int)mfm3_row_stride(96), SP = 4096;
+#define MFM3_OFS(g, kq) ((((g) + ((kq) == 3 ? 1 : 0)) & 3) * SP + (1 + (((g) + ((kq) == 3 ? 1 : 0)) >> 2)) * RS + ((kq) == 3 ? 0 : 64 * (kq)))
+                const uint32_t ka = (uint32_t)(uintptr_t)krow_s;
+                mfm_v4i pb, qb, rb2 = { 0, 0, 0, 0 }; /* three rotating fragment buffers */
+                asm volatile("ds_read_b128 %[x0], %[lb] offset:%[a]\n\t"
+                             "ds_read_b128 %[x1], %[lb] offset:%[b]\n\t"
+                             : [x0] "=&v"(pb), [x1] "=&v"(qb)
+                             : [lb] "v"(lb), [a] "n"(MFM3_OFS(0, 0)), [b] "n"(MFM3_OFS(0, 1))
+                             : "memory");
+                mfm_v4i acc0[3], acc1[3];
+                uint32_t t[4];
+                const mfm_v4i none[3] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+                mfm3_group_d96_b8<false, true, IN8, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
+                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, none, acc0, t);
+                mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
+                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qb, rb2, pb, acc0, acc1, t);
+                f[0][0] = t[0];
+                f[0][1] = t[2];
+                mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
+                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rb2, pb, qb, acc1, acc0, t);
+                f[1][0] = t[0];
+                f[1][1] = t[2];
+                mfm3_group_d96_b8<true, false, IN8, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, acc0, acc1, t);
+                f[2][0] = t[0];
+                f[2][1] = t[2];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
