@@ -184,6 +184,33 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
             "ms_per_block": total, "value": block * len(offs) / total / 1e3, "unit": "MSamp/s x channels"}
 
 
+def ingest_8bit(pkg, fs, decim, taps, offs, gains, block, int16_kernel_ms, steps=6, warmup=2):
+    """the same channels fed with an RTL-SDR block (8-bit IQ, multifm/rtl_sdr_if.c:146-148) that the
+    matrix kernel reads as bytes, outside the timed region; kernel duration from the engine's HIP
+    events.  Never part of `value`."""
+    b = pkg.binding
+    eng = pkg.Engine(fs, decim, block, device=0, flags=b.MFM_F_DEVICE_ONLY | b.MFM_F_TIMING)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    base = pkg.synth.synth_iq(1 << 22, fs, offs[:: max(1, len(offs) // 8)][:8], seed=7).reshape(-1, 2)
+    u8 = np.clip((base.astype(np.int32) >> 7) + 127, 0, 255).astype(np.uint8)
+    data = np.tile(u8, (block // u8.shape[0] + 1, 1))[:block]
+    for _ in range(warmup + steps):
+        rc = eng.push_bytes(data, b.MFM_IN_RTLSDR_U8)
+        if rc != 0:
+            raise SystemExit(f"mfm_engine_push_bytes: {rc}")
+    eng.sync()
+    ms = float(np.mean(eng.launch_ms()[-steps:]))
+    st = eng.stats()
+    eng.close()
+    alg = block * 2 + len(offs) * (block // decim) * 2
+    return {"input": "rtl-sdr u8 IQ, read as bytes by the matrix kernel", "block_samples": block, "kernel_ms": ms,
+            "launches_8bit": st["launches_8bit"], "launches": st["launches"], "algorithmic_bytes": alg,
+            "hbm_GBps": alg / ms / 1e6, "input_msamp_per_s": block / ms / 1e3,
+            "time_vs_int16_kernel": ms / int16_kernel_ms}
+
+
 def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=24, iters=30):
     """Kernel time of the floating-point IQ path (mfm_f32_*) on 2^24-sample blocks resident in HBM, HIP events on
     the launch stream; the integer kernel's time is scaled to the same block length for the ratio."""
@@ -404,6 +431,8 @@ def main():
                                          block)
     if rank == 0 and world == 1 and not args.no_chain and decim == 96:
         line["flex_chain"] = flex_chain(pkg, torch, fs, decim, taps, offs, gains, block)
+        if line["roofline"]["kernel"].startswith("mfm_channel_kernel_v3"):
+            line["ingest_8bit"] = ingest_8bit(pkg, fs, decim, taps, offs, gains, block, line["roofline"]["kernel_ms"])
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
