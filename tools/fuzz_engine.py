@@ -70,10 +70,73 @@ def case(pkg, ora, rng):
     return None, variant
 
 
+def case8(pkg, ora, rng):
+    """8-bit ingest: a stream of blocks in the reference's 8-bit formats (mostly one format, now and then another one or
+    int16), each block widened for the oracle the way the reference's front ends widen it; geometries drawn so that the
+    kernel that reads bytes runs in most cases."""
+    b = pkg.binding
+    decim = int(rng.choice([32, 64, 96, 96, 96, 128, 160, 25, 40]))
+    fs = int(rng.choice([1200000, 2400000]))
+    ntaps = max(decim, int(rng.choice([32, 64, 128, 128, 100, 96])))
+    nch = int(rng.choice([1, 3, 8, 9, 16, 64, 65, 130]))
+    taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
+    offs = rng.randint(-fs // 2, fs // 2, size=nch)
+    offs[: min(nch, 4)] = [0, 25000, -37500, 3125][: min(nch, 4)]
+    gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
+    max_block = int(rng.choice([65536, 8192, 100000]))
+    flags = b.MFM_F_WIDEN_8BIT if rng.rand() < 0.15 else 0
+    try:
+        eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
+        for o, g in zip(offs, gains):
+            eng.add_channel(int(o), taps, float(g))
+        eng.commit()
+    except pkg.MfmError as e:
+        return None, "refused: %s" % e
+    cre = np.stack([eng.get_channel(c)[0] for c in range(nch)])
+    cim = np.stack([eng.get_channel(c)[1] for c in range(nch)])
+    incr = np.stack([eng.get_channel(c)[2] for c in range(nch)])
+    main_fmt = int(rng.choice([1, 2, 3, 3]))
+    total, iq, got, seq = 0, [], [], []
+    while total < 300000:
+        m = int(rng.randint(1, max_block + 1))
+        fmt = main_fmt if rng.rand() < 0.9 else int(rng.randint(0, 4))
+        if fmt == 0:
+            blk = rng.randint(-32768, 32768, size=(m, 2)).astype(np.int16)
+            iq.append(blk)
+        else:
+            blk = rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+            iq.append(ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+        seq.append((fmt, m))
+        while True:
+            rc = eng.push(blk.reshape(-1)) if fmt == 0 else eng.push_bytes(blk, fmt)
+            if rc == 0:
+                break
+            if rc != b.MFM_E_BUSY:
+                return "push failed (%d)" % rc, None
+            got.append(eng.fetch()[1])
+        total += m
+    eng.sync()
+    while True:
+        blk = eng.fetch()
+        if blk is None:
+            break
+        got.append(blk[1])
+    st = eng.stats()
+    eng.close()
+    ref, _ = ora.run_channels(np.concatenate(iq), cre, cim, incr, decim, threads=8)
+    gotc = np.concatenate(got, axis=1) if got else np.zeros((nch, 0), np.int16)
+    desc = "8-bit: fs %d D %d T %d C %d flags %d max_block %d variant %d bytes-launches %d/%d blocks %s" % (
+        fs, decim, ntaps, nch, flags, max_block, st["kernel_variant"], st["launches_8bit"], st["launches"], seq[:12])
+    if gotc.shape != ref.shape or not np.array_equal(gotc, ref):
+        return "PCM differs: " + desc, desc
+    return None, "bytes" if st["launches_8bit"] else "widened"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--ingest8", action="store_true", help="8-bit ingest streams (mfm_engine_push_bytes) instead")
     args = ap.parse_args()
     from __graft_entry__ import load_package
     import oracle_lib as ora
@@ -82,13 +145,17 @@ def main():
     t0 = time.time()
     counts = {}
     while time.time() - t0 < args.seconds:
-        err, info = case(pkg, ora, rng)
+        err, info = case8(pkg, ora, rng) if args.ingest8 else case(pkg, ora, rng)
         if err:
             print("FAIL", err, "after", counts)
             return 1
+        if args.ingest8:
+            k8 = "refused" if str(info).startswith("refused") else info
+            counts[k8] = counts.get(k8, 0) + 1
+            continue
         key = info if isinstance(info, (int, np.integer)) else "refused"
         counts[int(key) if key != "refused" else key] = counts.get(int(key) if key != "refused" else key, 0) + 1
-    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2)", counts)
+    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2; --ingest8: by how the blocks were read)", counts)
     return 0
 
 
