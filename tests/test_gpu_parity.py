@@ -443,15 +443,22 @@ def _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, max_block, flags=0):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt", [1, 2, 3])
-@pytest.mark.parametrize("geom", ["d96_t128", "d32_t32", "d64_t64", "d128_t128"])
+@pytest.mark.parametrize("geom", ["d96_t128", "d32_t32", "d64_t64", "d128_t128", "d96_t128_gen1", "d25_t128", "d40_t64",
+                                  "d96_t512", "d400_t512", "d7_t33"])
 def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom):
     """Where the second-generation matrix kernel runs, an 8-bit block stays bytes in HBM and the kernel's GEMM takes
     the one sample plane as it is (mfm_kernel_v3.hip, IN8): the PCM must equal the oracle run on the reference's
     host-side widening (rtl_sdr_if.c:146-158, file_if.c:66-157), block sizes ragged, the history crossing blocks as
     bytes.  Full-range bytes (0x00, 0x7f, 0x80, 0xff all occur)."""
     fs = 2400000
-    decim, ntaps = {"d96_t128": (96, 128), "d32_t32": (32, 32), "d64_t64": (64, 64), "d128_t128": (128, 128)}[geom]
-    taps = pkg.synth.design_lpf(ntaps, 9000.0, fs)
+    # second-generation kernel; first-generation kernel: forced, rows that are not multiples of 16 bytes (chunks straddle
+    # rows), streamed filters, single-iteration tiles, a tiny decimation
+    decim, ntaps = {"d96_t128": (96, 128), "d32_t32": (32, 32), "d64_t64": (64, 64), "d128_t128": (128, 128),
+                    "d96_t128_gen1": (96, 128), "d25_t128": (25, 128), "d40_t64": (40, 64), "d96_t512": (96, 512),
+                    "d400_t512": (400, 512), "d7_t33": (7, 33)}[geom]
+    variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128") else 1
+    base_flags = pkg.binding.MFM_F_FORCE_MFMA_V1 if geom == "d96_t128_gen1" else 0
+    taps = pkg.synth.design_lpf(ntaps, 9000.0, fs) * (3.0 if geom in ("d96_t512", "d7_t33") else 1.0)
     offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-9, 10)]
     rng = np.random.RandomState(40 + fmt)
     sizes = [65536, 4096, 30000, 2, 8, 96, 50000, 65536, 12346, 332]
@@ -462,12 +469,13 @@ def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom)
         raw = rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
         raw[:4] = [[0, 255], [127, 128], [128, 127], [255, 0]][:min(4, m)]
         blocks.append((raw, fmt))
-    got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536)
-    assert st["kernel_variant"] == 2
+    got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536, flags=base_flags)
+    assert st["kernel_variant"] == variant
     assert st["launches_8bit"] == st["launches"] > 0
     assert got.shape == want.shape and np.array_equal(got, want)
     # the same through the widening pass: same bits, no byte launches
-    got2, _, st2 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536, flags=pkg.binding.MFM_F_WIDEN_8BIT)
+    got2, _, st2 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536,
+                                flags=base_flags | pkg.binding.MFM_F_WIDEN_8BIT)
     assert st2["launches_8bit"] == 0 and np.array_equal(got2, want)
 
 

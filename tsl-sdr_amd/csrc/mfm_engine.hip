@@ -162,7 +162,7 @@ struct mfm_engine {
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
     int32_t *d_krow8[4] = { nullptr, nullptr, nullptr, nullptr }; /* [MFM_IN_*]: row constants of the 8-bit input forms */
-    bool v_raw8 = false; /* the second-generation kernel can read 8-bit input as it is (mfm_kernel_v3.hip, IN8) */
+    bool v_raw8 = false; /* the matrix kernels can read 8-bit input as it is (IN8 forms of mfm_kernel_v3.hip, mfm_kernel_mfma.hip) */
 
     /* device tables */
     uint32_t *d_coef = nullptr, *d_tapoff = nullptr;
@@ -906,7 +906,9 @@ static int commit_locked(struct mfm_engine *e)
     }
     /* 8-bit input read as it is (mfm_kernel_v3.hip, IN8): x = alpha * s + beta with s the byte as int8, so the row
      * constant is (beta * sum(W) + 8192) / alpha - exact for all three forms.  krow = 128 * sum(W) + 8192. */
-    e->v_raw8 = e->use_v3 && (e->v_nstage4 / 2u + 511u) / 512u <= 4u && !(e->cfg.flags & MFM_F_WIDEN_8BIT);
+    /* both matrix kernels have the form for it (not built for the filtered-IQ debug output) */
+    e->v_raw8 = e->use_mfma && (!e->use_v3 || (e->v_nstage4 / 2u + 511u) / 512u <= 4u) && !e->any_iq &&
+                !(e->cfg.flags & MFM_F_WIDEN_8BIT);
     if (e->v_raw8) {
         std::vector<int32_t> k8(krow.size());
         for (int fmt = MFM_IN_CS8; fmt <= MFM_IN_RTLSDR_U8; fmt++) {
@@ -1231,6 +1233,14 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.lut = e->d_lut;
             M.pcm = slot->d_pcm;
             M.iq_dbg = L.iq_dbg;
+            if (raw8) {
+                /* the buffer holds 2-byte samples: twice as many fit; a staging chunk (4 samples) is an 8-byte load */
+                M.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
+                M.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
+                M.krow = e->d_krow8[fmt];
+                M.x_last4 = (2u * e->cap_in - 4u) & ~3u;
+                e->launches_8bit++;
+            }
             const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_per_cu);
             HIP_TRY(mfm_launch_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, e->m_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */

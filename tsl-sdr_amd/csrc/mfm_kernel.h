@@ -98,6 +98,10 @@ struct mfm_launch_mfma {
                              plane is not all zero.  Low-pass taps decay towards both ends, so for the outer k-steps the two
                              products with the high-byte plane are zero and are not computed. */
     uint32_t tail_src, tail_n; /* samples x[tail_src .. tail_src + tail_n) are the history the next block needs ... */
+    uint32_t in8;         /* 0: x is packed int16 IQ.  7 / 14: x is 8-bit IQ off the wire (2 bytes per sample), the value is
+                             the first rounding's shift and krow the matching row constants; x_last4 then is the last
+                             sample index at which an 8-byte load stays inside the buffer */
+    uint32_t in8_xor;     /* 0x80808080 when the bytes are unsigned (RTL-SDR), else 0 */
     uint32_t *tail_dst;   /* ... at the front of the other input buffer (workgroup 0 copies them) */
     const uint32_t *afrag;   /* [nrb][kq][plane hi,lo][lane][4 dwords] */
     const int32_t *krow;     /* [nrb][16]: 128 * sum_k W[row][k] + 8192 */

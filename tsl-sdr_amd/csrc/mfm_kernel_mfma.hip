@@ -78,6 +78,21 @@ static __device__ __forceinline__ void mfm_round_pack2(const uint32_t re_b[2], c
     p[1] = p1;
 }
 
+/* the same with the shift in an SGPR (8-bit input: 7 for the RTL-SDR scaling, 14 for cs8 / cu8) */
+static __device__ __forceinline__ void mfm_round_pack2_s(const uint32_t re_b[2], const uint32_t im_b[2], uint32_t sh, uint32_t p[2])
+{
+    uint32_t p0, p1;
+    asm("v_lshrrev_b32_sdwa %0, %6, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, %6, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %0, %6, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_lshrrev_b32_sdwa %1, %6, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "s_nop 0"
+        : "=&v"(p0), "=&v"(p1)
+        : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]), "s"(sh));
+    p[0] = p0;
+    p[1] = p1;
+}
+
 /*
  * o = f * r + 8192 for a packed complex f and the two packed rotator operands: two VOP3P v_dot2_i32_i16 with the
  * bias as an SGPR operand.  The builtin compiles to v_dot2c_i32_i16, which needs its accumulator preloaded by a
@@ -132,8 +147,10 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
  * KC = 1: the taps (A operand, KQ k-steps) stay in registers for the whole launch.  KC > 1 (filters of 129..512 taps):
  * KQ = 4 and the A operand is re-read from L2 in KC chunks of four k-steps in every iteration.
  * NIT = iterations (31 new outputs each) per tile: 2, or 1 when a 62-output tile does not fit LDS (large decimations).
- * AHM >= 0: L.ah_mask as a compile-time constant (no branches between the MFMAs of a k-step); -1: read at run time. */
-template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM, int NIT>
+ * AHM >= 0: L.ah_mask as a compile-time constant (no branches between the MFMAs of a k-step); -1: read at run time.
+ * IN8: the input is 8-bit IQ off the wire (two bytes per sample): one sample plane, two products per k-step, the first
+ * rounding's shift in L.in8 (mfm_kernel_v3.hip has the arithmetic).  A staging chunk stays 4 samples - an 8-byte load. */
+template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM, int NIT, bool IN8>
 __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -147,6 +164,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     const uint32_t D = L.decim, row_bytes = L.row_bytes, rs = L.rs;
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
+    const uint32_t in8_sh = (uint32_t)__builtin_amdgcn_readfirstlane(L.in8);
     /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
      * offset field of the LDS instructions instead of costing a v_add each (ds_read has no SGPR offset) */
     const uint32_t plane_dist = FIXP ? MFM_M_PLANE_DIST : L.plane_bytes;
@@ -217,6 +235,15 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         int gs = g0 < 0 ? 0 : g0;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
         /* uniform base + 32-bit byte offset: one VGPR of address instead of a 64-bit pair */
+        if (IN8) {
+            const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 1));
+            uint64_t w = (uint64_t)w2.x | ((uint64_t)w2.y << 32);
+            const int sh8 = -g0;
+            if (L.split_rows && sh8 > 0 && sh8 < 4) {
+                w <<= 16 * sh8; /* the chunk that straddles the stream start keeps its real samples in place */
+            }
+            return make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
+        }
         uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
         if (L.split_rows) {
             /* chunks start at any sample here: the one that straddles the stream start (g0 = -1 .. -3) holds real
@@ -229,7 +256,24 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         return v;
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
-        if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
+        if (IN8) {
+            if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
+                const uint32_t m = L.in8_xor; /* 0x80808080: unsigned bytes -> int8 */
+                const uint2 hi = make_uint2(v.x ^ m, v.y ^ m);
+                const uint32_t st = sta_s[j * MFM_M_NT + tid];
+                uint8_t *base = smem + buf * buf_bytes + (st & 0xffffu);
+                if (!L.split_rows) {
+                    *reinterpret_cast<uint2 *>(base) = hi;
+                } else {
+                    const uint32_t in_row = st >> 16, hop = rs - 2u * D;
+                    const uint32_t h[4] = { hi.x & 0xffffu, hi.x >> 16, hi.y & 0xffffu, hi.y >> 16 };
+#pragma unroll
+                    for (uint32_t m4 = 0; m4 < 4; m4++) {
+                        *reinterpret_cast<uint16_t *>(base + 2u * m4 + (m4 >= in_row ? hop : 0u)) = (uint16_t)h[m4];
+                    }
+                }
+            }
+        } else if (tid + (uint32_t)j * MFM_M_NT < nchunk) {
             /* dword = [lo0 hi0 lo1 hi1]: gather high / low bytes of four int16 into one dword */
             uint2 hi, lo;
             hi.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
@@ -301,7 +345,11 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
      * by a separate copy behind the kernel (one stream operation less per block) */
     if (blockIdx.x == 0) {
         for (uint32_t i = tid; i < L.tail_n; i += MFM_M_NT) {
-            L.tail_dst[i] = L.x[L.tail_src + i];
+            if (IN8) {
+                reinterpret_cast<uint16_t *>(L.tail_dst)[i] = reinterpret_cast<const uint16_t *>(L.x)[L.tail_src + i];
+            } else {
+                L.tail_dst[i] = L.x[L.tail_src + i];
+            }
         }
     }
 
@@ -424,6 +472,14 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
              * 16 gq + n */
             auto finish_group = [&](int gq, const mfm_v4i &hh, const mfm_v4i &md, const mfm_v4i &ll) {
                 uint32_t a_re[2], a_im[2], f[2], o_re[2], o_im[2];
+                if (IN8) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_re[c]) : "v"(hh[2 * c]), "v"(ll[2 * c]));
+                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_im[c]) : "v"(hh[2 * c + 1]), "v"(ll[2 * c + 1]));
+                    }
+                    mfm_round_pack2_s(a_re, a_im, in8_sh, f);
+                } else {
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     /* a + 8192 (mod 2^32); r14(a) truncated to int16 is bits 29:14 (filter/complex.h:30-34) */
@@ -431,6 +487,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     a_im[c] = mfm_combine(hh[2 * c + 1], md[2 * c + 1], ll[2 * c + 1]);
                 }
                 mfm_round_pack2(a_re, a_im, f);
+                }
                 /* filter/direct_fir.c:406-413: o = f * rot, then r14 again (bias folded into the dot2) */
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -466,6 +523,13 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                         for (int gq = 0; gq < 2; gq++) {
                             const uint32_t at = ibase + bo4[kq] + (uint32_t)gq * 16u * rs;
                             const mfm_v4i b_h = *reinterpret_cast<const mfm_v4i *>(plane_h + at);
+                            if (IN8) {
+                                if ((ah_mask >> (ck * KQ + kq)) & 1u) {
+                                    hh2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h, hh2[gq], 0, 0, 0);
+                                }
+                                ll2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], b_h, ll2[gq], 0, 0, 0);
+                                continue;
+                            }
                             const mfm_v4i b_l = *reinterpret_cast<const mfm_v4i *>(plane_l + at);
                             if ((ah_mask >> (ck * KQ + kq)) & 1u) {
                                 hh2[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], b_h, hh2[gq], 0, 0, 0);
@@ -497,13 +561,24 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     const uint32_t gbase = (it * MFM_M_NEW + 16u * (uint32_t)gq) * rs;
                     mfm_v4i bh[2], bl[2];
                     bh[0] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[0]);
-                    bl[0] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[0]);
+                    if (!IN8) {
+                        bl[0] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[0]);
+                    }
     #pragma unroll
                     for (int kq = 0; kq < KQ; kq++) {
                         const int cb = kq & 1, nb = cb ^ 1;
                         if (kq + 1 < KQ) {
                             bh[nb] = *reinterpret_cast<const mfm_v4i *>(plane_h + gbase + boff[kq + 1]);
-                            bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
+                            if (!IN8) {
+                                bl[nb] = *reinterpret_cast<const mfm_v4i *>(plane_l + gbase + boff[kq + 1]);
+                            }
+                        }
+                        if (IN8) { /* one sample plane: hh = sum Wh * s, ll = sum Wl * s + row constant */
+                            if ((ah_mask >> kq) & 1u) {
+                                hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
+                            }
+                            ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], ll, 0, 0, 0);
+                            continue;
                         }
                         if ((ah_mask >> kq) & 1u) { /* uniform: skipped where the high-byte tap plane is all zero */
                             hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh, 0, 0, 0);
@@ -653,6 +728,9 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
     if (L->ntiles == 0) {
         return hipSuccess;
     }
+    if (L->in8 && dbg_iq) {
+        return hipErrorInvalidValue;
+    }
 #define MFM_LAUNCH_N(KQ_, DBG_, FIXP_, NCH_)                                                                 \
     do {                                                                                                     \
         /* the usual case - 128-tap low-pass, only the two middle k-steps carry taps beyond one byte - and the  \
@@ -669,7 +747,9 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 #define MFM_LAUNCH_A(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_) MFM_LAUNCH_T(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, 2)
 #define MFM_LAUNCH_T(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_)                                                \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_>;                         \
+        /* 8-bit input (L->in8: the engine only asks when no channel wants its filtered IQ) */                  \
+        auto kfn = (L->in8 && !DBG_) ? mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_, !DBG_>           \
+                                     : mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_, false>;          \
         /* every launch: the attribute is per device, and engines on different devices or threads share this   \
          * code (a process-wide "already set" flag would skip the second device) */                           \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
