@@ -860,10 +860,10 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rb2, pb, qb, acc1, acc0, t);
                 f[1][0] = t[0];
                 f[1][1] = t[2];
-                mfm3_group_d96_b8<true, false, IN8, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, acc0, acc1, t);
-                f[2][0] = t[0];
-                f[2][1] = t[2];
+                /* rotator entries of this tile: requested in front of the last column group instead of behind the matrix
+                 * phase - a column group more time to arrive (the knock-out build without these loads was 8 us faster: what
+                 * they cost is their own latency).  This form has the 16 registers for it; the int16 form spills with it
+                 * and loses more than it gains (126-129 against 123 us, same box). */
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -872,6 +872,10 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                mfm3_group_d96_b8<true, false, IN8, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, acc0, acc1, t);
+                f[2][0] = t[0];
+                f[2][1] = t[2];
                 settle();
                 finish(acc1, f[3]);
 #undef MFM3_OFS
