@@ -162,8 +162,10 @@ def test_receiver_threads_are_race_free_under_tsan(tmp_path):
     assert r.returncode == 0, r.stderr
     sink = tmp_path / "pcm.out"
     sink.write_bytes(b"")
+    # (tools/sanitize_cpu.sh runs this suite with libasan preloaded; two sanitizer runtimes do not share a process)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
     r = subprocess.run([str(exe), str(sink)], capture_output=True, text=True, timeout=120,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0"))
+                       env=dict(env, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0"))
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     res = json.loads(r.stdout.strip().splitlines()[-1])
