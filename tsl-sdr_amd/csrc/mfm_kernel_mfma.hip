@@ -852,6 +852,29 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         if (L->fixed_planes) {
             return hipErrorInvalidValue; /* the streaming variants are built for packed planes only */
         }
+        if (L->in8 && !dbg_iq) {
+            /* 8-bit input: no low sample plane, no middle accumulator - the registers that frees hold all eight k-steps
+             * of taps, so nothing is streamed (the D = 25 plan of etc/pocsag_rtlsdr.json: 6 k-steps run as 8) */
+#define MFM_LAUNCH_R8(NCH_)                                                                                  \
+    do {                                                                                                     \
+        auto kfn = mfm_channel_kernel_mfma<8, false, false, NCH_, 1, -1, 2, true>;                           \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        if (e_ != hipSuccess) {                                                                              \
+            return e_;                                                                                       \
+        }                                                                                                    \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
+    } while (0)
+            if (nch <= 2) { /* more staging registers than that and the taps no longer fit beside them */
+                if (nch == 1) {
+                    MFM_LAUNCH_R8(1);
+                } else {
+                    MFM_LAUNCH_R8(2);
+                }
+                break;
+            }
+#undef MFM_LAUNCH_R8
+        }
         MFM_LAUNCH_S(2);
         break;
     case 16:
