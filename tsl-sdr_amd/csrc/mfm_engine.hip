@@ -162,7 +162,7 @@ struct mfm_engine {
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
     int32_t *d_krow8[4] = { nullptr, nullptr, nullptr, nullptr }; /* [MFM_IN_*]: row constants of the 8-bit input forms */
-    bool v_raw8 = false; /* the matrix kernels can read 8-bit input as it is (IN8 forms of mfm_kernel_v3.hip, mfm_kernel_mfma.hip) */
+    bool raw8_ok = false; /* the matrix kernels can read 8-bit input as it is (IN8 forms of mfm_kernel_v3.hip, mfm_kernel_mfma.hip) */
 
     /* device tables */
     uint32_t *d_coef = nullptr, *d_tapoff = nullptr;
@@ -907,9 +907,9 @@ static int commit_locked(struct mfm_engine *e)
     /* 8-bit input read as it is (mfm_kernel_v3.hip, IN8): x = alpha * s + beta with s the byte as int8, so the row
      * constant is (beta * sum(W) + 8192) / alpha - exact for all three forms.  krow = 128 * sum(W) + 8192. */
     /* both matrix kernels have the form for it (not built for the filtered-IQ debug output) */
-    e->v_raw8 = e->use_mfma && (!e->use_v3 || (e->v_nstage4 / 2u + 511u) / 512u <= 4u) && !e->any_iq &&
+    e->raw8_ok = e->use_mfma && (!e->use_v3 || (e->v_nstage4 / 2u + 511u) / 512u <= 4u) && !e->any_iq &&
                 !(e->cfg.flags & MFM_F_WIDEN_8BIT);
-    if (e->v_raw8) {
+    if (e->raw8_ok) {
         std::vector<int32_t> k8(krow.size());
         for (int fmt = MFM_IN_CS8; fmt <= MFM_IN_RTLSDR_U8; fmt++) {
             for (size_t i = 0; i < krow.size(); i++) {
@@ -1005,7 +1005,7 @@ int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_sample
 {
     /* not a cu8 block of odd length (file_if.c:146-150 widens its last sample differently), not behind a history of
      * another format */
-    return e && e->committed && e->v_raw8 && (format == MFM_IN_CS8 || format == MFM_IN_CU8 || format == MFM_IN_RTLSDR_U8) &&
+    return e && e->committed && e->raw8_ok && (format == MFM_IN_CS8 || format == MFM_IN_CU8 || format == MFM_IN_RTLSDR_U8) &&
            !(format == MFM_IN_CU8 && (nr_samples & 1u)) && (0 == e->tail || e->tail_fmt == format);
 }
 
