@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--proto", default="flex", choices=["flex", "pocsag"],
                     help="pocsag: etc/pocsag_rtlsdr.json geometry (1.2 MS/s, D = 25 -> 48 kS/s) -> 4/5 (81 taps) -> POCSAG stage")
     ap.add_argument("--dc-block", action="store_true", help="decoder -b: the DC blocker behind the resampler (pole 0.9999)")
+    ap.add_argument("--in8", action="store_true", help="the wideband block is RTL-SDR bytes (mfm_engine_acquire_input_bytes), "
+                    "read as they are by the matrix kernel")
     args = ap.parse_args()
     import torch
     from __graft_entry__ import load_package
@@ -51,6 +53,10 @@ def main():
     eng.commit()
     base = sy.synth_iq(1 << 22, fs, offs[:: max(1, C // 8)][:8], seed=7)
     host = np.tile(base, (-(-(in_bytes // 4) // base.shape[0]), 1))[: in_bytes // 4].reshape(-1)
+    if args.in8:
+        # the same signal as an RTL-SDR would deliver it: 8 bits around mid-scale, two bytes per sample, all over the buffers
+        u8 = np.clip((host.astype(np.int32) >> 7) + 127, 0, 255).astype(np.uint8)
+        host = np.concatenate([u8, u8])[: in_bytes].view(np.int16)
     for b in bufs:
         b.copy_(torch.from_numpy(host))
     ri, rd, rn = (4, 5, 81) if args.proto == "pocsag" else (16, 25, args.resampler_taps)
@@ -63,7 +69,10 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.iters)]
 
     def step(marks):
-        eng.acquire_input()
+        if args.in8:
+            eng.acquire_input_bytes(pkg.binding.MFM_IN_RTLSDR_U8)
+        else:
+            eng.acquire_input()
         if marks:
             marks[0].record(st)
         eng.submit(block, producer_stream=0, wait_producer=False)
@@ -92,7 +101,8 @@ def main():
     stage = np.diff(np.concatenate([np.zeros((args.iters, 1)), t], 1), axis=1)
     med = np.median(stage, 0)
     total = float(np.median(t[:, 2]))
-    print(json.dumps({"chain": "IQ (HBM) -> engine (D %d, %d taps) -> resampler %d/%d (%d taps) -> %s stage" % (decim, len(taps), ri, rd, rn, args.proto.upper()),
+    print(json.dumps({"input": "rtl-sdr u8 bytes" if args.in8 else "int16", "launches_8bit": eng.stats()["launches_8bit"],
+                      "chain": "IQ (HBM) -> engine (D %d, %d taps) -> resampler %d/%d (%d taps) -> %s stage" % (decim, len(taps), ri, rd, rn, args.proto.upper()),
                       "channels": C, "block_samples": block, "pcm_in_per_channel": int(nout), "pcm_out_per_channel": int(ny),
                       "ms_engine": round(float(med[0]), 4), "ms_resampler": round(float(med[1]), 4), "ms_pager": round(float(med[2]), 4),
                       "ms_per_block": round(total, 4), "msamp_per_s_x_channels": round(block * C / total / 1e3, 1),
