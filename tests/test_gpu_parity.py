@@ -444,7 +444,7 @@ def _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, max_block, flags=0):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt", [1, 2, 3])
 @pytest.mark.parametrize("geom", ["d96_t128", "d32_t32", "d64_t64", "d128_t128", "d96_t128_gen1", "d25_t128", "d40_t64",
-                                  "d96_t512", "d400_t512", "d7_t33"])
+                                  "d96_t512", "d400_t512", "d7_t33", "d25_t170", "d30_t150", "d24_t140"])
 def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom):
     """Where the second-generation matrix kernel runs, an 8-bit block stays bytes in HBM and the kernel's GEMM takes
     the one sample plane as it is (mfm_kernel_v3.hip, IN8): the PCM must equal the oracle run on the reference's
@@ -455,7 +455,9 @@ def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom)
     # rows), streamed filters, single-iteration tiles, a tiny decimation
     decim, ntaps = {"d96_t128": (96, 128), "d32_t32": (32, 32), "d64_t64": (64, 64), "d128_t128": (128, 128),
                     "d96_t128_gen1": (96, 128), "d25_t128": (25, 128), "d40_t64": (40, 64), "d96_t512": (96, 512),
-                    "d400_t512": (400, 512), "d7_t33": (7, 33)}[geom]
+                    "d400_t512": (400, 512), "d7_t33": (7, 33),
+                    # 7 / 5 / 5 k-steps of taps held in registers (one and two staging chunks per thread)
+                    "d25_t170": (25, 170), "d30_t150": (30, 150), "d24_t140": (24, 140)}[geom]
     variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128") else 1
     base_flags = pkg.binding.MFM_F_FORCE_MFMA_V1 if geom == "d96_t128_gen1" else 0
     taps = pkg.synth.design_lpf(ntaps, 9000.0, fs) * (3.0 if geom in ("d96_t512", "d7_t33") else 1.0)

@@ -155,6 +155,7 @@ struct mfm_engine {
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
     bool m_fixed_planes = false;
     uint32_t m_ah_mask = 0; /* k-steps whose high-byte tap plane is not all zero */
+    uint32_t m_kq_used = 0; /* k-steps that hold taps at all */
     /* second-generation matrix kernel (mfm_kernel_v3.hip): same tap fragments, its own LDS image */
     bool use_v3 = false;
     uint32_t v_rs = 0, v_sp_pitch = 0, v_nstage4 = 0, v_lds_bytes = 0, v_wg_per_cu = 1, v_cross[4] = { 0, 0, 0, 0 },
@@ -681,6 +682,7 @@ static int commit_locked(struct mfm_engine *e)
         while (64u * kq < k_elems) {
             kq *= 2;
         }
+        e->m_kq_used = (k_elems + 63u) / 64u;
         const uint32_t row_bytes = row_bytes_p;
         const bool padded = row_bytes_p != 2u * D;
         /* LDS row stride: an ODD multiple of 32 bytes.  tools/ubench_lds.hip: the B-fragment read pattern (lane
@@ -1202,6 +1204,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.decim = D;
             M.x_last4 = (e->cap_in - 4u) & ~3u;
             M.kq = e->m_ks;
+            M.kq_used = e->m_kq_used;
             M.ot = e->m_ot;
             M.nstage = e->m_nstage;
             M.rs = e->m_rs;

@@ -75,6 +75,7 @@ struct mfm_launch_mfma {
     uint32_t n_avail, n_new, decim;
     uint32_t x_last4;     /* last sample index at which a 16-byte load stays inside the input buffer (multiple of 4) */
     uint32_t kq;          /* k-steps of 64 elements: padded taps = 32 * kq */
+    uint32_t kq_used;     /* k-steps that hold taps at all: ceil(elements / 64) <= kq (kq is rounded up to a power of two) */
     uint32_t ot;          /* NEW outputs per workgroup tile: 31 per iteration of 32 columns, two iterations (62) or, for
                              decimations whose 62-output tile does not fit LDS, one (31) */
     uint32_t nstage;      /* samples staged per tile: ot*D + 32*kq, rounded up to 4 */

@@ -408,7 +408,9 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
         if (slice != slice_loaded) {
             /* A operand: 16 rows x (64*KQ) elements, both byte planes, already in fragment order */
             if (KC == 1) {
-                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rbc * KQ * 2 * 64 + mfm_opaque(lane);
+                /* L.kq k-steps are laid out per row block; this instance multiplies the first KQ of them (the rest, if
+                 * any, is the zero padding a filter is rounded up by) */
+                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rbc * L.kq * 2 * 64 + mfm_opaque(lane);
 #pragma unroll
                 for (int kq = 0; kq < KQ; kq++) {
                     a_h[kq] = ap[(kq * 2 + 0) * 64];
@@ -852,6 +854,44 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         if (L->fixed_planes) {
             return hipErrorInvalidValue; /* the streaming variants are built for packed planes only */
         }
+#define MFM_LAUNCH_X(KQ_, NCH_, IN8_)                                                                        \
+    do {                                                                                                     \
+        auto kfn = mfm_channel_kernel_mfma<KQ_, false, false, NCH_, 1, -1, 2, IN8_>;                         \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        if (e_ != hipSuccess) {                                                                              \
+            return e_;                                                                                       \
+        }                                                                                                    \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
+    } while (0)
+        /* Five to seven k-steps of taps (the D = 25 plan of etc/pocsag_rtlsdr.json: 326 elements = 6) fit the registers
+         * beside one or two staging chunks: nothing is streamed, nothing is multiplied with the padding up to the eighth.
+         * The int16 form has the registers for six of them and one chunk. */
+        if (!dbg_iq && L->in8 && nch <= 2 && L->kq_used >= 5u && L->kq_used <= 7u) {
+            if (nch == 1) {
+                switch (L->kq_used) {
+                case 5: MFM_LAUNCH_X(5, 1, true); break;
+                case 6: MFM_LAUNCH_X(6, 1, true); break;
+                default: MFM_LAUNCH_X(7, 1, true); break;
+                }
+            } else {
+                switch (L->kq_used) {
+                case 5: MFM_LAUNCH_X(5, 2, true); break;
+                case 6: MFM_LAUNCH_X(6, 2, true); break;
+                default: MFM_LAUNCH_X(7, 2, true); break;
+                }
+            }
+            break;
+        }
+        if (!dbg_iq && !L->in8 && nch == 1 && (L->kq_used == 5u || L->kq_used == 6u)) {
+            if (L->kq_used == 5u) {
+                MFM_LAUNCH_X(5, 1, false);
+            } else {
+                MFM_LAUNCH_X(6, 1, false);
+            }
+            break;
+        }
+#undef MFM_LAUNCH_X
         if (L->in8 && !dbg_iq) {
             /* 8-bit input: no low sample plane, no middle accumulator - the registers that frees hold all eight k-steps
              * of taps, so nothing is streamed (the D = 25 plan of etc/pocsag_rtlsdr.json: 6 k-steps run as 8) */
