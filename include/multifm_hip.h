@@ -150,8 +150,10 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples);
 
 /*
  * Host ingest of 8-bit captures: the byte pairs are staged as they are (half the
- * PCIe bytes of mfm_engine_push) and widened to int16 on the device exactly as the reference's front ends do on
- * the host.  nr_samples IQ pairs = 2 * nr_samples bytes.
+ * PCIe bytes of mfm_engine_push).  Where a matrix-core kernel runs and no channel asked for its filtered IQ they stay
+ * bytes in HBM and the kernel's GEMM takes them as its one sample plane (same bits as the widened path); otherwise - and
+ * for a cu8 block of odd length, or behind a history of another format - they are widened to int16 on the device exactly
+ * as the reference's front ends do on the host.  nr_samples IQ pairs = 2 * nr_samples bytes.
  */
 #define MFM_IN_CS16 0       /* interleaved int16, same as mfm_engine_push (multifm/file_if.c:46-64) */
 #define MFM_IN_CS8 1        /* signed bytes, sign-extended (multifm/file_if.c:66-111) */

@@ -4,7 +4,8 @@
  *
  * The reference fans every delivered sample_buf out to all of its channel threads (multifm/receiver.c:78-98): the
  * channels are independent given the same wideband input.  Here the channel set is cut into contiguous shards, one
- * mfm_engine per device; a delivered block is staged on the first device (H2D, 8-bit formats widened there) and
+ * mfm_engine per device; a delivered block is staged on the first device (H2D; an 8-bit block stays bytes when every
+ * member's kernel can read it so, and is widened there otherwise) and
  * broadcast with RCCL - ncclBroadcast over xGMI, in place into every other engine's input buffer - and then every
  * engine submits it.  No other exchange: each device copies its own PCM back, the caller demultiplexes by shard
  * (SURVEY.md section 8e).  One process, one host thread drives all devices (ncclCommInitAll + ncclGroupStart/End).
