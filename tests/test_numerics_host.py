@@ -87,3 +87,38 @@ def test_discriminator_matches_oracle_edges(pkg, ora):
     sre, sim = np.meshgrid(g, g)
     a, b = _disc_both(pkg, ora, sre.reshape(-1), sim.reshape(-1))
     assert np.array_equal(a, b)
+
+
+def test_byte_plane_sums_of_8bit_input_equal_the_widened_sums(ora):
+    """The arithmetic the IN8 kernel forms rest on (mfm_kernel_v3.hip), in numpy: with the taps split
+    as the engine splits them (W = 256 Wh + Wl, both int8) and the byte taken as int8 s (after ^ 0x80 for the RTL-SDR),
+    bits [sh + 15 : sh] of (sum Wh s << 8) + sum Wl s + K are the first rounding of the reference's wrapping int32 sum over
+    the WIDENED samples (filter/complex.h:30-34 on rtl_sdr_if.c:146-148 / file_if.c:66-157), for K = (beta sum W + 8192) /
+    alpha and sh = 14 - log2 alpha.  Full-range taps and bytes, sums that wrap."""
+    rng = np.random.RandomState(12)
+    for fmt, xor, alpha, beta, sh in ((1, 0, 1, 0, 14), (2, 0, 1, -127, 14), (3, 0x80, 128, 128, 7)):
+        for trial in range(200):
+            k = int(rng.choice([4, 64, 256, 1024]))  # an even number of IQ pairs: no cu8 odd-tail quirk (file_if.c:146-150)
+            lim = int(rng.choice([120, 3000, 32639]))
+            w = rng.randint(-lim, lim + 1, size=k).astype(np.int64)
+            raw = rng.randint(0, 256, size=k).astype(np.uint8)
+            if trial == 0:
+                w[:] = 32639
+                raw[:] = 255
+            if trial == 1:
+                w[:] = -32639
+                raw[:] = 128 if fmt != 3 else 0
+            x = ora.unpack_bytes(raw, fmt).astype(np.int64)          # the reference's widening, sample by sample
+            assert x.size == k
+            ref = int((w * x).sum()) & 0xFFFFFFFF                    # wrapping int32 sum (filter/direct_fir.c)
+            want = ((ref + 8192) & 0xFFFFFFFF) >> 14 & 0xFFFF       # round_q30_q15 + int16 truncation
+            wl = ((w & 0xFF) ^ 0x80) - 0x80                          # (int8)(w & 0xff)
+            wh = (w - wl) >> 8
+            assert np.all(np.abs(wh) <= 128) and np.all(w == 256 * wh + wl)
+            s = ((raw.astype(np.int64) ^ xor) ^ 0x80) - 0x80         # the byte as int8
+            assert np.array_equal(alpha * s + beta, x)
+            sw = int(w.sum())
+            kk = {1: 8192, 2: 8192 - 127 * sw, 3: sw + 64}[fmt]
+            assert kk * alpha == beta * sw + 8192
+            t = ((int((wh * s).sum()) << 8) + int((wl * s).sum()) + kk) & 0xFFFFFFFF
+            assert (t >> sh) & 0xFFFF == want, (fmt, trial)
