@@ -571,11 +571,14 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     }
     __syncthreads();
 
-    /* The second half of a workgroup loses the arbitration for the SIMD to the first (older) half on every phase and
-     * reaches each barrier ~1300 cycles later (s_memtime stamps, profiles/r02_v3_phases.txt): static priority for it. */
-    if (wave >= 4) {
-        __builtin_amdgcn_s_setprio(1);
-    }
+    /* Wave priorities.  (1) The second half of a workgroup loses the arbitration for the SIMD to the first (older) half on
+     * every phase and reaches each barrier ~1300 cycles later (s_memtime stamps, profiles/r02_v3_phases.txt): priority 1
+     * instead of 0 for it in the matrix phase.  (2) A wave in its epilogue goes ahead of waves in their matrix phase
+     * (priority 2): the epilogue is a stream of VALU instructions that needs every issue slot it can get, the matrix phase
+     * issues one MFMA every 32 cycles and hides what it has in between in the MFMA's shadow - it loses little by standing
+     * back, the epilogue's wave (and with it the workgroup's next barrier) gains.  Worth 3-4 % at 64 channels, 5 % at 1024
+     * (same-box A/B against the static form, profiles/r02_bench_table.txt's run). */
+    const int prio_matrix = wave >= 4 ? 1 : 0;
     mfm_v4i a_h[KQ], a_l[KQ];
     /* 128 * sum(W) + 8192 of the wave's 16 rows: 64 bytes of LDS per wave (read back as the initial value of the low
      * accumulator of every column group; four registers that need not be live through the epilogue) */
@@ -636,6 +639,11 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
         }
 
+        if (prio_matrix) {
+            __builtin_amdgcn_s_setprio(1);
+        } else {
+            __builtin_amdgcn_s_setprio(0);
+        }
         const uint32_t rb = slice * 8u + wave;
         const bool rb_valid = rb < L.nrb; /* wave uniform */
         const uint32_t lb = lb0 + cur * buf_pitch;
@@ -914,6 +922,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             stage_store(cur ^ 1u, j, pre[j]);
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(2); /* epilogue */
         if (EARLY) {
             uint32_t a_item = n_item, a_chunk = n_chunk, a_slice = n_slice, a_tile = n_tile, a_tend = n_tend;
             bool a_first = false;
