@@ -465,6 +465,8 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 
 #pragma unroll
         for (uint32_t it = 0; it < NIT; it++) {
+            /* a wave in its epilogue goes ahead of waves in their matrix phase (mfm_kernel_v3.hip has the reasoning) */
+            __builtin_amdgcn_s_setprio(0);
             uint32_t q[2][2];
             /* The two 16-column groups of an iteration one after the other: three accumulators (hh, md, ll) and one
              * pair of B fragments are live at a time instead of six and four - the registers that buys go into the
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 }
             }
 
+            __builtin_amdgcn_s_setprio(2);
             int pcm[2][2];
             if (it == 0) {
                 /* column 0 of the pass is the last filtered sample of the previous pass */
