@@ -588,3 +588,45 @@ def test_gpu_8bit_bytes_on_the_reference_geometry(pkg, ora, fmt):
     want, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
     got = np.concatenate(got, axis=1)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [2, 3])
+def test_full_size_8bit_blocks_bytes_equal_widened(pkg, fmt):
+    """BASELINE full size (64 channels, 2^24-sample blocks) fed with 8-bit IQ: the kernel instance that reads the bytes
+    (compile-time geometry, hand-scheduled column groups) against the widening pass + int16 kernel on the same stream -
+    two independent routes through the engine that must agree sample for sample (each is checked against the oracle at
+    small sizes above), and re-blocking the stream must not change the PCM either."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch")
+    rng = np.random.RandomState(90 + fmt)
+    n = (1 << 24) + 4322
+    raw = rng.randint(0, 256, size=(n, 2)).astype(np.uint8)
+
+    def run(flags, block):
+        eng = pkg.Engine(fs, decim, block, device=0, flags=flags)
+        for o, g in zip(offs, gains):
+            eng.add_channel(int(o), taps, float(g))
+        eng.commit()
+        out, pos = [], 0
+        while pos < n:
+            m = min(block, n - pos)
+            m -= (m & 1) if fmt == 2 and pos + m < n else 0
+            while eng.push_bytes(raw[pos:pos + m], fmt) != 0:
+                out.append(eng.fetch()[1])
+            pos += m
+        eng.sync()
+        while True:
+            b = eng.fetch()
+            if b is None:
+                break
+            out.append(b[1])
+        st = eng.stats()
+        eng.close()
+        return np.concatenate(out, axis=1), st
+
+    a, sa = run(0, 1 << 24)
+    b, sb = run(pkg.binding.MFM_F_WIDEN_8BIT, 1 << 24)
+    c, sc = run(0, (1 << 20) - 78)
+    assert sa["launches_8bit"] == sa["launches"] and sb["launches_8bit"] == 0 and sc["launches_8bit"] == sc["launches"]
+    assert a.shape == b.shape == c.shape and a.shape[1] == (n - len(taps)) // decim + 1
+    assert np.array_equal(a, b) and np.array_equal(a, c)
