@@ -94,6 +94,51 @@ def _native_oracle(ora):
     return run, "oracle/*.c rebuilt here with gcc -O2 -march=native (the reference's flags, CMakeLists.txt:77)"
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def verify_last_block(pkg, eng, fs, decim, taps, offs, gains, buf, tail, block, outputs_before):
+    """Self-check of the measured shape (VERDICT r02 'Next round' 2b): the PCM the LAST timed launch left in HBM against the
+    oracle, for four channels spread over the rows x three windows of 1024 outputs (start, middle, end of the block).
+    The oracle is the checker here, never the thing measured: this runs after the timed region.  `buf` = the torch tensor
+    the last launch read ([history tail | block], int16 pairs), `outputs_before` = outputs per channel the stream had
+    produced before that launch (the rotator of output n has been stepped n times, filter/direct_fir.c:166-167)."""
+    import ctypes as C
+    from __graft_entry__ import load_oracle
+    ora = load_oracle()
+    dptr, stride, nout, _ = eng.last_output_device()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    T = len(taps)
+    n_avail = tail + block
+    assert nout == (n_avail - T) // decim + 1, (nout, n_avail)
+    host_in = buf[: 2 * n_avail].cpu().numpy().reshape(-1, 2)
+    chans = sorted(set(int(round(k * (len(offs) - 1) / 3)) for k in range(4)))
+    wins = sorted(set([1, max(1, nout // 2 - 512), max(1, nout - 1024)]))
+    bad, checked = 0, 0
+    for c in chans:
+        row = np.empty(nout, np.int16)
+        rc = hip.hipMemcpy(row.ctypes.data, C.c_void_p(dptr + 2 * stride * c), 2 * nout, 2)
+        if rc != 0:
+            raise SystemExit(f"hipMemcpy of the PCM row failed: {rc}")
+        cre, cim, incr = eng.get_channel(c)
+        for w0 in wins:
+            cnt = min(1024, nout - w0)
+            want = ora.window_pcm(host_in, cre, cim, decim, incr, outputs_before, w0, cnt)
+            bad += int((row[w0: w0 + cnt] != want).sum())
+            checked += cnt
+    return {"verified": bad == 0, "mismatches": bad, "outputs_checked": checked, "channels": chans, "windows": wins,
+            "outputs_before_block": int(outputs_before),
+            "how": "last timed launch's PCM in HBM vs oracle/mfm_oracle.c on the same input window, bit-exact"}
+
+
 def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
     """The oracle (a port of the reference's per-channel loop) on the host cores, thread-per-channel
     like multifm/receiver.c:89-95, on a bounded sample of the same workload."""
@@ -130,6 +175,7 @@ def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
         if dt >= target_s:
             break
     return {"value": passes * n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
+            "host_cores": cores, "host_cpu": _cpu_model(),
             "msamp_per_s_one_channel_one_core": one_core,
             "sample": f"{passes} passes over {n} IQ samples x {nch} channels, {how}, {threads} threads "
                       f"thread-per-channel, {dt:.1f} s"}
@@ -282,7 +328,9 @@ def main():
     in_bytes = lib.mfm_engine_input_bytes(block, T)
     bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
     eng = pkg.Engine(fs, decim, block, device=local_rank,
+                     # one launch in four carries the event pair (runs too short to hold a few samples time every launch)
                      flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
+                     (pkg.binding.MFM_F_TIMING_SPARSE if args.steps >= 16 else 0) |
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
                      (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
@@ -303,11 +351,14 @@ def main():
     # form (tsl-sdr_amd/dist.py) - written for point-to-point xGMI, gloo-tested, not yet run on a multi-GPU node
     exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "broadcast")) if use_dist else None
 
+    last = {"which": 0, "tail": 0}
+
     def step():
         ptr, cap = eng.acquire_input()
+        which = 0 if ptr < bufs[0].data_ptr() + in_bytes and ptr >= bufs[0].data_ptr() else 1
+        off = (ptr - bufs[which].data_ptr()) // 2
+        last["which"], last["tail"] = which, off // 2
         if use_dist:
-            which = 0 if ptr < bufs[0].data_ptr() + in_bytes and ptr >= bufs[0].data_ptr() else 1
-            off = (ptr - bufs[which].data_ptr()) // 2
             view = bufs[which][off: off + 2 * block]
             if exchange.algo == "auto":
                 exchange.choose(view, sync=torch.cuda.synchronize)
@@ -340,6 +391,10 @@ def main():
         for _ in range(settle_steps):
             step()
         fence()
+    # a fresh stream from here (history, rotators, discriminator state): the self-check behind the timed region steps the
+    # oracle's rotators to the last block's first output, and that distance should be the run's warm-up + timed launches,
+    # not the settle phase's thousands.  Same kernel, same launch geometry, nothing inside the timed region changes.
+    eng.reset()
     for _ in range(args.warmup):
         step()
     fence()
@@ -354,8 +409,9 @@ def main():
         dt = pkg.dist.max_over_ranks(dt, device="cuda")
 
     launches = st1["launches"] - st0["launches"]
-    k_ms = (st1["kernel_ms"] - st0["kernel_ms"]) / max(1, launches)
-    per_launch = np.sort(eng.launch_ms(min(int(launches), 4096)).astype(np.float64))
+    timed = st1["timed_launches"] - st0["timed_launches"]  # MFM_F_TIMING_SPARSE: one launch in four carries the event pair
+    k_ms = (st1["kernel_ms"] - st0["kernel_ms"]) / max(1, timed)
+    per_launch = np.sort(eng.launch_ms(min(int(timed), 4096)).astype(np.float64))
     outs = (st1["outputs"] - st0["outputs"]) / max(1, launches)
     bytes_per_launch = block * 4 + len(offs) * outs * 2        # 4 + 2*C_g/D bytes per input sample
     dot2_per_launch = 2.0 * len(offs) * T * outs               # two v_dot2 lane-ops per complex tap per output
@@ -363,10 +419,16 @@ def main():
     mfma = st1["kernel_variant"] >= 1
     kname = {0: "mfm_channel_kernel", 1: "mfm_channel_kernel_mfma", 2: "mfm_channel_kernel_v3"}[st1["kernel_variant"]]
     if mfma:
-        # exact int16 MACs done as four int8 products on the matrix cores: 2 ops x 4 x (4 real MACs per complex tap)
+        # exact int16 MACs done as four int8 byte-plane products on the matrix cores: 2 ops x 4 planes x (4 real MACs per
+        # complex tap).  That is the four-plane figure; the kernel does not issue the two products of a k-step whose
+        # high-byte tap plane is all zero (mfm_stats.tap_hi_mask), so the matrix pipe's real load is `frac_issued`.
         ops = 2.0 * 4.0 * 4.0 * len(offs) * T * outs
+        ks, hi = max(1, st1["k_steps"]), bin(st1["tap_hi_mask"]).count("1")
+        issued_share = (2.0 * ks + 2.0 * hi) / (4.0 * ks)
         compute_roof = {"bound": "mfma_i8", "achieved": ops / (k_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS,
-                        "unit": "TOP/s", "frac": ops / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}
+                        "unit": "TOP/s", "frac": ops / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                        "mfma_per_k_step_issued": 2 + 2.0 * hi / ks, "mfma_per_k_step_four_planes": 4,
+                        "frac_issued": ops * issued_share / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS}
     else:
         compute_roof = {"bound": "v_dot2_i32_i16", "achieved": dot2_per_launch / (k_ms * 1e-3) / 1e12,
                         "peak": VALU_DOT2_PEAK / 1e12, "unit": "T lane-ops/s",
@@ -376,11 +438,20 @@ def main():
     # HBM bytes per launch from the committed PMC passes (profiles/, tools/prof_r02.sh: FETCH_SIZE and WRITE_SIZE each in
     # its own rocprofv3 --pmc run, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): only quoted for the
     # exact workload and kernel they were collected on
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and args.config == "cfg2_64ch" \
-            and os.path.exists(tpath):
-        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+    traffic, traffic_source = None, None
+    for rnd in ("r03", "r02"):
+        tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
+        if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and \
+                args.config == "cfg2_64ch" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            traffic_source = f"profiles/{rnd}_hbm_traffic.json (rocprofv3 --pmc passes of this command, not this run)"
+            break
+
+    verified = None
+    if rank == 0:
+        n_last = eng.last_output_device()[2]
+        verified = verify_last_block(pkg, eng, fs, decim, taps, offs, gains, bufs[last["which"]], last["tail"], block,
+                                     st1["outputs"] - n_last)
 
     if rank == 0:
         line = {
@@ -398,7 +469,8 @@ def main():
                        "parallelism": "1 GPU" if not use_dist else
                                       f"channel shards x{world} + RCCL {exchange.algo} of the IQ block"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "timed_launches": int(timed), "launches": int(launches),
                          "kernel": kname, "kernel_ms": k_ms,
                          "kernel_ms_min": float(per_launch[0]) if len(per_launch) else None,
                          "kernel_ms_median": float(np.median(per_launch)) if len(per_launch) else None,
@@ -406,6 +478,8 @@ def main():
                          "bytes_per_launch": bytes_per_launch,
                          # what holds the kernel below the HBM roof (SQ counters in profiles/)
                          "binding": "simd_issue" if mfma else "valu_dot2"},
+            "verified": verified["verified"], "verification": verified,
+            "rotators": {"exact_channels": st1["rot_exact_channels"], "channels": len(offs)},
             "protocol": {"settle_seconds": args.settle_seconds, "settle_steps": settle_steps + 8,
                          "warmup_steps": args.warmup, "timed_steps": args.steps},
             "compute_roofline": compute_roof,
@@ -414,6 +488,9 @@ def main():
             # 2.4 MS/s stream is 10 MB/s).  xGMI: 7 links x ~153 GB/s per GPU, point to point.
             "exchange": None if not use_dist else {
                 "algo": exchange.algo, "bytes_per_step_per_peer": block * 4, "peers": world - 1,
+                # what every peer would have to receive for the exchange to hide behind the kernel (a step then costs
+                # max(exchange, kernel)): one block per kernel time
+                "needed_GBps_per_peer": block * 4 / (k_ms * 1e-3) / 1e9,
                 "delivered_GBps_per_peer": block * 4 / (dt / args.steps) / 1e9,
                 "delivered_GBps_total": block * 4 * (world - 1) / (dt / args.steps) / 1e9,
                 "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7},
@@ -444,6 +521,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+        if not line["verified"]:
+            raise SystemExit(f"bench.py: the timed kernel's output differs from the oracle: {line['verification']}")
 
 
 if __name__ == "__main__":

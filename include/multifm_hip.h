@@ -53,7 +53,8 @@ extern "C" {
 #define MFM_E_STATE (-5)  /* call not valid in this state (e.g. add_channel after commit) */
 #define MFM_E_DONE (-6)   /* nothing to fetch (A_E_DONE analogue) */
 
-#define MFM_ABI_VERSION 2 /* 2: mfm_resampler_config grew flags + reserved; mfm_flex_*, mfm_group_* added */
+#define MFM_ABI_VERSION 3 /* 2: mfm_resampler_config grew flags + reserved; mfm_flex_*, mfm_group_* added
+                             3: mfm_stats grew timed_launches, rot_class_*; MFM_F_TIMING_SPARSE; mfm_group_config.exchange */
 
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
@@ -63,6 +64,9 @@ extern "C" {
 #define MFM_F_FORCE_MFMA_V1 0x8u /* where both matrix-core kernels apply, run the first-generation one (31-output column
                                   blocks, 2-byte PCM stores) instead of the second (64-output tiles, 8-byte stores) */
 
+#define MFM_F_TIMING_SPARSE 0x20u /* with MFM_F_TIMING: bracket one launch in four only (a back-to-back stream then runs
+                                     without an event pair between most kernels; mfm_stats.timed_launches says how many
+                                     durations kernel_ms sums) */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 
@@ -93,7 +97,7 @@ struct mfm_stats {
     uint64_t samples_in;       /* wideband samples accepted */
     uint64_t outputs;          /* outputs produced per channel */
     uint64_t launches;         /* kernel launches */
-    double kernel_ms;          /* sum of launch durations (MFM_F_TIMING), HIP events */
+    double kernel_ms;          /* sum of the durations of `timed_launches` launches (MFM_F_TIMING), HIP events */
     uint32_t nr_channels;
     uint32_t nr_taps;
     uint32_t outputs_per_tile; /* kernel geometry, informational */
@@ -104,6 +108,15 @@ struct mfm_stats {
     uint32_t kernel_variant;   /* 0 = v_dot2 kernel, 1 = int8-MFMA (FIR-as-GEMM) kernel, 2 = its second generation */
     uint32_t pending_blocks;   /* finished or in-flight blocks not yet fetched + released */
     uint64_t launches_8bit;    /* of `launches`: those that read an 8-bit block as bytes (mfm_engine_push_bytes) */
+    uint64_t timed_launches;   /* launches whose duration is in kernel_ms: all of them with MFM_F_TIMING, one in four
+                                  with MFM_F_TIMING_SPARSE as well */
+    uint32_t rot_exact_channels; /* channels whose rotator (filter/direct_fir.c:151-172) is exactly +-(16384, 0) for ever:
+                                    offsets at multiples of half the output rate; their derotation is the identity or a
+                                    sign flip */
+    uint32_t rot_fast_slices;  /* 64-channel slices of the second-generation kernel made of such channels only */
+    uint32_t k_steps;          /* matrix kernels: k-steps of 64 int16 elements (32 complex taps) per output, padded */
+    uint32_t tap_hi_mask;      /* matrix kernels: bit k set = k-step k has taps beyond one byte, so its two products with
+                                  the high-byte tap plane are issued (4 matrix instructions for that k-step, else 2) */
 };
 
 /* Size in bytes of one input staging buffer for this configuration and tap count. */

@@ -240,6 +240,23 @@ void mfmo_chan_rot(const struct mfmo_chan *ch, int16_t *rot_re, int16_t *rot_im)
     *rot_im = ch->rot_im;
 }
 
+/* Window checks (bench.py's `verified`, the full-size GPU tests): put a fresh channel where a stream stands after
+ * nr_outputs outputs as far as the rotator is concerned - filter/direct_fir.c:166-167 applied nr_outputs times, which is
+ * all the state direct_fir carries besides the samples themselves.  The discriminator's last sample (fm_demod.c:16-17)
+ * stays zero: callers feed the window one output early and drop that output's PCM. */
+void mfmo_chan_skip_outputs(struct mfmo_chan *ch, uint64_t nr_outputs)
+{
+    if (!ch->derotate) {
+        return;
+    }
+    int16_t re = ch->rot_re, im = ch->rot_im;
+    for (uint64_t i = 0; i < nr_outputs; i++) {
+        mfmo_rot_step(&re, &im, ch->incr_re, ch->incr_im);
+    }
+    ch->rot_re = re;
+    ch->rot_im = im;
+}
+
 /* One output from a window of nr_taps samples starting at w (interleaved IQ). */
 static inline void chan_one_output(struct mfmo_chan *ch, const int16_t *w, int16_t *q_re, int16_t *q_im,
                                    int16_t *pcm)

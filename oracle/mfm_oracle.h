@@ -94,6 +94,11 @@ void mfmo_chan_free(struct mfmo_chan *ch);
 size_t mfmo_chan_feed(struct mfmo_chan *ch, const int16_t *iq, size_t nr_samples, int16_t *pcm_out,
                       int16_t *iq_out, size_t max_out);
 
+/* Advance a channel's rotator as if nr_outputs outputs had been produced (filter/direct_fir.c:166-167 that many times):
+ * lets a test check a window in the middle of a long stream.  Feed the window one output early and drop that output's PCM
+ * (the discriminator's previous sample is not reconstructed). */
+void mfmo_chan_skip_outputs(struct mfmo_chan *ch, uint64_t nr_outputs);
+
 /* Rotator state after the outputs produced so far (direct_fir.h:52-64). */
 void mfmo_chan_rot(const struct mfmo_chan *ch, int16_t *rot_re, int16_t *rot_im);
 

@@ -51,6 +51,8 @@ def lib():
         o.mfmo_chan_free.restype = None
         o.mfmo_chan_feed.argtypes = [C.c_void_p, _i16p, C.c_size_t, _i16p, _i16p, C.c_size_t]
         o.mfmo_chan_feed.restype = C.c_size_t
+        o.mfmo_chan_skip_outputs.argtypes = [C.c_void_p, C.c_uint64]
+        o.mfmo_chan_skip_outputs.restype = None
         o.mfmo_chan_rot.argtypes = [C.c_void_p, _i16p, _i16p]
         o.mfmo_chan_rot.restype = None
         o.mfmo_run_channels.argtypes = [_i16p, C.c_size_t, C.c_size_t, _i16p, _i16p, C.c_size_t, C.c_uint, _i16p,
@@ -190,6 +192,10 @@ class Channel:
         q = np.zeros((cap, 2), np.int16)
         n = lib().mfmo_chan_feed(self.h, p16(iq), iq.shape[0], p16(pcm), p16(q), cap)
         return pcm[:n], q[:n]
+
+    def skip_outputs(self, n):
+        """advance the rotator as if n outputs had been produced (window checks in the middle of a long stream)"""
+        lib().mfmo_chan_skip_outputs(self.h, int(n))
 
     def rot(self):
         a = np.zeros(2, np.int16)
@@ -495,3 +501,19 @@ class MuellerMuller:
         ptr = C.cast(a.ctypes.data + 2 * offset, C.POINTER(C.c_int16))
         n = lib().mfmo_mm_process(self.st, ptr, nr_samples, p16(dec), cap)
         return dec[:n].copy()
+
+
+def window_pcm(iq, cre, cim, decimation, incr, first_sample_is_output, w0, count):
+    """PCM of outputs [w0, w0 + count) of one channel, w0 >= 1, computed from the samples of that window alone.  `iq` holds
+    stream samples starting at the first sample of output `first_sample_is_output` (a global output index); w0 counts from
+    there.  The rotator is stepped to output first_sample_is_output + w0 - 1, that output is computed for its filtered
+    sample only (its PCM needs the sample before it) and dropped."""
+    T = np.asarray(cre).size
+    ch = Channel(cre, cim, decimation, incr)
+    ch.skip_outputs(first_sample_is_output + w0 - 1)
+    lo = (w0 - 1) * decimation
+    hi = (w0 - 1 + count) * decimation + T
+    pcm, _ = ch.feed(iq[lo:hi])
+    ch.close()
+    assert pcm.size == count + 1, (pcm.size, count)
+    return pcm[1:]

@@ -353,6 +353,77 @@ def test_full_size_block_properties(pkg, ora, kernel):
     assert np.array_equal(big, small)
 
 
+def _tiled_iq(pkg, n, fs, carriers, seed):
+    """n samples made of a 2^22-sample synthetic base repeated (what bench.py feeds the engine)"""
+    base = pkg.synth.synth_iq(1 << 22, fs, carriers, seed=seed)
+    return np.tile(base, (-(-n // base.shape[0]), 1))[:n]
+
+
+@pytest.mark.parametrize("shape", ["cfg2_64ch_2p26", "cfg3_1024ch_2p24", "cfg5_256ch_2p24", "exact_grid_64ch_2p26",
+                                   "exact_grid_1024ch_2p24"])
+def test_bench_shapes_against_the_oracle(pkg, ora, shape):
+    """The sizes the numbers in BENCH_*.json, profiles/ and DESIGN.md are quoted on ('Next round' 2a): one
+    block of 2^26 samples for 64 channels (bench.py's default and the driver's line), one block of 2^24 samples for 1024
+    channels on one GPU (16 slices x chunked tiles x the XCD item map), 256 channels of the Airspy plan (D = 400, 512 taps)
+    - every channel and every output against the oracle, bit-exact, plus the re-blocking property (the same stream in
+    smaller, ragged blocks leaves the PCM unchanged).  The exact_grid shapes put every channel on the 25 kHz grid, where
+    all rotators are exact and the kernel instances without derotation run (filter/direct_fir.c:151-172)."""
+    name, nch, log2 = {"cfg2_64ch_2p26": ("cfg2_64ch", 64, 26), "cfg3_1024ch_2p24": ("cfg3_1024ch", 1024, 24),
+                       "cfg5_256ch_2p24": ("cfg5_airspy", 256, 24), "exact_grid_64ch_2p26": ("cfg2_64ch", 64, 26),
+                       "exact_grid_1024ch_2p24": ("cfg3_1024ch", 1024, 24)}[shape]
+    fs, decim, taps, offs, gains = pkg.synth.plan(name, nr_channels=nch)
+    if shape.startswith("exact_grid"):
+        # multiples of the output rate (identity rotators) and odd multiples of half of it (sign flips), mixed
+        offs = pkg.synth.grid_offsets(nch, fs, decim)
+    block = 1 << log2
+    n = block + 54321
+    iq = _tiled_iq(pkg, n, fs, offs[:: max(1, nch // 6)][:6], seed=log2 + nch)
+    threads = os.cpu_count() or 8
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=block, want_iq=False)
+    st = eng.stats()
+    if shape.startswith("exact_grid"):
+        assert st["rot_exact_channels"] == nch and st["kernel_variant"] == 2
+    cre, cim, incr = _oracle_tables(eng, nch)
+    pcm, _ = eng.run(iq, block)
+    eng.close()
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=threads)
+    assert pcm.shape == ref.shape
+    if not np.array_equal(pcm, ref):
+        bad = np.argwhere(pcm != ref)
+        raise AssertionError(f"{shape}: {len(bad)} PCM samples differ from the oracle; first at (chan, n) = {bad[0]}")
+    del ref
+    small_block = (block >> 3) - 4097
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=small_block, want_iq=False)
+    small, _ = eng.run(iq, small_block)
+    eng.close()
+    assert np.array_equal(pcm, small), f"{shape}: re-blocking changed the PCM"
+
+
+@pytest.mark.parametrize("mix", ["all_four", "exact_three", "flip_and_identity", "identity", "quarter_only"])
+def test_rotator_classes_mixed_in_one_channel_set(pkg, ora, mix):
+    """filter/direct_fir.c:151-172 for increments that make the recurrence exact: (16384, 0) (identity), (-16384, 0) (sign
+    flip), (0, +-16384) (quarter turns), next to tabulated ones.  Rows are ordered by class, a launch runs the instance of
+    its lowest class and, in a launch with tabulated channels, each wave picks the exact form when its eight channels
+    allow it: channel sets that mix the classes at every granularity - within a wave, across waves, across slices - with
+    the filtered-IQ output on (which shows the derotated samples themselves) and off, several ragged blocks so that the
+    phases cross launches at odd output counts, full-scale input so that components of -32768 reach the sign changes."""
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 12500.0, fs)
+    rng = np.random.RandomState(5)
+    kinds_of = {"all_four": [0, 1, 2, 3], "exact_three": [0, 1, 2], "flip_and_identity": [0, 1], "identity": [0],
+                "quarter_only": [2]}[mix]
+    for nch, want_iq in ((3, True), (20, False), (70, True), (200, False)):
+        kinds = rng.choice(kinds_of, size=nch)
+        k = rng.randint(-40, 40, size=nch)
+        offs = np.select([kinds == 0, kinds == 1, kinds == 2], [25000 * k, 12500 * (2 * k + 1), 6250 * (2 * k + 1)],
+                         rng.randint(-1100000, 1100000, size=nch)).astype(np.int32)
+        iq = pkg.synth.random_iq(96 * 1501 + 333, seed=nch)
+        eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=96 * 333 + 17, want_iq=want_iq)
+        assert eng.stats()["rot_exact_channels"] == int((kinds != 3).sum())
+        eng.close()
+        _check(pkg, ora, fs, decim, taps, offs, iq, 96 * 333 + 17, want_iq=want_iq)
+
+
 def test_oracle_unpack_known_answers(ora):
     """the reference's 8-bit widenings restated (file_if.c:66-157, rtl_sdr_if.c:146-158)."""
     raw = np.array([0x7F, 0x80, 0xFF, 0x01, 0x00, 0x7F, 0x80, 0xFF], np.uint8)

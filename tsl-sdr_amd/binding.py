@@ -13,12 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFM_LIB") or os.path.join(_HERE, "libmultifm_hip.so")
 
 MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_DONE = 0, -1, -2, -3, -4, -5, -6
-MFM_ABI_VERSION = 2
+MFM_ABI_VERSION = 3
 MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
 MFM_F_FORCE_DOT2 = 0x4
 MFM_F_FORCE_MFMA_V1 = 0x8
 MFM_F_WIDEN_8BIT = 0x10
+MFM_F_TIMING_SPARSE = 0x20
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
@@ -78,7 +79,9 @@ class Stats(C.Structure):
                 ("outputs_per_tile", C.c_uint32), ("lds_bytes", C.c_uint32), ("grid_last", C.c_uint32),
                 ("tail_samples", C.c_uint32), ("rot_table_entries", C.c_uint64),
                 ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32),
-                ("launches_8bit", C.c_uint64)]
+                ("launches_8bit", C.c_uint64), ("timed_launches", C.c_uint64),
+                ("rot_exact_channels", C.c_uint32), ("rot_fast_slices", C.c_uint32),
+                ("k_steps", C.c_uint32), ("tap_hi_mask", C.c_uint32)]
 
 
 class PocsagConfig(C.Structure):

@@ -27,11 +27,15 @@
 #include "mfm_taps.h"
 #include "mfm_engine_internal.h"
 
-extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, int dbg_iq, uint32_t lds_bytes,
-                                                hipStream_t stream);
-extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, uint32_t lds_bytes,
+/* every kernel file exports a pair: select (which template instance runs a launch description; asked at commit, where the
+ * instance's LDS limit is raised once) and launch (through that pointer) */
+extern "C" hipError_t mfm_select_channel_kernel(int opl, int dbg_iq, const void **kfn_out);
+extern "C" hipError_t mfm_launch_channel_kernel(const void *kfn, const mfm_launch *L, uint32_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out);
+extern "C" hipError_t mfm_launch_channel_kernel_mfma(const void *kfn, const mfm_launch_mfma *L, uint32_t lds_bytes,
                                                      uint32_t grid, hipStream_t stream);
-extern "C" hipError_t mfm_launch_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, uint32_t lds_bytes, uint32_t grid,
+extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out);
+extern "C" hipError_t mfm_launch_channel_kernel_v3(const void *kfn, const mfm_launch_v3 *L, uint32_t lds_bytes, uint32_t grid,
                                                    hipStream_t stream);
 
 
@@ -62,6 +66,7 @@ constexpr uint64_t MFM_ATAN_TABLE_FNV1A = 0x674d1aab1787b44bull;
 
 constexpr int kOutSlots = 4;      /* output ring depth (2 in device-only mode) */
 constexpr int kTimingPairs = 256; /* event pairs kept before the oldest is folded into the total */
+constexpr uint64_t kSparseTiming = 4; /* MFM_F_TIMING_SPARSE: one launch in this many is bracketed */
 constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine_get_launch_ms() */
 constexpr uint32_t kMaxOutputsPerTile = 128;
 constexpr uint64_t kMaxRotEntries = 1ull << 26; /* per distinct increment: 512 MiB of table */
@@ -164,6 +169,10 @@ struct mfm_engine {
     int32_t *d_krow = nullptr;
     int32_t *d_krow8[4] = { nullptr, nullptr, nullptr, nullptr }; /* [MFM_IN_*]: row constants of the 8-bit input forms */
     bool raw8_ok = false; /* the matrix kernels can read 8-bit input as it is (IN8 forms of mfm_kernel_v3.hip, mfm_kernel_mfma.hip) */
+    uint32_t v_rc = 0; /* the lowest rotator class (MFM_RC_*) among the channels: selects the kernel instance */
+    uint32_t rot_exact_channels = 0, rot_fast_slices = 0;
+    /* the kernel instance that runs a block of input format MFM_IN_* (selected, and its LDS limit raised, at commit) */
+    const void *kfn[4] = { nullptr, nullptr, nullptr, nullptr };
 
     /* device tables */
     uint32_t *d_coef = nullptr, *d_tapoff = nullptr;
@@ -220,6 +229,112 @@ struct mfm_engine {
 };
 
 namespace {
+
+/* The geometry half of a launch description - everything commit fixed, per input format; submit adds the block (input
+ * address and counts, chunking, output slot, carried state).  Also what the kernel files' select functions look at. */
+void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
+{
+    V.decim = e->cfg.decimation;
+    V.x_last4 = (e->cap_in - 4u) & ~3u;
+    V.kq = e->m_ks;
+    V.rs = e->v_rs;
+    V.sp_pitch = e->v_sp_pitch;
+    V.plane_pitch = 4u * e->v_sp_pitch;
+    V.buf_pitch = 8u * e->v_sp_pitch;
+    V.nstage4 = e->v_nstage4;
+    V.lut_off = 16u * e->v_sp_pitch;
+    V.sta_off = V.lut_off + 2048u;
+    for (int k = 0; k < 4; k++) {
+        V.cross[k] = e->v_cross[k];
+        V.within[k] = e->v_within[k];
+    }
+    V.nslices = e->m_nslices;
+    V.nrb = e->m_nrb;
+    V.nchan = (uint32_t)e->chans.size();
+    V.out_stride = e->out_stride;
+    V.ah_mask = e->m_ah_mask;
+    V.rc = e->v_rc;
+    V.afrag = e->d_afrag;
+    V.krow = e->d_krow;
+    V.info = e->d_info;
+    V.rot = e->d_rot;
+    V.lut = e->d_lut;
+    if (fmt != MFM_IN_CS16) {
+        /* the buffer holds 2-byte samples: twice as many fit, a 16-byte chunk is 8 of them */
+        V.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
+        V.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
+        V.krow = e->d_krow8[fmt];
+        V.nstage4 = e->v_nstage4 / 2u;
+        V.x_last4 = (2u * e->cap_in - 8u) & ~7u;
+    }
+}
+
+void fill_mfma(const mfm_engine *e, int fmt, mfm_launch_mfma &M)
+{
+    const uint32_t C = (uint32_t)e->chans.size(), D = e->cfg.decimation;
+    M.decim = D;
+    M.x_last4 = (e->cap_in - 4u) & ~3u;
+    M.kq = e->m_ks;
+    M.kq_used = e->m_kq_used;
+    M.ot = e->m_ot;
+    M.nstage = e->m_nstage;
+    M.rs = e->m_rs;
+    M.row_bytes = e->m_row_bytes;
+    M.split_rows = (D % 4u) != 0u ? 1u : 0u;
+    M.plane_bytes = e->m_plane_bytes;
+    M.fixed_planes = e->m_fixed_planes ? 1u : 0u;
+    M.lut_off = e->m_lut_off;
+    M.sta_off = e->m_lut_off + 2048u;
+    M.bof_off = M.sta_off + ((M.nstage / 4u + MFM_MFMA_NW * 64u - 1u) / (MFM_MFMA_NW * 64u)) * MFM_MFMA_NW * 64u * 4u;
+    M.tbl_off = C <= 256u ? M.bof_off + (e->m_ks > MFM_MFMA_KQ_MAX ? 2048u : 0u) : 0u;
+    M.nslices = e->m_nslices;
+    M.nrb = e->m_nrb;
+    M.nchan = C;
+    M.out_stride = e->out_stride;
+    M.ah_mask = e->m_ah_mask;
+    M.afrag = e->d_afrag;
+    M.krow = e->d_krow;
+    M.info = e->d_info;
+    M.rot = e->d_rot;
+    M.lut = e->d_lut;
+    if (fmt != MFM_IN_CS16) {
+        /* the buffer holds 2-byte samples: twice as many fit; a staging chunk (4 samples) is an 8-byte load */
+        M.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
+        M.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
+        M.krow = e->d_krow8[fmt];
+        M.x_last4 = (2u * e->cap_in - 4u) & ~3u;
+    }
+}
+
+/* which instance runs blocks of each input format; its LDS limit is raised here, once (commit, on the engine's device) */
+int select_kernels(mfm_engine *e)
+{
+    for (int fmt = MFM_IN_CS16; fmt <= MFM_IN_RTLSDR_U8; fmt++) {
+        e->kfn[fmt] = nullptr;
+        if (fmt != MFM_IN_CS16 && !e->raw8_ok) {
+            continue;
+        }
+        const void *fn = nullptr;
+        uint32_t lds = 0;
+        if (e->use_v3) {
+            mfm_launch_v3 V{};
+            fill_v3(e, fmt, V);
+            HIP_TRY(mfm_select_channel_kernel_v3(&V, e->any_iq ? 1 : 0, &fn));
+            lds = e->v_lds_bytes;
+        } else if (e->use_mfma) {
+            mfm_launch_mfma M{};
+            fill_mfma(e, fmt, M);
+            HIP_TRY(mfm_select_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, &fn));
+            lds = e->m_lds_bytes;
+        } else {
+            HIP_TRY(mfm_select_channel_kernel(e->opl, e->any_iq ? 1 : 0, &fn));
+            lds = e->lds_bytes;
+        }
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        e->kfn[fmt] = fn;
+    }
+    return MFM_OK;
+}
 
 int fold_timing(mfm_engine *e, bool all)
 {
@@ -746,6 +861,91 @@ static int commit_locked(struct mfm_engine *e)
             e->m_nslices = (e->m_nrb + MFM_MFMA_NW - 1u) / MFM_MFMA_NW;
             e->m_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
 
+        }
+    }
+
+    /* ---- second-generation matrix kernel: 64-output tiles, four sub-planes per byte plane (mfm_kernel.h) ---- */
+    e->use_v3 = false;
+    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && e->m_ks <= 4u && (2u * D) % 64u == 0u) {
+        const uint32_t kq = e->m_ks, row_bytes = 2u * D;
+        uint32_t rs_v = (row_bytes + 31u) / 32u * 32u;
+        if (((rs_v / 32u) & 1u) == 0u) {
+            rs_v += 32u; /* odd multiple of 32 bytes: the B-fragment read pattern runs at the full ds_read_b128 rate */
+        }
+        const uint32_t extra = (64u * kq - 1u) / row_bytes; /* rows the last output's window reaches past the tile */
+        const uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + extra;
+        const uint32_t sr = (rows + 3u) / 4u;
+        uint32_t sp = sr * rs_v;
+        sp = sp <= 4096u ? 4096u : (sp + 63u) & ~63u;
+        const uint32_t nstage4 = rows * D / 4u; /* D % 16 == 0 here */
+        const uint32_t nch = (nstage4 + 511u) / 512u;
+        const uint32_t lds = 16u * sp + 2048u + nch * 512u * 4u + 1024u + 2048u; /* image, atan table, staging offsets, row constants + fold constants, exact-rotator table */
+        if (nch <= MFM_V3_CH_MAX && lds <= 160u * 1024u) {
+            e->use_v3 = true;
+            e->v_rs = rs_v;
+            e->v_sp_pitch = sp;
+            e->v_nstage4 = nstage4;
+            e->v_lds_bytes = lds;
+            e->v_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
+            for (uint32_t k = 0; k < 4; k++) {
+                e->v_cross[k] = k < kq ? (64u * k) / row_bytes : 0u;
+                e->v_within[k] = k < kq ? (64u * k) % row_bytes : 0u;
+            }
+        }
+    }
+
+    /* ---- rotator classes and row order (filter/direct_fir.c:151-172,406-413).  An increment of exactly (16384, 0) - every
+     *      channel whose offset is a multiple of the output rate, e.g. a 25 kHz grid at 2.4 MS/s / 96 - leaves the rotator at
+     *      (16384, 0) for ever, and r14(f * 16384) = f: nothing to do.  An increment of (-16384, 0) - offsets at odd
+     *      multiples of half the output rate - makes it alternate between (16384, 0) and (-16384, 0), and r14(f * -16384)
+     *      = -f with the int16 cast's wrap: one packed multiply by +-1.  An increment of (0, +-16384) - offsets at odd
+     *      multiples of a quarter of the output rate - walks the four axis points: r14(f * rot) = f * j^m, a swap of
+     *      the halves and two signs.  Everything else is the general case (two Q14
+     *      dot products against the tabulated rotator and a second rounding).  The second-generation kernel runs a
+     *      64-channel slice without the table loads and the derotation arithmetic when all its channels are exact, so
+     *      the rows are ordered by class (stable); where a row's PCM goes is in its mfm_chan_info. ---- */
+    auto chan_class = [](const Channel &ch) -> uint32_t {
+        if ((ch.incr_re == 16384 && ch.incr_im == 0) || (ch.incr_re == 0 && ch.incr_im == 0)) {
+            return MFM_RC_IDENT; /* direct_fir.c:406 skips the derotation altogether for a zero increment */
+        }
+        if (ch.incr_re == -16384 && ch.incr_im == 0) {
+            return MFM_RC_FLIP;
+        }
+        return (ch.incr_re == 0 && (ch.incr_im == 16384 || ch.incr_im == -16384)) ? MFM_RC_QUARTER : MFM_RC_GENERAL;
+    };
+    /* quarter turns per output: rot after k outputs = j^(turns * k) * 16384 for the exact classes */
+    auto chan_turns = [](const Channel &ch) -> uint32_t {
+        return ch.incr_im == 16384 ? 1u : ch.incr_im == -16384 ? 3u : ch.incr_re == -16384 ? 2u : 0u;
+    };
+    std::vector<uint32_t> perm(C);
+    for (uint32_t c = 0; c < C; c++) {
+        perm[c] = c;
+    }
+    if (e->use_v3) {
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+            return chan_class(e->chans[a]) > chan_class(e->chans[b]);
+        });
+    }
+    e->rot_exact_channels = 0;
+    for (uint32_t c = 0; c < C; c++) {
+        e->rot_exact_channels += chan_class(e->chans[c]) != MFM_RC_GENERAL ? 1u : 0u;
+    }
+    e->v_rc = MFM_RC_IDENT;
+    e->rot_fast_slices = 0;
+    for (uint32_t sl = 0; sl < e->m_nslices && e->use_v3; sl++) {
+        uint32_t cls = MFM_RC_IDENT; /* rows past the last channel have zero taps and store nothing */
+        for (uint32_t c = sl * 64u; c < std::min(C, sl * 64u + 64u); c++) {
+            cls = std::min(cls, chan_class(e->chans[perm[c]]));
+        }
+        e->v_rc = std::min(e->v_rc, cls);
+        e->rot_fast_slices += cls != MFM_RC_GENERAL ? 1u : 0u;
+    }
+    if (!e->use_v3 || e->any_iq) {
+        e->v_rc = MFM_RC_GENERAL; /* the exact-rotator instances are built without the filtered-IQ output */
+    }
+
+    if (e->use_mfma) {
+        const uint32_t kq = e->m_ks, row_bytes = e->m_row_bytes;
             /* W[2c] = (cr0,-ci0,cr1,-ci1..), W[2c+1] = (ci0,cr0,ci1,cr1..) (filter/complex.h:40-46) */
             const uint32_t K = 64u * kq;
             auto w_at = [&](uint32_t row, uint32_t k) -> int32_t {
@@ -755,7 +955,7 @@ static int commit_locked(struct mfm_engine *e)
                 if (c >= C || pos >= 2u * D || i >= T) {
                     return 0;
                 }
-                const int32_t cr = e->chans[c].cre[i], ci = e->chans[c].cim[i];
+                const int32_t cr = e->chans[perm[c]].cre[i], ci = e->chans[perm[c]].cim[i];
                 if (row & 1u) {
                     return (k & 1u) ? cr : ci;
                 }
@@ -790,37 +990,6 @@ static int commit_locked(struct mfm_engine *e)
                     krow[(size_t)rb * 16 + i] = (int32_t)(128u * sum + 8192u);
                 }
             }
-        }
-    }
-
-    /* ---- second-generation matrix kernel: 64-output tiles, four sub-planes per byte plane (mfm_kernel.h) ---- */
-    e->use_v3 = false;
-    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && e->m_ks <= 4u && (2u * D) % 64u == 0u) {
-        const uint32_t kq = e->m_ks, row_bytes = 2u * D;
-        uint32_t rs_v = (row_bytes + 31u) / 32u * 32u;
-        if (((rs_v / 32u) & 1u) == 0u) {
-            rs_v += 32u; /* odd multiple of 32 bytes: the B-fragment read pattern runs at the full ds_read_b128 rate */
-        }
-        const uint32_t extra = (64u * kq - 1u) / row_bytes; /* rows the last output's window reaches past the tile */
-        const uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + extra;
-        const uint32_t sr = (rows + 3u) / 4u;
-        uint32_t sp = sr * rs_v;
-        sp = sp <= 4096u ? 4096u : (sp + 63u) & ~63u;
-        const uint32_t nstage4 = rows * D / 4u; /* D % 16 == 0 here */
-        const uint32_t nch = (nstage4 + 511u) / 512u;
-        const uint32_t lds = 16u * sp + 2048u + nch * 512u * 4u + 1024u; /* image, atan table, staging offsets, row constants + fold constants */
-        if (nch <= MFM_V3_CH_MAX && lds <= 160u * 1024u) {
-            e->use_v3 = true;
-            e->v_rs = rs_v;
-            e->v_sp_pitch = sp;
-            e->v_nstage4 = nstage4;
-            e->v_lds_bytes = lds;
-            e->v_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
-            for (uint32_t k = 0; k < 4; k++) {
-                e->v_cross[k] = k < kq ? (64u * k) / row_bytes : 0u;
-                e->v_within[k] = k < kq ? (64u * k) % row_bytes : 0u;
-            }
-        }
     }
 
     /* ---- rotator tables (one per distinct increment) ---- */
@@ -871,10 +1040,13 @@ static int commit_locked(struct mfm_engine *e)
     std::vector<mfm_chan_info> info((size_t)e->ngroups * MFM_CG);
     memset(info.data(), 0, info.size() * sizeof(mfm_chan_info));
     for (uint32_t c = 0; c < C; c++) {
-        info[c].rot_base = e->chans[c].rot_base;
-        info[c].mu = e->chans[c].mu;
-        info[c].lam = e->chans[c].lam;
-        info[c].lam_magic = (uint32_t)std::min<uint64_t>(0xffffffffull, (1ull << 32) / e->chans[c].lam);
+        const Channel &ch = e->chans[perm[c]];
+        info[c].rot_base = ch.rot_base;
+        info[c].mu = ch.mu;
+        info[c].lam = ch.lam;
+        info[c].lam_magic = (uint32_t)std::min<uint64_t>(0xffffffffull, (1ull << 32) / ch.lam);
+        info[c].out_row = perm[c];
+        info[c].rot_class = chan_class(ch) | (chan_class(ch) != MFM_RC_GENERAL ? chan_turns(ch) << 4 : 0u);
     }
 
     /* ---- atan LUT: fast_atan2f.c:14-81, entries atan(i/255) at 7 significant digits ---- */
@@ -975,6 +1147,12 @@ static int commit_locked(struct mfm_engine *e)
         for (int i = 0; i < kTimingPairs; i++) {
             HIP_TRY(hipEventCreate(&e->t0[i]));
             HIP_TRY(hipEventCreate(&e->t1[i]));
+        }
+    }
+    {
+        const int rc = select_kernels(e);
+        if (rc != MFM_OK) {
+            return rc;
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -1127,7 +1305,11 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             /* the previous D2H out of this slot must have drained before the kernel rewrites it */
             HIP_TRY(hipStreamWaitEvent(e->s_compute, slot->ready, 0));
         }
-        const bool timing = (e->cfg.flags & MFM_F_TIMING) != 0;
+        /* MFM_F_TIMING_SPARSE: every fourth launch carries the event pair.  An event record is a packet the command
+         * processor handles between two kernels (~4 us each on MI355X): bracketing every launch of a back-to-back
+         * stream costs 6 % of a 0.12 ms step, a sample of them costs under 1 % and measures the same kernel. */
+        const bool timing = (e->cfg.flags & MFM_F_TIMING) != 0 &&
+                            (!(e->cfg.flags & MFM_F_TIMING_SPARSE) || (e->launches % kSparseTiming) == 0);
         int ti = 0;
         if (timing) {
             int rc = fold_timing(e, false);
@@ -1139,25 +1321,10 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         }
         if (e->use_v3) {
             mfm_launch_v3 V{};
+            fill_v3(e, fmt, V);
             V.x = e->d_in[cur];
             V.n_avail = n_avail;
             V.n_new = n_new;
-            V.decim = D;
-            V.x_last4 = (e->cap_in - 4u) & ~3u;
-            V.kq = e->m_ks;
-            V.rs = e->v_rs;
-            V.sp_pitch = e->v_sp_pitch;
-            V.plane_pitch = 4u * e->v_sp_pitch;
-            V.buf_pitch = 8u * e->v_sp_pitch;
-            V.nstage4 = e->v_nstage4;
-            V.lut_off = 16u * e->v_sp_pitch;
-            V.sta_off = V.lut_off + 2048u;
-            for (int k = 0; k < 4; k++) {
-                V.cross[k] = e->v_cross[k];
-                V.within[k] = e->v_within[k];
-            }
-            V.nslices = e->m_nslices;
-            V.nrb = e->m_nrb;
             V.ntiles = (n_new + MFM_V3_OT - 1u) / MFM_V3_OT;
             /* chunks of consecutive tiles, `rounds` per workgroup slot and slice, lengths equal to within one tile
              * (a chunk pays one extra column group) */
@@ -1167,89 +1334,46 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             V.nchunks = std::min(V.ntiles, per_slice);
             V.cl = (V.ntiles + V.nchunks - 1u) / V.nchunks;
             V.nitems = ((V.nchunks + 7u) / 8u) * 8u * V.nslices;
-            V.nchan = C;
-            V.out_stride = e->out_stride;
-            V.ah_mask = e->m_ah_mask;
             V.tail_src = n_new * D;
             V.tail_n = n_avail - n_new * D;
             V.tail_dst = e->d_in[cur ^ 1];
             tail_in_kernel = true;
-            V.afrag = e->d_afrag;
-            V.krow = e->d_krow;
-            V.info = e->d_info;
-            V.rot = e->d_rot;
             V.st_in = L.st_in;
             V.st_out = L.st_out;
-            V.lut = e->d_lut;
             V.pcm = slot->d_pcm;
             V.iq_dbg = L.iq_dbg;
             if (raw8) {
-                /* the buffer holds 2-byte samples: twice as many fit, a 16-byte chunk is 8 of them */
-                V.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
-                V.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
-                V.krow = e->d_krow8[fmt];
-                V.nstage4 = e->v_nstage4 / 2u;
-                V.x_last4 = (2u * e->cap_in - 8u) & ~7u;
                 e->launches_8bit++;
             }
             const uint32_t grid = std::min(V.nitems, slots);
-            HIP_TRY(mfm_launch_channel_kernel_v3(&V, e->any_iq ? 1 : 0, e->v_lds_bytes, grid, e->s_compute));
+            HIP_TRY(mfm_launch_channel_kernel_v3(e->kfn[fmt], &V, e->v_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */
             L.nslices = 1;
         } else if (e->use_mfma) {
             mfm_launch_mfma M{};
+            fill_mfma(e, fmt, M);
             M.x = e->d_in[cur];
             M.n_avail = n_avail;
             M.n_new = n_new;
-            M.decim = D;
-            M.x_last4 = (e->cap_in - 4u) & ~3u;
-            M.kq = e->m_ks;
-            M.kq_used = e->m_kq_used;
-            M.ot = e->m_ot;
-            M.nstage = e->m_nstage;
-            M.rs = e->m_rs;
-            M.row_bytes = e->m_row_bytes;
-            M.split_rows = (D % 4u) != 0u ? 1u : 0u;
-            M.plane_bytes = e->m_plane_bytes;
-            M.fixed_planes = e->m_fixed_planes ? 1u : 0u;
-            M.lut_off = e->m_lut_off;
-            M.sta_off = e->m_lut_off + 2048u;
-            M.bof_off = M.sta_off + ((M.nstage / 4u + MFM_MFMA_NW * 64u - 1u) / (MFM_MFMA_NW * 64u)) * MFM_MFMA_NW * 64u * 4u;
-            M.tbl_off = C <= 256u ? M.bof_off + (e->m_ks > MFM_MFMA_KQ_MAX ? 2048u : 0u) : 0u;
-            M.nslices = e->m_nslices;
-            M.nrb = e->m_nrb;
             M.ntiles = (n_new + e->m_ot - 1u) / e->m_ot;
             M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
-            M.nchan = C;
-            M.out_stride = e->out_stride;
-            M.ah_mask = e->m_ah_mask;
             M.tail_src = n_new * D;
             M.tail_n = n_avail - n_new * D;
             M.tail_dst = e->d_in[cur ^ 1];
             tail_in_kernel = true;
-            M.afrag = e->d_afrag;
-            M.krow = e->d_krow;
-            M.info = e->d_info;
-            M.rot = e->d_rot;
             M.st_in = L.st_in;
             M.st_out = L.st_out;
-            M.lut = e->d_lut;
             M.pcm = slot->d_pcm;
             M.iq_dbg = L.iq_dbg;
             if (raw8) {
-                /* the buffer holds 2-byte samples: twice as many fit; a staging chunk (4 samples) is an 8-byte load */
-                M.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
-                M.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
-                M.krow = e->d_krow8[fmt];
-                M.x_last4 = (2u * e->cap_in - 4u) & ~3u;
                 e->launches_8bit++;
             }
             const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_per_cu);
-            HIP_TRY(mfm_launch_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, e->m_lds_bytes, grid, e->s_compute));
+            HIP_TRY(mfm_launch_channel_kernel_mfma(e->kfn[fmt], &M, e->m_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */
             L.nslices = 1;
         } else {
-            HIP_TRY(mfm_launch_channel_kernel(&L, e->opl, e->any_iq ? 1 : 0, e->lds_bytes, e->s_compute));
+            HIP_TRY(mfm_launch_channel_kernel(e->kfn[MFM_IN_CS16], &L, e->lds_bytes, e->s_compute));
         }
         if (timing) {
             HIP_TRY(hipEventRecord(e->t1[ti], e->s_compute));
@@ -1542,6 +1666,11 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->outputs = e->outputs;
     st->launches = e->launches;
     st->kernel_ms = e->kernel_ms;
+    st->timed_launches = e->launch_ms_n;
+    st->rot_exact_channels = e->rot_exact_channels;
+    st->rot_fast_slices = e->rot_fast_slices;
+    st->k_steps = e->use_mfma ? e->m_ks : 0u;
+    st->tap_hi_mask = e->use_mfma ? e->m_ah_mask : 0u;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
     st->outputs_per_tile = e->use_v3 ? MFM_V3_OT : e->use_mfma ? e->m_ot : 64u * e->opl;

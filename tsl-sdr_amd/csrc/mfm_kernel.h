@@ -22,8 +22,20 @@ struct mfm_chan_info {
     uint32_t mu;       /* pre-period of the rotator sequence */
     uint32_t lam;      /* period */
     uint32_t lam_magic; /* floor(2^32 / lam) */
-    uint32_t pad[3];
-}; /* 8 dwords: the kernel reads it as a dword array */
+    uint32_t pad0;      /* the first-generation matrix kernel keeps the channel's table position here in its LDS copy */
+    uint32_t out_row;   /* row of the PCM / filtered-IQ output this channel's samples go to (the second-generation
+                           kernel orders its rows by rotator class; the others keep the caller's order) */
+    uint32_t rot_class; /* MFM_RC_* */
+}; /* 8 dwords: the kernels read it as a dword array */
+
+/* rotator classes (filter/direct_fir.c:151-172): what the recurrence rot <- r14(rot * incr) does for this increment.
+ * mfm_chan_info::rot_class = class | (quarter turns per output) << 4.  Higher = cheaper; a set of channels runs at the
+ * lowest class among them. */
+#define MFM_RC_GENERAL 0u /* tabulated; derotation = two Q14 dot products + rounding */
+#define MFM_RC_QUARTER 1u /* incr = (0, +-16384): rot walks the four axis points; r14(f * rot) = f * j^m exactly (with the
+                             int16 cast's wrap): a swap of the halves and two signs */
+#define MFM_RC_FLIP 2u    /* incr = (-16384, 0): rot alternates (16384, 0), (-16384, 0); r14(f * rot) = +-f */
+#define MFM_RC_IDENT 3u   /* incr = (16384, 0) or zero: rot stays (16384, 0); r14(f * rot) = f */
 
 /* per-channel state carried between launches (ping-pong) */
 struct mfm_chan_state {
@@ -154,6 +166,7 @@ struct mfm_launch_v3 {
     uint32_t nchunks;     /* ceil(ntiles / cl) */
     uint32_t nitems;      /* chunks rounded up to a multiple of 8, times slices */
     uint32_t nchan, out_stride, ah_mask;
+    uint32_t rc;          /* the lowest MFM_RC_* of the launch's channels (selects the kernel instance) */
     uint32_t tail_src, tail_n;
     uint32_t in8;         /* 0: x is packed int16 IQ.  7 / 14: x is 8-bit IQ off the wire (2 bytes per sample; n_avail,
                              x_last4, tail_* count samples all the same), the value is the first rounding's shift and

@@ -242,41 +242,29 @@ __global__ __launch_bounds__(MFM_NT) void mfm_channel_kernel(const mfm_launch L)
 
 /* ------------------------------------------------------------------------------------- */
 
-extern "C" hipError_t mfm_launch_channel_kernel(const mfm_launch *L, int opl, int dbg_iq, uint32_t lds_bytes,
-                                                hipStream_t stream)
+/* which instance runs (outputs per lane, filtered-IQ output): asked once at commit, where its LDS limit is raised */
+extern "C" hipError_t mfm_select_channel_kernel(int opl, int dbg_iq, const void **kfn_out)
+{
+    *kfn_out = nullptr;
+    if (opl == 2) {
+        *kfn_out = dbg_iq ? reinterpret_cast<const void *>(&mfm_channel_kernel<2, true>)
+                          : reinterpret_cast<const void *>(&mfm_channel_kernel<2, false>);
+    } else if (opl == 1) {
+        *kfn_out = dbg_iq ? reinterpret_cast<const void *>(&mfm_channel_kernel<1, true>)
+                          : reinterpret_cast<const void *>(&mfm_channel_kernel<1, false>);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipSuccess;
+}
+
+extern "C" hipError_t mfm_launch_channel_kernel(const void *kfn, const mfm_launch *L, uint32_t lds_bytes, hipStream_t stream)
 {
     const uint32_t tiles8 = (L->ntiles + 7u) / 8u;
     const dim3 grid(tiles8 * 8u * L->nslices), block(MFM_NT);
     if (L->ntiles == 0) {
         return hipSuccess;
     }
-#define MFM_LAUNCH(OPL_, DBG_)                                                                               \
-    do {                                                                                                     \
-        auto kfn = mfm_channel_kernel<OPL_, DBG_>;                                                           \
-        /* every launch: the attribute is per device (engines on several devices share this code) */         \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-        if (e_ != hipSuccess) {                                                                              \
-            return e_;                                                                                       \
-        }                                                                                                    \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, *L);                                         \
-    } while (0)
-
-    if (opl == 2) {
-        if (dbg_iq) {
-            MFM_LAUNCH(2, true);
-        } else {
-            MFM_LAUNCH(2, false);
-        }
-    } else if (opl == 1) {
-        if (dbg_iq) {
-            MFM_LAUNCH(1, true);
-        } else {
-            MFM_LAUNCH(1, false);
-        }
-    } else {
-        return hipErrorInvalidValue;
-    }
-#undef MFM_LAUNCH
-    return hipGetLastError();
+    void *args[] = { const_cast<mfm_launch *>(L) };
+    return hipLaunchKernel(kfn, grid, block, args, lds_bytes, stream);
 }

@@ -727,12 +727,12 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     }
 }
 
-extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, uint32_t lds_bytes,
-                                                     uint32_t grid, hipStream_t stream)
+/* Which instance runs a launch description - decided by geometry fields that are fixed at commit (and the input format);
+ * the engine asks once per format at commit, raises the instance's LDS limit there and launches through the pointer
+ * (mfm_kernel_v3.hip has the same pair). */
+extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out)
 {
-    if (L->ntiles == 0) {
-        return hipSuccess;
-    }
+    *kfn_out = nullptr;
     if (L->in8 && dbg_iq) {
         return hipErrorInvalidValue;
     }
@@ -753,16 +753,9 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 #define MFM_LAUNCH_T(KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_)                                                \
     do {                                                                                                     \
         /* 8-bit input (L->in8: the engine only asks when no channel wants its filtered IQ) */                  \
-        auto kfn = (L->in8 && !DBG_) ? mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_, !DBG_>           \
-                                     : mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_, false>;          \
-        /* every launch: the attribute is per device, and engines on different devices or threads share this   \
-         * code (a process-wide "already set" flag would skip the second device) */                           \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-        if (e_ != hipSuccess) {                                                                              \
-            return e_;                                                                                       \
-        }                                                                                                    \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
+        *kfn_out = (L->in8 && !DBG_)                                                                         \
+                       ? reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_, !DBG_>) \
+                       : reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ_, DBG_, FIXP_, NCH_, KC_, AHM_, NIT_, false>); \
     } while (0)
 #define MFM_LAUNCH_M(KQ_, DBG_, FIXP_)                                                                       \
     do {                                                                                                     \
@@ -844,7 +837,7 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         }
 #undef MFM_LAUNCH_1
 #undef MFM_LAUNCH_1N
-        return hipGetLastError();
+        return hipSuccess;
     }
     if (nch > 4) {
         return hipErrorInvalidValue; /* two-iteration tiles are built for up to 4 chunks per thread */
@@ -859,13 +852,7 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
         }
 #define MFM_LAUNCH_X(KQ_, NCH_, IN8_)                                                                        \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<KQ_, false, false, NCH_, 1, -1, 2, IN8_>;                         \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-        if (e_ != hipSuccess) {                                                                              \
-            return e_;                                                                                       \
-        }                                                                                                    \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
+        *kfn_out = reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ_, false, false, NCH_, 1, -1, 2, IN8_>); \
     } while (0)
         /* Five to seven k-steps of taps (the D = 25 plan of etc/pocsag_rtlsdr.json: 326 elements = 6) fit the registers
          * beside one or two staging chunks: nothing is streamed, nothing is multiplied with the padding up to the eighth.
@@ -900,13 +887,7 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
              * of taps, so nothing is streamed (the D = 25 plan of etc/pocsag_rtlsdr.json: 6 k-steps run as 8) */
 #define MFM_LAUNCH_R8(NCH_)                                                                                  \
     do {                                                                                                     \
-        auto kfn = mfm_channel_kernel_mfma<8, false, false, NCH_, 1, -1, 2, true>;                           \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
-        if (e_ != hipSuccess) {                                                                              \
-            return e_;                                                                                       \
-        }                                                                                                    \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(MFM_M_NT), lds_bytes, stream, *L);                          \
+        *kfn_out = reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<8, false, false, NCH_, 1, -1, 2, true>); \
     } while (0)
             if (nch <= 2) { /* more staging registers than that and the taps no longer fit beside them */
                 if (nch == 1) {
@@ -935,5 +916,15 @@ extern "C" hipError_t mfm_launch_channel_kernel_mfma(const mfm_launch_mfma *L, i
 #undef MFM_LAUNCH_C
 #undef MFM_LAUNCH_A
 #undef MFM_LAUNCH_T
-    return hipGetLastError();
+    return hipSuccess;
+}
+
+extern "C" hipError_t mfm_launch_channel_kernel_mfma(const void *kfn, const mfm_launch_mfma *L, uint32_t lds_bytes,
+                                                     uint32_t grid, hipStream_t stream)
+{
+    if (L->ntiles == 0) {
+        return hipSuccess;
+    }
+    void *args[] = { const_cast<mfm_launch_mfma *>(L) };
+    return hipLaunchKernel(kfn, dim3(grid), dim3(MFM_M_NT), args, lds_bytes, stream);
 }

@@ -74,6 +74,9 @@ CONFIGS = {
     "multifm_1ch_2400k": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, offsets=[112500]),
     "cfg2_64ch": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, nr_channels=64),
     "cfg3_1024ch": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, nr_channels=1024),
+    # the same geometry with every channel on the 12.5 kHz raster: all rotators exact
+    "cfg2_64ch_grid": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, nr_channels=64, grid=True),
+    "cfg3_1024ch_grid": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, nr_channels=1024, grid=True),
     "pocsag_rtlsdr": dict(fs=1200000, decim=25, taps=128, cutoff=12500.0, offsets=[-320000, -492000],
                           gains_db=[4.0, 0.0]),
     # the FLEX 25 kHz LPF of configs[4] (512 taps, etc/flex_25khz_lpf*.json) at the 2.4 MS/s / D = 96 geometry
@@ -83,6 +86,15 @@ CONFIGS = {
 }
 
 
+def grid_offsets(nr_channels, sample_rate_hz=2400000, decimation=96):
+    """Channel centres on the grid of half the output rate (12.5 kHz at 2.4 MS/s / 96), wrapping around inside the band:
+    every rotator increment is exactly (16384, 0) or (-16384, 0) (filter/direct_fir.c:72-79), the channel plans real
+    deployments use (a 25 kHz or 12.5 kHz raster)."""
+    half = sample_rate_hz // decimation // 2
+    span = int(0.99 * sample_rate_hz / 2) // half
+    return np.array([half * ((k % (2 * span)) - span) for k in range(nr_channels)], dtype=np.int32)
+
+
 def plan(name, nr_channels=None):
     """Resolve a named configuration to (fs, decimation, lpf_taps, offsets[int32], gains[float])."""
     c = dict(CONFIGS[name])
@@ -90,6 +102,8 @@ def plan(name, nr_channels=None):
     taps = design_lpf(c["taps"], c["cutoff"], fs)
     if "offsets" in c and nr_channels is None:
         offs = np.array(c["offsets"], dtype=np.int32)
+    elif c.get("grid"):
+        offs = grid_offsets(nr_channels or c["nr_channels"], fs, decim)
     else:
         offs = channel_offsets(nr_channels or c["nr_channels"], fs)
     gains_db = c.get("gains_db", [0.0] * len(offs))
