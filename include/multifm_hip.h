@@ -212,8 +212,10 @@ const char *mfm_last_error(void); /* thread-local detail of the last failure */
  * ---- one channel set on several GPUs of a node (SURVEY.md section 8b "set_devices", section 8e) -----------------
  * The reference fans every delivered sample_buf out to all channel threads (multifm/receiver.c:78-98).  A device
  * group does the same across GPUs: channels are cut into contiguous shards (mfm_shard_range), one engine per device;
- * mfm_group_push() stages a block on the first device and broadcasts it with RCCL (ncclBroadcast over xGMI, in place
- * into every other engine's input buffer), then every engine runs its shard.  No other exchange.  Blocks come back per
+ * mfm_group_push() stages a block on the first device and exchanges it with RCCL over xGMI (ncclBroadcast, or a scatter
+ * plus ncclAllGather: MFM_X_*), in place into every other engine's input buffer, then every engine runs its shard - all
+ * shards take a block or none does; a failure after the first shard has taken it makes every later call fail with
+ * MFM_E_DEVICE rather than let the shards drift apart.  No other exchange.  Blocks come back per
  * shard: mfm_group_fetch() fills one mfm_block per shard, all for the same stream position; channel c of the group is
  * row c - first_channel of its shard's block (mfm_group_shard_info).  One host thread at a time may push, another one
  * fetch/release (as for a single engine).  RCCL (librccl.so) is loaded at run time, and only by groups that exchange.
@@ -221,6 +223,9 @@ const char *mfm_last_error(void); /* thread-local detail of the last failure */
 #define MFM_GROUP_MAX_DEVICES 16
 #define MFM_X_AUTO 0u /* one device: direct staging, no RCCL; several: RCCL broadcast */
 #define MFM_X_RCCL 1u /* always through the RCCL broadcast path (exercises the call sequence on a one-GPU box) */
+#define MFM_X_RCCL_ALLGATHER 2u /* RCCL, large-block form for point-to-point xGMI: the root sends 1/S of the block to each of
+                                   its S - 1 peers (ncclSend/ncclRecv, S - 1 links at once), then ncclAllGather in place -
+                                   no single link carries the whole block, as it does along a broadcast's ring */
 
 struct mfm_group_config {
     uint32_t abi_version;       /* MFM_ABI_VERSION */
@@ -249,7 +254,7 @@ int mfm_group_commit(struct mfm_group *g);
 int mfm_group_nr_shards(struct mfm_group *g); /* >= 1 after commit */
 int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_channel, uint32_t *nr_channels, int32_t *device);
 /* host ingest of one block in any MFM_IN_* format.  MFM_E_BUSY when a shard's output ring is full (nothing was
- * staged: fetch/release and retry). */
+ * staged on any shard: fetch/release and retry). */
 int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format);
 /* oldest finished block of every shard into blks[0 .. nr_shards); MFM_E_DONE when nothing is pending */
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks);

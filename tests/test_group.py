@@ -66,13 +66,17 @@ def _drive(grp, iq, block, pkg):
     return np.concatenate(parts, axis=1)
 
 
+def _xmode(b, exchange):
+    return {"direct": b.MFM_X_AUTO, "rccl": b.MFM_X_RCCL, "allgather": b.MFM_X_RCCL_ALLGATHER}[exchange]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["direct", "rccl"])
+@pytest.mark.parametrize("exchange", ["direct", "rccl", "allgather"])
 def test_group_on_one_device_matches_oracle(pkg, ora, exchange):
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=70)
     iq = pkg.synth.synth_iq(96 * 3000 + 321, fs, offs[:4], seed=7)
     b = pkg.binding
-    grp = b.Group(fs, decim, 1 << 16, devices=(0,), exchange=b.MFM_X_RCCL if exchange == "rccl" else b.MFM_X_AUTO)
+    grp = b.Group(fs, decim, 1 << 16, devices=(0,), exchange=_xmode(b, exchange))
     for o, g in zip(offs, gains):
         grp.add_channel(int(o), taps, float(g))
     grp.commit()
@@ -80,7 +84,7 @@ def test_group_on_one_device_matches_oracle(pkg, ora, exchange):
     pcm = _drive(grp, iq, 50000, pkg)
     uses, blocks, moved = grp.exchange_info()
     grp.close()
-    assert uses == (exchange == "rccl") and (blocks > 0) == uses and moved == 0  # one device: nothing leaves it
+    assert uses == (exchange != "direct") and (blocks > 0) == uses and moved == 0  # one device: nothing leaves it
     cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
     cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
     incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
@@ -89,7 +93,7 @@ def test_group_on_one_device_matches_oracle(pkg, ora, exchange):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["direct", "rccl"])
+@pytest.mark.parametrize("exchange", ["direct", "rccl", "allgather"])
 def test_group_exchanges_8bit_blocks_as_bytes(pkg, ora, exchange):
     """RTL-SDR bytes through the group: where every member's kernel can read them as they are the block is staged,
     broadcast (RCCL path: half the bytes of an int16 block) and consumed as bytes; a stream that turns to int16 goes
@@ -97,7 +101,7 @@ def test_group_exchanges_8bit_blocks_as_bytes(pkg, ora, exchange):
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=24)
     rng = np.random.RandomState(9)
     b = pkg.binding
-    grp = b.Group(fs, decim, 1 << 16, devices=(0,), exchange=b.MFM_X_RCCL if exchange == "rccl" else b.MFM_X_AUTO)
+    grp = b.Group(fs, decim, 1 << 16, devices=(0,), exchange=_xmode(b, exchange))
     for o, g in zip(offs, gains):
         grp.add_channel(int(o), taps, float(g))
     grp.commit()
@@ -119,7 +123,7 @@ def test_group_exchanges_8bit_blocks_as_bytes(pkg, ora, exchange):
     _, nblk, moved = grp.exchange_info()
     grp.close()
     assert st["launches_8bit"] == 4 and st["launches"] == 6
-    assert moved == 0 and (nblk == 6) == (exchange == "rccl")
+    assert moved == 0 and (nblk == 6) == (exchange != "direct")
     iq = np.concatenate(iq)
     cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
     cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
@@ -189,3 +193,4 @@ def test_bench_runs_its_distributed_path_on_one_rank(pkg):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
+    assert line["verified"] is True and line["exchange"]["needed_GBps_per_peer"] > 0

@@ -317,3 +317,19 @@ def test_decoder_driver_refuses_loudly_without_a_gpu_and_unknown_protocols(tmp_p
     for proto in ([], ["-m", "FLEX"], ["-m", "POCSAG"]):
         r = subprocess.run(base + proto + [str(tmp_path / "in.pcm")], capture_output=True, text=True, timeout=60)
         assert r.returncode != 0 and "NO-RESAMPLER" in r.stderr, r.stderr[-500:]
+
+
+def test_group_push_is_all_or_nothing_and_fetch_never_sees_half_a_push(tmp_path):
+    """The ORDER of a device group's push and fetch (tsl-sdr_amd/csrc/mfm_group_seq.h, the template mfm_group.hip
+    instantiates over its engines) on fake shards, under ThreadSanitizer: a shard that has no room, refuses its input
+    buffer, a root whose copy fails, a collective that fails, a submit that fails after two shards took the block -
+    nothing is staged or submitted where the reference's all-or-nothing delivery (multifm/receiver.c:78-98) forbids it, a
+    half-submitted block makes every later call fail instead of letting the shards drift apart, and a consumer thread
+    polling fetch while the producer sits between two submits only ever sees "nothing yet" or a whole block (round 2's
+    "shards out of step" failure of the receiver)."""
+    exe = tmp_path / "group_seq_test"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread", "-o", str(exe),
+                        os.path.join(ROOT, "tests", "hoststub", "group_seq_test.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks held" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -65,7 +65,7 @@ class GroupConfig(C.Structure):
                 ("flags", C.c_uint32), ("exchange", C.c_uint32)]
 
 
-MFM_X_AUTO, MFM_X_RCCL = 0, 1
+MFM_X_AUTO, MFM_X_RCCL, MFM_X_RCCL_ALLGATHER = 0, 1, 2
 
 
 class Block(C.Structure):

@@ -1518,6 +1518,15 @@ void *mfm_engine_copy_stream(struct mfm_engine *e)
     return (e && e->committed) ? e->s_in : nullptr;
 }
 
+int mfm_engine_pending_blocks(struct mfm_engine *e)
+{
+    if (!e || !e->committed) {
+        return 0;
+    }
+    std::lock_guard<std::mutex> guard(e->mu);
+    return (int)(e->submit_seq - e->fetch_seq);
+}
+
 int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples)
 {
     if (!e || !e->committed) {

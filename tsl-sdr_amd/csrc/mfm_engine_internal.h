@@ -20,6 +20,8 @@ __attribute__((visibility("hidden"))) int mfm_engine_stage(struct mfm_engine *e,
 __attribute__((visibility("hidden"))) int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_samples);
 /* the stream mfm_engine_stage() queues its work on (hipStream_t) */
 __attribute__((visibility("hidden"))) void *mfm_engine_copy_stream(struct mfm_engine *e);
+/* blocks submitted (with outputs) and not yet released */
+__attribute__((visibility("hidden"))) int mfm_engine_pending_blocks(struct mfm_engine *e);
 /* MFM_OK when a block of nr_samples would find a free output slot, MFM_E_BUSY otherwise */
 __attribute__((visibility("hidden"))) int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples);
 }

@@ -6,9 +6,19 @@
  * channels are independent given the same wideband input.  Here the channel set is cut into contiguous shards, one
  * mfm_engine per device; a delivered block is staged on the first device (H2D; an 8-bit block stays bytes when every
  * member's kernel can read it so, and is widened there otherwise) and
- * broadcast with RCCL - ncclBroadcast over xGMI, in place into every other engine's input buffer - and then every
- * engine submits it.  No other exchange: each device copies its own PCM back, the caller demultiplexes by shard
- * (SURVEY.md section 8e).  One process, one host thread drives all devices (ncclCommInitAll + ncclGroupStart/End).
+ * exchanged with RCCL over xGMI, in place into every other engine's input buffer - and then every engine submits it.
+ * Two forms of the exchange (mfm_group_config::exchange):
+ *   MFM_X_RCCL            ncclBroadcast from the root.  A broadcast is a pipeline along a ring: every byte crosses one
+ *                         link per hop, so the block arrives at the rate of ONE xGMI link (~153 GB/s) whatever the number
+ *                         of GPUs.
+ *   MFM_X_RCCL_ALLGATHER  the root sends 1/S of the block to each of its S - 1 peers (ncclSend / ncclRecv inside one
+ *                         group: S - 1 different links at once), then ncclAllGather in place: every GPU ends up with the
+ *                         whole block, and every GPU both sends and receives on all its links.  The volume per GPU is the
+ *                         same; what changes is that no single link carries the whole block (DESIGN.md section 7 has the
+ *                         numbers: the break-even channel count per GPU drops by the number of links in use).
+ * No other exchange: each device copies its own PCM back, the caller demultiplexes by shard.
+ * One process, one host thread drives all devices (ncclCommInitAll + ncclGroupStart/End).  The ORDER of a push - what
+ * is checked before anything changes, what happens under the lock that fetch takes - is mfm_group_seq.h.
  *
  * RCCL is loaded at run time (dlopen "librccl.so"), and only when a group really exchanges: a single-device group
  * stages and submits directly and never touches it.  MFM_X_RCCL forces the exchange path for a single device too, so
@@ -21,11 +31,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/multifm_hip.h"
 #include "mfm_engine_internal.h"
+#include "mfm_group_seq.h"
 
 extern "C" __attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *msg);
 
@@ -49,6 +61,9 @@ struct RcclApi {
     int (*CommInitAll)(nccl_comm_t *, int, const int *) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -70,10 +85,14 @@ int load_rccl(RcclApi *api)
     api->CommInitAll = reinterpret_cast<decltype(api->CommInitAll)>(dlsym(h, "ncclCommInitAll"));
     api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api->Broadcast = reinterpret_cast<decltype(api->Broadcast)>(dlsym(h, "ncclBroadcast"));
+    api->AllGather = reinterpret_cast<decltype(api->AllGather)>(dlsym(h, "ncclAllGather"));
+    api->Send = reinterpret_cast<decltype(api->Send)>(dlsym(h, "ncclSend"));
+    api->Recv = reinterpret_cast<decltype(api->Recv)>(dlsym(h, "ncclRecv"));
     api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(dlsym(h, "ncclGroupStart"));
     api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!api->CommInitAll || !api->CommDestroy || !api->Broadcast || !api->GroupStart || !api->GroupEnd) {
+    if (!api->CommInitAll || !api->CommDestroy || !api->Broadcast || !api->GroupStart || !api->GroupEnd || !api->AllGather ||
+        !api->Send || !api->Recv) {
         dlclose(h);
         return gfail(MFM_E_DEVICE, "librccl.so lacks a required entry point");
     }
@@ -102,6 +121,8 @@ struct mfm_group {
     std::vector<nccl_comm_t> comm;
     std::vector<hipStream_t> xs; /* exchange stream per shard (shard 0: the root engine's copy stream) */
     uint64_t blocks = 0, bytes_exchanged = 0;
+    bool broken = false; /* a push failed after the first shard had taken the block (mfm_group_seq.h) */
+    std::mutex mu;       /* push's submit loop against fetch's "does every shard hold a block" */
 };
 
 extern "C" {
@@ -184,6 +205,11 @@ static void group_release(mfm_group *g)
         mfm_engine_destroy(&g->eng[i]);
     }
     g->eng.clear();
+    /* a group whose commit failed may be committed again: nothing of the failed attempt may survive */
+    g->dev.clear();
+    g->first.clear();
+    g->count.clear();
+    g->broken = false;
     g->committed = false;
 }
 
@@ -270,7 +296,11 @@ int mfm_group_commit(struct mfm_group *g)
         return rc; /* the failing call left its message */
     }
     const size_t S = g->eng.size();
-    g->exchange = S > 1 || g->cfg.exchange == MFM_X_RCCL;
+    if (g->cfg.exchange > MFM_X_RCCL_ALLGATHER) {
+        group_release(g);
+        return gfail(MFM_E_INVAL, "unknown exchange mode %u", g->cfg.exchange);
+    }
+    g->exchange = S > 1 || g->cfg.exchange != MFM_X_AUTO;
     if (g->exchange) {
         rc = load_rccl(&g->rccl);
         if (rc != MFM_OK) {
@@ -321,6 +351,90 @@ int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_ch
     return MFM_OK;
 }
 
+} /* extern "C" */
+
+namespace {
+
+/* the group's shards behind the operations mfm_group_seq.h sequences */
+struct GroupOps {
+    mfm_group *g;
+    size_t shards() { return g->eng.size(); }
+    int room(size_t i, size_t n) { return mfm_engine_output_room(g->eng[i], n); }
+    bool takes_bytes(size_t i, int fmt, size_t n) { return 0 != mfm_engine_can_take_bytes(g->eng[i], fmt, n); }
+    int acquire(size_t i, bool raw, int fmt, void **dst, size_t *cap)
+    {
+        return raw ? mfm_engine_acquire_input_bytes(g->eng[i], fmt, dst, cap) : mfm_engine_acquire_input(g->eng[i], dst, cap);
+    }
+    int stage_root(const void *data, size_t n, int fmt, bool raw, void **d_root)
+    {
+        return mfm_engine_stage(g->eng[0], data, n, fmt, raw ? 1 : 0, d_root);
+    }
+    int nccl_fail(int nrc, const char *what, size_t bytes)
+    {
+        return gfail(MFM_E_DEVICE, "%s of a %zu-byte block failed: %s", what, bytes,
+                     g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?");
+    }
+    /* the wideband block, as bytes, from the root's input buffer into every member's input buffer.  One thread drives
+     * all devices: the calls of every step sit in one RCCL group. */
+    int exchange(void *d_root, void *const *dst, size_t bytes)
+    {
+        const size_t S = g->eng.size();
+        const RcclApi &r = g->rccl;
+        /* all-gather form: equal parts of whole 16-byte units; what does not divide goes by broadcast behind it */
+        const size_t part = g->cfg.exchange == MFM_X_RCCL_ALLGATHER ? (bytes / S) & ~(size_t)15 : 0;
+        const size_t even = part * S;
+        int nrc = 0, nre = 0;
+        if (part) {
+            /* 1. part i of the block to peer i, over S - 1 different links at once (the root keeps part 0 where it is) */
+            nrc = r.GroupStart();
+            for (size_t i = 1; i < S && nrc == 0; i++) {
+                nrc = r.Send(static_cast<const uint8_t *>(d_root) + i * part, part, kNcclInt8, (int)i, g->comm[0], g->xs[0]);
+                nrc = nrc ? nrc : r.Recv(static_cast<uint8_t *>(dst[i]) + i * part, part, kNcclInt8, 0, g->comm[i], g->xs[i]);
+            }
+            nre = r.GroupEnd();
+            nrc = nrc ? nrc : nre;
+            if (nrc != 0) {
+                return nccl_fail(nrc, "the scatter (ncclSend/ncclRecv)", bytes);
+            }
+            /* 2. all-gather in place: rank i contributes its part i, every rank's buffer ends up whole */
+            nrc = r.GroupStart();
+            for (size_t i = 0; i < S && nrc == 0; i++) {
+                nrc = r.AllGather(static_cast<const uint8_t *>(dst[i]) + i * part, dst[i], part, kNcclInt8, g->comm[i], g->xs[i]);
+            }
+            nre = r.GroupEnd();
+            nrc = nrc ? nrc : nre;
+            if (nrc != 0) {
+                return nccl_fail(nrc, "ncclAllGather", bytes);
+            }
+        }
+        if (even < bytes) {
+            nrc = r.GroupStart();
+            for (size_t i = 0; i < S && nrc == 0; i++) {
+                nrc = r.Broadcast(static_cast<const uint8_t *>(d_root) + even, static_cast<uint8_t *>(dst[i]) + even, bytes - even,
+                                  kNcclInt8, 0, g->comm[i], g->xs[i]);
+            }
+            nre = r.GroupEnd();
+            nrc = nrc ? nrc : nre;
+            if (nrc != 0) {
+                return nccl_fail(nrc, "ncclBroadcast", bytes);
+            }
+        }
+        return MFM_OK;
+    }
+    int submit(size_t i, size_t n) { return mfm_engine_submit(g->eng[i], n, g->xs[i], 1); }
+    int pending(size_t i) { return mfm_engine_pending_blocks(g->eng[i]); }
+    int fetch(size_t i, mfm_block *blk) { return mfm_engine_fetch(g->eng[i], blk); }
+    uint64_t first_output(const mfm_block &b) { return b.first_output; }
+    size_t nr_outputs(const mfm_block &b) { return b.nr_outputs; }
+    void lock() { g->mu.lock(); }
+    void unlock() { g->mu.unlock(); }
+    int fail(int code, const char *what, size_t shard) { return gfail(code, "%s (shard %zu)", what, shard); }
+};
+
+} /* namespace */
+
+extern "C" {
+
 int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format)
 {
     if (!g || !data) {
@@ -329,63 +443,18 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
     if (!g->committed) {
         return gfail(MFM_E_STATE, "commit first");
     }
-    const size_t S = g->eng.size();
     if (!g->exchange) {
         return format == MFM_IN_CS16 ? mfm_engine_push(g->eng[0], static_cast<const int16_t *>(data), nr_samples)
                                      : mfm_engine_push_bytes(g->eng[0], data, nr_samples, format);
     }
-    /* every member must have room for the block before anything is staged: the members move in lock step */
-    for (size_t i = 1; i < S; i++) {
-        const int rc = mfm_engine_output_room(g->eng[i], nr_samples);
-        if (rc != MFM_OK) {
-            return rc;
-        }
+    GroupOps ops{ g };
+    size_t bytes = 0;
+    const int rc = mfm_group_push_seq(ops, &g->broken, data, nr_samples, format, format != MFM_IN_CS16, &bytes);
+    if (rc == MFM_OK) {
+        g->blocks++;
+        g->bytes_exchanged += bytes * (g->eng.size() - 1);
     }
-    /* an 8-bit block crosses the links as bytes when every member's kernel can read it so (half the exchange) */
-    bool raw = format != MFM_IN_CS16;
-    for (size_t i = 0; i < S && raw; i++) {
-        raw = 0 != mfm_engine_can_take_bytes(g->eng[i], format, nr_samples);
-    }
-    void *d_root = nullptr;
-    int rc = mfm_engine_stage(g->eng[0], data, nr_samples, format, raw ? 1 : 0, &d_root); /* MFM_E_BUSY: nothing staged yet */
-    if (rc != MFM_OK) {
-        return rc;
-    }
-    std::vector<void *> dst(S, nullptr);
-    dst[0] = d_root;
-    for (size_t i = 1; i < S; i++) {
-        size_t cap = 0;
-        rc = raw ? mfm_engine_acquire_input_bytes(g->eng[i], format, &dst[i], &cap)
-                 : mfm_engine_acquire_input(g->eng[i], &dst[i], &cap);
-        if (rc != MFM_OK) {
-            return rc;
-        }
-        if (cap < nr_samples) {
-            return gfail(MFM_E_INVAL, "shard %zu cannot take %zu samples", i, nr_samples);
-        }
-    }
-    /* the wideband block, as bytes, from the root's input buffer into every member's input buffer (the root's own
-     * broadcast is in place).  One thread drives all devices: the calls sit in one RCCL group. */
-    const size_t bytes = nr_samples * (raw ? 2 : 4);
-    int nrc = g->rccl.GroupStart();
-    for (size_t i = 0; i < S && nrc == 0; i++) {
-        nrc = g->rccl.Broadcast(d_root, dst[i], bytes, kNcclInt8, 0, g->comm[i], g->xs[i]);
-    }
-    const int nre = g->rccl.GroupEnd();
-    nrc = nrc ? nrc : nre;
-    if (nrc != 0) {
-        return gfail(MFM_E_DEVICE, "ncclBroadcast of a %zu-byte block failed: %s", bytes,
-                     g->rccl.GetErrorString ? g->rccl.GetErrorString(nrc) : "?");
-    }
-    for (size_t i = 0; i < S; i++) {
-        rc = mfm_engine_submit(g->eng[i], nr_samples, g->xs[i], 1);
-        if (rc != MFM_OK) {
-            return rc; /* cannot happen after the checks above short of a device error */
-        }
-    }
-    g->blocks++;
-    g->bytes_exchanged += bytes * (S - 1);
-    return MFM_OK;
+    return rc;
 }
 
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks)
@@ -396,19 +465,8 @@ int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks)
     if (!g->committed) {
         return gfail(MFM_E_STATE, "commit first");
     }
-    for (size_t i = 0; i < g->eng.size(); i++) {
-        const int rc = mfm_engine_fetch(g->eng[i], &blks[i]);
-        if (rc != MFM_OK) {
-            if (rc == MFM_E_DONE && i != 0) {
-                return gfail(MFM_E_STATE, "shards out of step: shard %zu has no block where shard 0 has one", i);
-            }
-            return rc;
-        }
-        if (blks[i].first_output != blks[0].first_output || blks[i].nr_outputs != blks[0].nr_outputs) {
-            return gfail(MFM_E_STATE, "shards out of step at output %llu", (unsigned long long)blks[0].first_output);
-        }
-    }
-    return MFM_OK;
+    GroupOps ops{ g };
+    return mfm_group_fetch_seq(ops, &g->broken, blks);
 }
 
 int mfm_group_release(struct mfm_group *g)
