@@ -547,6 +547,19 @@ struct mfm_flex {
 
 extern "C" {
 
+/* inside mfm_flex_create(): a device failure releases what exists and leaves *pf NULL */
+#define FX_TRY_C(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t err_c_ = (expr);                                                                          \
+        if (err_c_ != hipSuccess) {                                                                          \
+            char msg_c_[256];                                                                                \
+            snprintf(msg_c_, sizeof(msg_c_), "%s failed: %s", #expr, hipGetErrorString(err_c_));             \
+            mfm_internal_set_error(msg_c_);                                                                  \
+            mfm_flex_destroy(pf);                                                                            \
+            return MFM_E_DEVICE;                                                                             \
+        }                                                                                                    \
+    } while (0)
+
 int mfm_flex_create(struct mfm_flex **pf, const struct mfm_flex_config *cfg)
 {
     if (!pf || !cfg) {
@@ -578,12 +591,12 @@ int mfm_flex_create(struct mfm_flex **pf, const struct mfm_flex_config *cfg)
     f->sstride = f->mstride / 64 + 2;
     const size_t C = cfg->nr_channels;
     *pf = f;
-    FX_TRY(hipSetDevice(cfg->device));
-    FX_TRY(hipMalloc(&f->d_hist, C * FX_HIST * sizeof(int16_t)));
-    FX_TRY(hipMemset(f->d_hist, 0, C * FX_HIST * sizeof(int16_t)));
-    FX_TRY(hipMalloc(&f->d_m, C * f->mstride * sizeof(uint32_t)));
-    FX_TRY(hipMalloc(&f->d_sum, C * f->sstride * sizeof(uint64_t)));
-    FX_TRY(hipMalloc(&f->d_st, C * sizeof(FxState)));
+    FX_TRY_C(hipSetDevice(cfg->device));
+    FX_TRY_C(hipMalloc(&f->d_hist, C * FX_HIST * sizeof(int16_t)));
+    FX_TRY_C(hipMemset(f->d_hist, 0, C * FX_HIST * sizeof(int16_t)));
+    FX_TRY_C(hipMalloc(&f->d_m, C * f->mstride * sizeof(uint32_t)));
+    FX_TRY_C(hipMalloc(&f->d_sum, C * f->sstride * sizeof(uint64_t)));
+    FX_TRY_C(hipMalloc(&f->d_st, C * sizeof(FxState)));
     {
         /* pager_flex_new (:1371): registers zero-filled "before sample 0", so the search opens at sample 310 */
         std::vector<FxState> st(C);
@@ -592,14 +605,14 @@ int mfm_flex_create(struct mfm_flex **pf, const struct mfm_flex_config *cfg)
             st[c].mode = FX_SEARCH;
             st[c].p = FX_DEAD - 1;
         }
-        FX_TRY(hipMemcpy(f->d_st, st.data(), C * sizeof(FxState), hipMemcpyHostToDevice));
+        FX_TRY_C(hipMemcpy(f->d_st, st.data(), C * sizeof(FxState), hipMemcpyHostToDevice));
     }
-    FX_TRY(hipMalloc(&f->d_ev, C * f->max_ev * sizeof(mfm_flex_event)));
-    FX_TRY(hipMalloc(&f->d_fw, C * f->max_fw * sizeof(mfm_flex_frame_words)));
-    FX_TRY(hipMalloc(&f->d_fd, C * f->max_fw * sizeof(FxFrameDesc)));
-    FX_TRY(hipMalloc(&f->d_counts, C * 2 * sizeof(uint32_t)));
-    FX_TRY(hipMemset(f->d_counts, 0, C * 2 * sizeof(uint32_t)));
-    FX_TRY(hipDeviceSynchronize());
+    FX_TRY_C(hipMalloc(&f->d_ev, C * f->max_ev * sizeof(mfm_flex_event)));
+    FX_TRY_C(hipMalloc(&f->d_fw, C * f->max_fw * sizeof(mfm_flex_frame_words)));
+    FX_TRY_C(hipMalloc(&f->d_fd, C * f->max_fw * sizeof(FxFrameDesc)));
+    FX_TRY_C(hipMalloc(&f->d_counts, C * 2 * sizeof(uint32_t)));
+    FX_TRY_C(hipMemset(f->d_counts, 0, C * 2 * sizeof(uint32_t)));
+    FX_TRY_C(hipDeviceSynchronize());
     return MFM_OK;
 }
 

@@ -215,6 +215,18 @@ struct mfm_mm {
 
 extern "C" {
 
+/* inside mfm_mm_create(): a device failure releases what exists and leaves *pm NULL */
+#define MM_TRY_C(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t err_ = (expr);                                                                            \
+        if (err_ != hipSuccess) {                                                                            \
+            snprintf(g_mm_error, sizeof(g_mm_error), "%s failed: %s", #expr, hipGetErrorString(err_));       \
+            mfm_internal_set_error(g_mm_error);                                                              \
+            mfm_mm_destroy(pm);                                                                              \
+            return MFM_E_DEVICE;                                                                             \
+        }                                                                                                    \
+    } while (0)
+
 int mfm_mm_create(struct mfm_mm **pm, const struct mfm_mm_config *cfg)
 {
     if (!pm || !cfg) {
@@ -239,25 +251,32 @@ int mfm_mm_create(struct mfm_mm **pm, const struct mfm_mm_config *cfg)
         return MFM_E_NOMEM;
     }
     m->cfg = *cfg;
-    /* every step advances by at least floor(error_min + km * sample) >= ... samples; sized for steps of
-     * error_min / 2, and the kernel never writes past it */
-    m->dec_cap = (uint32_t)((double)cfg->max_in_samples / (cfg->error_min * 0.5) + 16.0);
+    /* no step is shorter than floor(error_min - |km| * 32768) >= 1 samples (:87-96; the check above): a row is sized
+     * for a block walked in steps of that length - the worst any accepted configuration can do - and the kernel never
+     * writes past it */
+    {
+        const double min_step = floor((double)cfg->error_min - fabs((double)cfg->km) * 32768.0);
+        m->dec_cap = (uint32_t)((double)cfg->max_in_samples / (min_step < 1.0 ? 1.0 : min_step) + 16.0);
+    }
     *pm = m;
-    MM_TRY(hipSetDevice(cfg->device));
-    MM_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_mm_kernel<true>),
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        mfm_mm_destroy(pm); /* an error means *pm == NULL, and nothing of a half-built object survives */
+        return MFM_E_DEVICE;
+    }
+    MM_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_mm_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
-    MM_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_mm_kernel<false>),
+    MM_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void *>(mfm_mm_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_LDS));
     m->dec_pitch = m->dec_cap + 8u;
-    MM_TRY(hipMalloc(&m->d_dec, (size_t)cfg->nr_channels * m->dec_pitch * 2));
-    MM_TRY(hipMalloc(&m->d_counts, (size_t)cfg->nr_channels * 4));
+    MM_TRY_C(hipMalloc(&m->d_dec, (size_t)cfg->nr_channels * m->dec_pitch * 2));
+    MM_TRY_C(hipMalloc(&m->d_counts, (size_t)cfg->nr_channels * 4));
     /* no step is shorter than floor(error_min - |km| * 32768) (:87-96); one below it for the rounding of the sums */
     m->smin = (uint32_t)floorf(cfg->error_min - fabsf(cfg->km) * 32768.0f) - 1u;
-    MM_TRY(hipMalloc(&m->d_st, (size_t)cfg->nr_channels * sizeof(MmState)));
+    MM_TRY_C(hipMalloc(&m->d_st, (size_t)cfg->nr_channels * sizeof(MmState)));
     /* mm_init, mueller_muller.c:17-26 */
     MmState init{ cfg->samples_per_bit, cfg->samples_per_bit, 0.0f, 0.0f };
     for (uint32_t c = 0; c < cfg->nr_channels; c++) {
-        MM_TRY(hipMemcpy(m->d_st + c, &init, sizeof(init), hipMemcpyHostToDevice));
+        MM_TRY_C(hipMemcpy(m->d_st + c, &init, sizeof(init), hipMemcpyHostToDevice));
     }
     return MFM_OK;
 }

@@ -18,86 +18,100 @@
 #define SAMPLES_PER_BUF 4096 /* multifm/file_if.c:18 */
 #define FL_MSG(sev, sys, msg, ...) MESSAGE("FILEIF", sev, sys, msg, ##__VA_ARGS__)
 
-enum file_worker_sample_format {
-    FILE_WORKER_SAMPLE_FORMAT_UNKNOWN = 0,
-    FILE_WORKER_SAMPLE_FORMAT_S8,
-    FILE_WORKER_SAMPLE_FORMAT_U8,
-    FILE_WORKER_SAMPLE_FORMAT_S16,
+struct file_worker_thread;
+
+/* How one capture format turns a read of raw bytes into what a sample_buf carries.  `widen` is the host-side conversion
+ * (NULL: the bytes are the samples); `raw_type` is the tag under which the engine takes the bytes as they are and widens
+ * them on the device ("gpuUnpack", default on: half the PCIe traffic). */
+struct file_format {
+    const char *name;            /* "fileFormat" value; matched as a prefix, like the reference's strncmp */
+    size_t bytes_per_sample;     /* one complex sample on disk */
+    enum sample_type raw_type;   /* for 8-bit formats: the sample_buf tag of the unwidened bytes */
+    void (*widen)(const int8_t *in, size_t nr_values, int16_t *out);
 };
+
+static void _widen_cs8(const int8_t *in, size_t nr_values, int16_t *out)
+{
+    for (size_t i = 0; i < nr_values; i++) {
+        out[i] = in[i]; /* multifm/file_if.c:91-103: sign extension */
+    }
+}
+
+static void _widen_cu8(const int8_t *in, size_t nr_values, int16_t *out)
+{
+    /* multifm/file_if.c:122,139-151: the bytes are read as SIGNED, 127 is subtracted, and the remainder loop behind the
+     * four-at-a-time body stores the bare cast - both are behaviour, so both are kept */
+    const size_t body = nr_values & ~(size_t)3;
+    for (size_t i = 0; i < body; i++) {
+        out[i] = (int16_t)((int16_t)in[i] - 127);
+    }
+    for (size_t i = body; i < nr_values; i++) {
+        out[i] = in[i];
+    }
+}
+
+static const struct file_format file_formats[] = {
+    { "cs16", 2 * sizeof(int16_t), COMPLEX_INT_16, NULL },
+    { "cs8", 2 * sizeof(int8_t), RAW_COMPLEX_INT_8, _widen_cs8 },
+    { "cu8", 2 * sizeof(int8_t), RAW_COMPLEX_FILE_UINT_8, _widen_cu8 },
+};
+
+static const struct file_format *_file_format_lookup(const char *name)
+{
+    for (size_t i = 0; i < sizeof(file_formats) / sizeof(file_formats[0]); i++) {
+        if (0 == strncmp(name, file_formats[i].name, strlen(file_formats[i].name))) {
+            return &file_formats[i];
+        }
+    }
+    return NULL;
+}
 
 struct file_worker_thread {
     struct receiver rcvr;
     int fd;
-    enum file_worker_sample_format sample_format;
-    void *bounce_buf;
-    size_t bounce_buf_bytes;
-    bool gpu_unpack; /* device stanza "gpuUnpack" (default true): widen 8-bit formats on the GPU */
+    const struct file_format *fmt;
+    int8_t *bounce;   /* one read of an 8-bit format that is widened on the host; NULL otherwise */
+    bool gpu_unpack;  /* device stanza "gpuUnpack" (default true): widen 8-bit formats on the GPU */
 };
 
-/* read until `want` bytes or end of file (a pipe may return short reads) */
-static aresult_t _file_read_full(int fd, void *dst, size_t want, size_t *got)
+/* read until `want` bytes or end of file (a pipe may return short reads); -1 on a read error */
+static ssize_t _file_read_full(int fd, void *dst, size_t want)
 {
     size_t n = 0;
     while (n < want) {
-        ssize_t r = read(fd, (uint8_t *)dst + n, want - n);
+        const ssize_t r = read(fd, (uint8_t *)dst + n, want - n);
+        if (r < 0 && EINTR == errno) {
+            continue;
+        }
         if (r < 0) {
-            if (errno == EINTR) {
-                continue;
-            }
             FL_MSG(SEV_FATAL, "FILE-READ-ERROR", "Failed to read data from file, reason: %s (%d)", strerror(errno), errno);
-            return A_E_INVAL;
+            return -1;
         }
         if (0 == r) {
             break;
         }
         n += (size_t)r;
     }
-    *got = n;
-    return A_OK;
+    return (ssize_t)n;
 }
 
-static aresult_t _file_fill(struct file_worker_thread *thr, struct sample_buf *sbuf)
+/* one buffer's worth of the capture into sbuf; false at end of input or on a read error */
+static bool _file_fill(struct file_worker_thread *thr, struct sample_buf *sbuf)
 {
-    size_t nr_read = 0;
-    int16_t *out = (int16_t *)sbuf->data_buf;
-
-    if (thr->sample_format == FILE_WORKER_SAMPLE_FORMAT_S16) {
-        if (FAILED(_file_read_full(thr->fd, sbuf->data_buf, SAMPLES_PER_BUF * 2 * sizeof(int16_t), &nr_read))) {
-            return A_E_INVAL;
-        }
-        sbuf->nr_samples = (uint32_t)(nr_read / (2 * sizeof(int16_t)));
-        return A_OK;
+    const struct file_format *f = thr->fmt;
+    const size_t want = SAMPLES_PER_BUF * f->bytes_per_sample;
+    const bool on_host = NULL != f->widen && !thr->gpu_unpack;
+    const ssize_t got = _file_read_full(thr->fd, on_host ? (void *)thr->bounce : (void *)sbuf->data_buf, want);
+    if (got <= 0) {
+        return false;
     }
-
-    if (thr->gpu_unpack) {
-        /* hand the bytes over as they are; the engine widens them on the device (half the PCIe traffic) */
-        if (FAILED(_file_read_full(thr->fd, sbuf->data_buf, thr->bounce_buf_bytes, &nr_read))) {
-            return A_E_INVAL;
-        }
-        sbuf->sample_type = thr->sample_format == FILE_WORKER_SAMPLE_FORMAT_S8 ? RAW_COMPLEX_INT_8 : RAW_COMPLEX_FILE_UINT_8;
-        sbuf->nr_samples = (uint32_t)(nr_read / 2);
-        return A_OK;
+    if (on_host) {
+        f->widen(thr->bounce, (size_t)got, (int16_t *)sbuf->data_buf);
+    } else if (NULL != f->widen) {
+        sbuf->sample_type = f->raw_type; /* the engine widens on the device, exactly as `widen` would */
     }
-    if (FAILED(_file_read_full(thr->fd, thr->bounce_buf, thr->bounce_buf_bytes, &nr_read))) {
-        return A_E_INVAL;
-    }
-    const int8_t *in = thr->bounce_buf; /* signed for both 8-bit formats, as in the reference */
-    if (thr->sample_format == FILE_WORKER_SAMPLE_FORMAT_S8) {
-        for (size_t i = 0; i < nr_read; i++) {
-            out[i] = in[i];
-        }
-    } else {
-        /* the reference's remainder loop stores the last nr_read % 4 values without the subtraction (:146-150) */
-        const size_t body = nr_read - nr_read % 4;
-        for (size_t i = 0; i < body; i++) {
-            out[i] = (int16_t)((int16_t)in[i] - 127);
-        }
-        for (size_t i = body; i < nr_read; i++) {
-            out[i] = in[i];
-        }
-    }
-    sbuf->nr_samples = (uint32_t)(nr_read / 2);
-    return A_OK;
+    sbuf->nr_samples = (uint32_t)((size_t)got / f->bytes_per_sample);
+    return 0 != sbuf->nr_samples;
 }
 
 static aresult_t _file_worker_thread_work(struct receiver *rx)
@@ -107,10 +121,10 @@ static aresult_t _file_worker_thread_work(struct receiver *rx)
     while (receiver_thread_running(rx)) {
         struct sample_buf *sbuf = NULL;
         if (FAILED(receiver_sample_buf_alloc(rx, &sbuf))) {
-            usleep(1000);
+            usleep(1000); /* the pool is empty (dropped and counted there); a file has no clock of its own to wait on */
             continue;
         }
-        if (FAILED(_file_fill(thr, sbuf)) || 0 == sbuf->nr_samples) {
+        if (!_file_fill(thr, sbuf)) {
             /* end of input: give the buffer back untouched and stop */
             sbuf->refcount = 1;
             TSL_BUG_IF_FAILED(sample_buf_decref(sbuf));
@@ -122,91 +136,91 @@ static aresult_t _file_worker_thread_work(struct receiver *rx)
     return A_OK;
 }
 
+static void _file_worker_release(struct file_worker_thread *thr)
+{
+    if (thr->fd >= 0) {
+        close(thr->fd);
+        thr->fd = -1;
+    }
+    if (NULL != thr->bounce) {
+        TFREE(thr->bounce);
+    }
+}
+
 static aresult_t _file_worker_thread_cleanup(struct receiver *rx)
 {
-    struct file_worker_thread *fwt = BL_CONTAINER_OF(rx, struct file_worker_thread, rcvr);
-    if (fwt->fd >= 0) {
-        close(fwt->fd);
-        fwt->fd = -1;
+    _file_worker_release(BL_CONTAINER_OF(rx, struct file_worker_thread, rcvr));
+    return A_OK;
+}
+
+/* what the "device" stanza says: {type: "file", filename, fileFormat in cs16 | cs8 | cu8 [, gpuUnpack]} */
+struct file_source_desc {
+    const char *filename;
+    const struct file_format *fmt;
+    bool gpu_unpack;
+};
+
+static aresult_t _file_source_parse(struct config *cfg, struct file_source_desc *d)
+{
+    struct config dev = CONFIG_INIT_EMPTY;
+    const char *format = NULL;
+
+    if (FAILED(config_get(cfg, &dev, "device"))) {
+        FL_MSG(SEV_FATAL, "MISSING-DEVICE-STANZA", "Missing 'device' stanza of configuration, aborting.");
+        return A_E_INVAL;
     }
-    if (NULL != fwt->bounce_buf) {
-        TFREE(fwt->bounce_buf);
+    if (FAILED(config_get_string(&dev, &d->filename, "filename"))) {
+        FL_MSG(SEV_FATAL, "CONFIG-NO-FILE", "Need to specify a filename in the device config, aborting.");
+        return A_E_INVAL;
     }
+    if (FAILED(config_get_string(&dev, &format, "fileFormat"))) {
+        FL_MSG(SEV_FATAL, "CONFIG-NO-FORMAT", "Need to specify a fileFormat (cs16, cs8, cu8), aborting.");
+        return A_E_INVAL;
+    }
+    if (NULL == (d->fmt = _file_format_lookup(format))) {
+        FL_MSG(SEV_FATAL, "UNSUPPORTED-FILE-FORMAT", "File format [%s] is not supported, aborting.", format);
+        return A_E_INVAL;
+    }
+    d->gpu_unpack = true;
+    (void)config_get_boolean(&dev, &d->gpu_unpack, "gpuUnpack");
     return A_OK;
 }
 
 aresult_t file_worker_thread_new(struct receiver **pthr, struct config *cfg)
 {
-    aresult_t ret = A_OK;
+    struct file_source_desc desc = { NULL, NULL, true };
     struct file_worker_thread *thr = NULL;
-    int fd = -1;
-    const char *filename = NULL, *format = NULL;
-    struct config devcfg = CONFIG_INIT_EMPTY;
-    enum file_worker_sample_format sample_format = FILE_WORKER_SAMPLE_FORMAT_UNKNOWN;
 
     TSL_ASSERT_ARG(NULL != pthr);
     TSL_ASSERT_ARG(NULL != cfg);
     *pthr = NULL;
 
-    if (FAILED(ret = config_get(cfg, &devcfg, "device"))) {
-        FL_MSG(SEV_FATAL, "MISSING-DEVICE-STANZA", "Missing 'device' stanza of configuration, aborting.");
-        goto done;
+    aresult_t ret = _file_source_parse(cfg, &desc);
+    if (FAILED(ret)) {
+        return ret;
     }
-    if (FAILED(ret = config_get_string(&devcfg, &filename, "filename"))) {
-        FL_MSG(SEV_FATAL, "CONFIG-NO-FILE", "Need to specify a filename in the device config, aborting.");
-        goto done;
-    }
-    if (FAILED(ret = config_get_string(&devcfg, &format, "fileFormat"))) {
-        FL_MSG(SEV_FATAL, "CONFIG-NO-FORMAT", "Need to specify a fileFormat (cs16, cs8, cu8), aborting.");
-        goto done;
-    }
-    if (!strncmp(format, "cs16", 4)) {
-        sample_format = FILE_WORKER_SAMPLE_FORMAT_S16;
-    } else if (!strncmp(format, "cs8", 3)) {
-        sample_format = FILE_WORKER_SAMPLE_FORMAT_S8;
-    } else if (!strncmp(format, "cu8", 3)) {
-        sample_format = FILE_WORKER_SAMPLE_FORMAT_U8;
-    } else {
-        FL_MSG(SEV_FATAL, "UNSUPPORTED-FILE-FORMAT", "File format [%s] is not supported, aborting.", format);
-        ret = A_E_INVAL;
-        goto done;
-    }
-    FL_MSG(SEV_INFO, "CREATING-FILE-SOURCE", "Sourcing samples in format %s from file [%s]", format, filename);
+    FL_MSG(SEV_INFO, "CREATING-FILE-SOURCE", "Sourcing samples in format %s from file [%s]", desc.fmt->name, desc.filename);
 
-    if (0 > (fd = open(filename, O_RDONLY))) {
-        FL_MSG(SEV_FATAL, "BAD-FILE", "Unable to open file [%s], aborting. Reason: %s (%d)", filename, strerror(errno), errno);
-        ret = A_E_INVAL;
-        goto done;
-    }
     if (FAILED(ret = TZAALLOC(thr, SYS_CACHE_LINE_LENGTH))) {
-        goto done;
+        return ret;
     }
-    thr->fd = fd;
-    thr->sample_format = sample_format;
-    thr->gpu_unpack = true;
-    (void)config_get_boolean(&devcfg, &thr->gpu_unpack, "gpuUnpack");
-    if (sample_format != FILE_WORKER_SAMPLE_FORMAT_S16) {
-        thr->bounce_buf_bytes = SAMPLES_PER_BUF * 2 * sizeof(int8_t);
-        if (FAILED(ret = TACALLOC(&thr->bounce_buf, SAMPLES_PER_BUF, 2 * sizeof(int8_t), SYS_CACHE_LINE_LENGTH))) {
-            goto done;
-        }
+    thr->fmt = desc.fmt;
+    thr->gpu_unpack = desc.gpu_unpack;
+    thr->fd = open(desc.filename, O_RDONLY);
+    if (thr->fd < 0) {
+        FL_MSG(SEV_FATAL, "BAD-FILE", "Unable to open file [%s], aborting. Reason: %s (%d)", desc.filename, strerror(errno), errno);
+        ret = A_E_INVAL;
+    } else if (NULL != desc.fmt->widen && !desc.gpu_unpack) {
+        ret = TACALLOC(&thr->bounce, SAMPLES_PER_BUF, desc.fmt->bytes_per_sample, SYS_CACHE_LINE_LENGTH);
     }
-    if (FAILED(ret = receiver_init(&thr->rcvr, cfg, _file_worker_thread_work, _file_worker_thread_cleanup, SAMPLES_PER_BUF))) {
-        goto done;
+    if (!FAILED(ret)) {
+        ret = receiver_init(&thr->rcvr, cfg, _file_worker_thread_work, _file_worker_thread_cleanup, SAMPLES_PER_BUF);
+    }
+    if (FAILED(ret)) {
+        _file_worker_release(thr);
+        TFREE(thr);
+        return ret;
     }
     *pthr = &thr->rcvr;
-
-done:
-    if (FAILED(ret)) {
-        if (NULL != thr) {
-            if (NULL != thr->bounce_buf) {
-                TFREE(thr->bounce_buf);
-            }
-            TFREE(thr);
-        }
-        if (fd != -1) {
-            close(fd);
-        }
-    }
-    return ret;
+    return A_OK;
 }

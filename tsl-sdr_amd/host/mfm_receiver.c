@@ -10,6 +10,7 @@
 #include <fcntl.h>
 #include <math.h>
 #include <stdatomic.h>
+#include <time.h>
 #include <unistd.h>
 
 #define MFM_MSG(sev, sys, msg, ...) MESSAGE("MULTIFM", sev, sys, msg, ##__VA_ARGS__)
@@ -39,6 +40,50 @@ static void list_del(struct list_entry *e)
 #define list_for_each_type(pos, head, member)                                                                \
     for (pos = BL_CONTAINER_OF((head)->next, __typeof__(*pos), member); &pos->member != (head);              \
          pos = BL_CONTAINER_OF(pos->member.next, __typeof__(*pos), member))
+
+/* ---- doorbells (mfm_receiver.h) ---- */
+
+static void _bell_init(struct mfm_doorbell *b)
+{
+    TSL_BUG_ON(0 != sem_init(&b->sem, 0, 0));
+    atomic_store(&b->sleeping, 0);
+}
+
+/* producer side: never blocks, one atomic exchange when nobody sleeps */
+static void _bell_ring(struct mfm_doorbell *b)
+{
+    if (1 == atomic_exchange(&b->sleeping, 0)) {
+        (void)sem_post(&b->sem);
+    }
+}
+
+/* waiter side: _bell_arm(), look for work once more, then _bell_sleep() - a ring between the two is not lost.  The sleep is
+ * bounded so that a thread also notices a shutdown request that nobody rang for. */
+static void _bell_arm(struct mfm_doorbell *b)
+{
+    atomic_store(&b->sleeping, 1);
+}
+
+static void _bell_disarm(struct mfm_doorbell *b)
+{
+    if (0 == atomic_exchange(&b->sleeping, 0)) {
+        (void)sem_trywait(&b->sem); /* a ring slipped in: take its post so that the next sleep does not return at once */
+    }
+}
+
+static void _bell_sleep(struct mfm_doorbell *b, unsigned max_ms)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_nsec += (long)max_ms * 1000000L;
+    ts.tv_sec += ts.tv_nsec / 1000000000L;
+    ts.tv_nsec %= 1000000000L;
+    while (0 != sem_timedwait(&b->sem, &ts) && EINTR == errno) {
+    }
+    atomic_store(&b->sleeping, 0);
+}
+
+#define MFM_IDLE_MS 50u /* how long a thread sleeps at most before it looks at its run flag again */
 
 /* ---- sample buffers ---- */
 
@@ -246,6 +291,7 @@ aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *bu
     rx->ring[head % rx->ring_slots] = buf;
     rx->ring_head = head + 1; /* publishes the slot */
     rx->nr_bufs_delivered++;
+    _bell_ring(&rx->ring_bell); /* wakes the submit thread if it sleeps; never waits */
     const uint64_t dt = tsl_get_clock_monotonic() - t0;
     if (dt > rx->max_deliver_ns) {
         rx->max_deliver_ns = dt;
@@ -270,19 +316,28 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
     while (worker_thread_is_running(wthr) || rx->ring_tail != rx->ring_head) {
         const size_t tail = rx->ring_tail;
         if (tail == rx->ring_head) {
-            usleep(200);
+            _bell_arm(&rx->ring_bell);
+            if (tail == rx->ring_head && worker_thread_is_running(wthr)) {
+                _bell_sleep(&rx->ring_bell, MFM_IDLE_MS);
+            } else {
+                _bell_disarm(&rx->ring_bell);
+            }
             continue;
         }
         struct sample_buf *buf = rx->ring[tail % rx->ring_slots]; /* the load of ring_head above acquired it */
         if (!rx->failed) {
             for (;;) {
+                /* armed before the attempt: a slot released between a refused push and the sleep still rings */
+                _bell_arm(&rx->room_bell);
                 const int rc = mfm_group_push(rx->group, buf->data_buf, buf->nr_samples, _format_of(buf));
+                if (MFM_E_BUSY == rc && !rx->failed) {
+                    /* every output slot holds a block the drain thread has not written out yet */
+                    _bell_sleep(&rx->room_bell, MFM_IDLE_MS);
+                    continue;
+                }
+                _bell_disarm(&rx->room_bell);
                 if (MFM_OK == rc) {
                     break;
-                }
-                if (MFM_E_BUSY == rc && !rx->failed) {
-                    usleep(200); /* every output slot holds a block the drain thread has not written out yet */
-                    continue;
                 }
                 MFM_MSG(SEV_FATAL, "ENGINE-PUSH", "mfm_group_push failed: %s", mfm_last_error());
                 rx->failed = 1;
@@ -291,6 +346,8 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
         }
         rx->ring_tail = tail + 1;
         rx->nr_bufs_submitted++;
+        _bell_ring(&rx->block_bell);
+        _bell_ring(&rx->idle_bell);
         TSL_BUG_IF_FAILED(sample_buf_decref(buf)); /* back to the pool */
     }
     return rx->failed ? A_E_DEVICE : A_OK;
@@ -325,7 +382,12 @@ static aresult_t _receiver_drain_once(struct receiver *rx, bool *got)
     }
     rx->nr_blocks_drained++;
     *got = true;
-    return MFM_OK == mfm_group_release(rx->group) ? A_OK : A_E_DEVICE;
+    if (MFM_OK != mfm_group_release(rx->group)) {
+        return A_E_DEVICE;
+    }
+    _bell_ring(&rx->room_bell);
+    _bell_ring(&rx->idle_bell);
+    return A_OK;
 }
 
 static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
@@ -335,10 +397,22 @@ static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
         bool got = false;
         if (FAILED(_receiver_drain_once(rx, &got))) {
             rx->failed = 1; /* deliver(), the submit thread and receiver_drain() stop waiting for us */
+            _bell_ring(&rx->idle_bell);
             return A_E_DEVICE;
         }
         if (!got) {
-            usleep(500);
+            /* nothing finished or in flight: sleep until the submit thread has pushed a buffer */
+            _bell_arm(&rx->block_bell);
+            if (FAILED(_receiver_drain_once(rx, &got))) {
+                rx->failed = 1;
+                _bell_ring(&rx->idle_bell);
+                return A_E_DEVICE;
+            }
+            if (!got && worker_thread_is_running(wthr)) {
+                _bell_sleep(&rx->block_bell, MFM_IDLE_MS);
+            } else {
+                _bell_disarm(&rx->block_bell);
+            }
         }
     }
     return A_OK;
@@ -352,7 +426,12 @@ aresult_t receiver_drain(struct receiver *rx)
         if (rx->failed) {
             return A_E_DEVICE;
         }
-        usleep(200);
+        _bell_arm(&rx->idle_bell);
+        if (rx->nr_bufs_submitted != rx->nr_bufs_delivered && !rx->failed) {
+            _bell_sleep(&rx->idle_bell, MFM_IDLE_MS);
+        } else {
+            _bell_disarm(&rx->idle_bell);
+        }
     }
     if (rx->failed || MFM_OK != mfm_group_sync(rx->group)) {
         return A_E_DEVICE;
@@ -373,7 +452,9 @@ aresult_t receiver_drain(struct receiver *rx)
             return A_E_DEVICE;
         }
         if (rx->drain_thr.started) {
-            usleep(500); /* the drain thread owns fetch/release */
+            /* the drain thread owns fetch/release and rings after every block */
+            _bell_arm(&rx->idle_bell);
+            _bell_sleep(&rx->idle_bell, 5u);
         } else {
             bool got = false;
             if (FAILED(_receiver_drain_once(rx, &got))) {
@@ -388,14 +469,171 @@ void receiver_mark_input_done(struct receiver *rx)
     rx->input_done = true;
 }
 
+/* what receiver_init() reads from the configuration before it builds anything (keys, defaults and messages of
+ * multifm/receiver.c:133-184; the MI355X keys gpuDevice / gpuDevices / gpuExchange are this build's) */
+struct receiver_settings {
+    int nr_samp_bufs, sample_rate, center_freq, decimation;
+    double *lpf_taps;
+    size_t lpf_nr_taps;
+    struct config channels;
+    struct mfm_group_config group;
+};
+
+static aresult_t _settings_devices(struct config *cfg, struct mfm_group_config *gc)
+{
+    struct config devs = CONFIG_INIT_EMPTY, dev = CONFIG_INIT_EMPTY;
+    const char *xchg = NULL;
+    aresult_t it = A_OK;
+    size_t ctr = 0;
+    int gpu = 0;
+
+    memset(gc, 0, sizeof(*gc));
+    gc->abi_version = MFM_ABI_VERSION;
+    /* "gpuDevices": [d0, d1, ...] shards the channels over several GPUs of the node (d0 ingests and is the root of the
+     * exchange); "gpuDevice": d is the one-GPU form (default device 0) */
+    if (!FAILED(config_get(cfg, &devs, "gpuDevices"))) {
+        CONFIG_ARRAY_FOR_EACH(dev, &devs, it, ctr) {
+            int d = -1;
+            if (gc->nr_devices >= MFM_GROUP_MAX_DEVICES || FAILED(config_get_integer(&dev, &d, NULL)) || d < 0) {
+                MFM_MSG(SEV_ERROR, "BAD-GPU-DEVICES", "'gpuDevices' must be an array of at most %d device numbers.",
+                        MFM_GROUP_MAX_DEVICES);
+                return A_E_INVAL;
+            }
+            gc->devices[gc->nr_devices++] = d;
+        }
+        (void)it;
+    }
+    if (0 == gc->nr_devices) {
+        (void)config_get_integer(cfg, &gpu, "gpuDevice");
+        gc->devices[0] = gpu;
+        gc->nr_devices = 1;
+    }
+    /* "gpuExchange": "rccl" sends the blocks through the RCCL broadcast path even on one device, "allgather" through the
+     * scatter + all-gather form (include/multifm_hip.h, MFM_X_*) */
+    if (!FAILED(config_get_string(cfg, &xchg, "gpuExchange"))) {
+        gc->exchange = 0 == strcmp(xchg, "rccl") ? MFM_X_RCCL : 0 == strcmp(xchg, "allgather") ? MFM_X_RCCL_ALLGATHER : MFM_X_AUTO;
+    }
+    return A_OK;
+}
+
+static aresult_t _settings_read(struct config *cfg, size_t samples_per_buf, struct receiver_settings *st)
+{
+    memset(st, 0, sizeof(*st));
+    if (FAILED(config_get_integer(cfg, &st->nr_samp_bufs, "nrSampBufs"))) {
+        MFM_MSG(SEV_INFO, "DEFAULT-SAMP-BUFS", "Setting sample buffer count to 64");
+        st->nr_samp_bufs = 64;
+    }
+    if (FAILED(config_get_integer(cfg, &st->sample_rate, "sampleRateHz"))) {
+        MFM_MSG(SEV_INFO, "NO-SAMPLE-RATE", "Need to specify a sample rate, in Hertz.");
+        return A_E_INVAL;
+    }
+    if (FAILED(config_get_integer(cfg, &st->center_freq, "centerFreqHz"))) {
+        MFM_MSG(SEV_INFO, "NO-CENTER-FREQ", "You forgot to specify a center frequency, in Hz.");
+        return A_E_INVAL;
+    }
+    MFM_MSG(SEV_INFO, "SAMPLE-RATE", "Sample rate is set to %u Hz", st->sample_rate);
+    MFM_MSG(SEV_INFO, "CENTER-FREQ", "Center Frequency is %u Hz", st->center_freq);
+    if (FAILED(config_get_integer(cfg, &st->decimation, "decimationFactor"))) {
+        MFM_MSG(SEV_INFO, "NO-DECIMATION", "Not decimating the output signal: using full bandwidth.");
+        return A_E_INVAL;
+    }
+    if (0 >= st->decimation) {
+        MFM_MSG(SEV_ERROR, "BAD-DECIMATION-FACTOR", "Decimation factor of '%d' is not valid.", st->decimation);
+        return A_E_INVAL;
+    }
+    if (FAILED(config_get_float_array(cfg, &st->lpf_taps, &st->lpf_nr_taps, "lpfTaps"))) {
+        MFM_MSG(SEV_ERROR, "BAD-FILTER-TAPS", "Need to provide a baseband filter with at least two filter taps as 'lpfTaps'.");
+        return A_E_INVAL;
+    }
+    if (1 >= st->lpf_nr_taps) {
+        MFM_MSG(SEV_ERROR, "INSUFF-FILTER-TAPS", "Not enough filter taps for the low-pass filter.");
+        return A_E_INVAL;
+    }
+    if (FAILED(config_get(cfg, &st->channels, "channels"))) {
+        MFM_MSG(SEV_ERROR, "MISSING-CHANNELS", "Need to specify at least one channel to demodulate.");
+        return A_E_INVAL;
+    }
+    aresult_t ret = _settings_devices(cfg, &st->group);
+    st->group.sample_rate_hz = (uint32_t)st->sample_rate;
+    st->group.decimation = (uint32_t)st->decimation;
+    st->group.max_block_samples = (uint32_t)samples_per_buf;
+    return ret;
+}
+
+/* one "channels" entry -> one demod_thread on the bound group (keys and messages of multifm/receiver.c:195-244) */
+static aresult_t _receiver_add_channel(struct receiver *rx, struct config *channel, const struct receiver_settings *st)
+{
+    const char *fifo_name = NULL, *signal_debug = NULL;
+    int nb_center_freq = -1;
+    struct demod_thread *dmt = NULL;
+    double gain = 1.0, gain_db = 0.0;
+
+    if (FAILED(config_get_string(channel, &fifo_name, "outFifo"))) {
+        MFM_MSG(SEV_ERROR, "MISSING-FIFO-ID", "Missing output FIFO filename, aborting.");
+        return A_E_INVAL;
+    }
+    if (FAILED(config_get_integer(channel, &nb_center_freq, "chanCenterFreq"))) {
+        MFM_MSG(SEV_ERROR, "MISSING-CENTER-FREQ", "Missing output channel center frequency.");
+        return A_E_INVAL;
+    }
+    if (!FAILED(config_get_string(channel, &signal_debug, "signalDebugFile"))) {
+        MFM_MSG(SEV_INFO, "WRITING-SIGNAL-DEBUG", "The channel at frequency %d will have raw I/Q written to '%s'",
+                nb_center_freq, signal_debug);
+    }
+    /* the key is case sensitive ("dbGain" in etc/pocsag_rtlsdr.json:19 is silently ignored) and the conversion is
+     * 10^(dB/10) applied to amplitude taps (multifm/receiver.c:218-220) */
+    if (!FAILED(config_get_float(channel, &gain_db, "dBGain"))) {
+        gain = pow(10.0, gain_db / 10.0);
+    }
+    if (FAILED(demod_thread_new(&dmt, (unsigned)-1, (int32_t)nb_center_freq - st->center_freq, (uint32_t)st->sample_rate,
+                                fifo_name, st->decimation, st->lpf_taps, st->lpf_nr_taps, signal_debug, gain))) {
+        MFM_MSG(SEV_ERROR, "FAILED-DEMOD-THREAD", "Failed to create demodulator thread, aborting.");
+        return A_E_INVAL;
+    }
+    list_append(&rx->demod_threads, &dmt->dt_node);
+    rx->nr_demod_threads++;
+    MFM_MSG(SEV_INFO, "CHANNEL", "[%zu]: %4.5f MHz Gain: %f dB -> [%s]%s%s", rx->nr_demod_threads, (double)nb_center_freq / 1e6,
+            gain_db, fifo_name, (NULL != signal_debug ? " DEBUG: " : ""), (NULL != signal_debug ? signal_debug : ""));
+    return A_OK;
+}
+
+static void _receiver_zero(struct receiver *rx, receiver_rx_thread_func_t rx_func, receiver_cleanup_func_t cleanup_func)
+{
+    memset(&rx->wthr, 0, sizeof(rx->wthr));
+    memset(&rx->submit_thr, 0, sizeof(rx->submit_thr));
+    memset(&rx->drain_thr, 0, sizeof(rx->drain_thr));
+    rx->muted = true;
+    rx->samp_alloc = NULL;
+    rx->cleanup_func = cleanup_func;
+    rx->thread_func = rx_func;
+    rx->group = NULL;
+    rx->nr_shards = 0;
+    rx->ring = NULL;
+    rx->ring_slots = 0;
+    rx->nr_demod_threads = 0;
+    atomic_store(&rx->nr_samp_buf_alloc_fails, 0);
+    atomic_store(&rx->input_done, false);
+    atomic_store(&rx->nr_blocks_drained, 0);
+    atomic_store(&rx->ring_head, 0);
+    atomic_store(&rx->ring_tail, 0);
+    atomic_store(&rx->failed, 0);
+    atomic_store(&rx->nr_bufs_delivered, 0);
+    atomic_store(&rx->nr_bufs_submitted, 0);
+    atomic_store(&rx->max_deliver_ns, 0);
+    list_init(&rx->demod_threads);
+    _bell_init(&rx->ring_bell);
+    _bell_init(&rx->room_bell);
+    _bell_init(&rx->block_bell);
+    _bell_init(&rx->idle_bell);
+}
+
 aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,
                         receiver_cleanup_func_t cleanup_func, size_t samples_per_buf)
 {
-    aresult_t ret = A_OK;
-    double *lpf_taps = NULL;
-    size_t lpf_nr_taps = 0, arr_ctr = 0;
-    int decimation_factor = 0, nr_samp_bufs = 0, sample_rate = 0, center_freq = 0;
-    struct config channels = CONFIG_INIT_EMPTY, channel = CONFIG_INIT_EMPTY;
+    struct receiver_settings st;
+    struct config channel = CONFIG_INIT_EMPTY;
+    aresult_t ret = A_OK, it = A_OK;
+    size_t ctr = 0;
 
     TSL_ASSERT_ARG(NULL != rx);
     TSL_ASSERT_ARG(NULL != cfg);
@@ -403,168 +641,45 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
     TSL_ASSERT_ARG(NULL != cleanup_func);
     TSL_ASSERT_ARG(0 != samples_per_buf);
 
-    rx->muted = true;
-    rx->samp_alloc = NULL;
-    rx->cleanup_func = cleanup_func;
-    rx->thread_func = rx_func;
-    rx->nr_samp_buf_alloc_fails = 0;
-    rx->input_done = false;
-    rx->nr_blocks_drained = 0;
-    memset(&rx->wthr, 0, sizeof(rx->wthr));
-    memset(&rx->submit_thr, 0, sizeof(rx->submit_thr));
-    memset(&rx->drain_thr, 0, sizeof(rx->drain_thr));
-    rx->group = NULL;
-    rx->nr_shards = 0;
-    rx->ring = NULL;
-    rx->ring_slots = 0;
-    rx->ring_head = rx->ring_tail = 0;
-    rx->failed = 0;
-    rx->nr_bufs_delivered = rx->nr_bufs_submitted = 0;
-    rx->max_deliver_ns = 0;
-    rx->nr_demod_threads = 0;
-    list_init(&rx->demod_threads);
-
-    /* keys and defaults of multifm/receiver.c:133-184 */
-    if (FAILED(config_get_integer(cfg, &nr_samp_bufs, "nrSampBufs"))) {
-        MFM_MSG(SEV_INFO, "DEFAULT-SAMP-BUFS", "Setting sample buffer count to 64");
-        nr_samp_bufs = 64;
-    }
-    if (FAILED(ret = config_get_integer(cfg, &sample_rate, "sampleRateHz"))) {
-        MFM_MSG(SEV_INFO, "NO-SAMPLE-RATE", "Need to specify a sample rate, in Hertz.");
+    _receiver_zero(rx, rx_func, cleanup_func);
+    if (FAILED(ret = _settings_read(cfg, samples_per_buf, &st))) {
         goto done;
     }
-    if (FAILED(ret = config_get_integer(cfg, &center_freq, "centerFreqHz"))) {
-        MFM_MSG(SEV_INFO, "NO-CENTER-FREQ", "You forgot to specify a center frequency, in Hz.");
-        goto done;
-    }
-    MFM_MSG(SEV_INFO, "SAMPLE-RATE", "Sample rate is set to %u Hz", sample_rate);
-    MFM_MSG(SEV_INFO, "CENTER-FREQ", "Center Frequency is %u Hz", center_freq);
-
     TSL_BUG_IF_FAILED(frame_alloc_new(&rx->samp_alloc, sizeof(struct sample_buf) + samples_per_buf * sizeof(int16_t) * 2,
-                                      (size_t)nr_samp_bufs));
+                                      (size_t)st.nr_samp_bufs));
 
-    if (FAILED(config_get_integer(cfg, &decimation_factor, "decimationFactor"))) {
-        MFM_MSG(SEV_INFO, "NO-DECIMATION", "Not decimating the output signal: using full bandwidth.");
-        ret = A_E_INVAL;
+    /* one device group for the whole channel set, and a pointer ring with a slot per pool frame in front of it */
+    if (MFM_OK != mfm_group_create(&rx->group, &st.group)) {
+        MFM_MSG(SEV_FATAL, "ENGINE-CREATE", "Unable to create the channel engine: %s", mfm_last_error());
+        ret = A_E_DEVICE;
         goto done;
     }
-    if (0 >= decimation_factor) {
-        MFM_MSG(SEV_ERROR, "BAD-DECIMATION-FACTOR", "Decimation factor of '%d' is not valid.", decimation_factor);
-        ret = A_E_INVAL;
+    MFM_MSG(SEV_INFO, "GPU-DEVICES", "Channels are sharded over %u GPU(s), first device %d%s", st.group.nr_devices,
+            st.group.devices[0], st.group.exchange == MFM_X_RCCL ? " (RCCL exchange forced)" :
+            st.group.exchange == MFM_X_RCCL_ALLGATHER ? " (RCCL scatter + all-gather exchange)" : "");
+    rx->ring_slots = (size_t)st.nr_samp_bufs;
+    if (FAILED(ret = TACALLOC(&rx->ring, rx->ring_slots, sizeof(*rx->ring), SYS_CACHE_LINE_LENGTH))) {
         goto done;
-    }
-    if (FAILED(ret = config_get_float_array(cfg, &lpf_taps, &lpf_nr_taps, "lpfTaps"))) {
-        MFM_MSG(SEV_ERROR, "BAD-FILTER-TAPS", "Need to provide a baseband filter with at least two filter taps as 'lpfTaps'.");
-        goto done;
-    }
-    if (1 >= lpf_nr_taps) {
-        MFM_MSG(SEV_ERROR, "INSUFF-FILTER-TAPS", "Not enough filter taps for the low-pass filter.");
-        ret = A_E_INVAL;
-        goto done;
-    }
-    if (FAILED(config_get(cfg, &channels, "channels"))) {
-        MFM_MSG(SEV_ERROR, "MISSING-CHANNELS", "Need to specify at least one channel to demodulate.");
-        ret = A_E_INVAL;
-        goto done;
-    }
-
-    /* one device group for the whole channel set: "gpuDevices": [d0, d1, ...] shards the channels over several GPUs of
-     * the node (d0 ingests and broadcasts), "gpuDevice": d is the one-GPU form (default device 0); "gpuExchange":
-     * "rccl" sends the blocks through the RCCL broadcast path even on one device */
-    {
-        struct mfm_group_config gc;
-        struct config devs = CONFIG_INIT_EMPTY, dev = CONFIG_INIT_EMPTY;
-        const char *xchg = NULL;
-        int gpu = 0;
-        size_t dctr = 0;
-        memset(&gc, 0, sizeof(gc));
-        gc.abi_version = MFM_ABI_VERSION;
-        if (!FAILED(config_get(cfg, &devs, "gpuDevices"))) {
-            aresult_t dret = A_OK;
-            (void)dret;
-            CONFIG_ARRAY_FOR_EACH(dev, &devs, dret, dctr) {
-                int d = -1;
-                if (gc.nr_devices >= MFM_GROUP_MAX_DEVICES || FAILED(config_get_integer(&dev, &d, NULL)) || d < 0) {
-                    MFM_MSG(SEV_ERROR, "BAD-GPU-DEVICES", "'gpuDevices' must be an array of at most %d device numbers.",
-                            MFM_GROUP_MAX_DEVICES);
-                    ret = A_E_INVAL;
-                    goto done;
-                }
-                gc.devices[gc.nr_devices++] = d;
-            }
-        }
-        if (0 == gc.nr_devices) {
-            (void)config_get_integer(cfg, &gpu, "gpuDevice");
-            gc.devices[0] = gpu;
-            gc.nr_devices = 1;
-        }
-        if (!FAILED(config_get_string(cfg, &xchg, "gpuExchange")) && 0 == strcmp(xchg, "rccl")) {
-            gc.exchange = MFM_X_RCCL;
-        }
-        gc.sample_rate_hz = (uint32_t)sample_rate;
-        gc.decimation = (uint32_t)decimation_factor;
-        gc.max_block_samples = (uint32_t)samples_per_buf;
-        if (MFM_OK != mfm_group_create(&rx->group, &gc)) {
-            MFM_MSG(SEV_FATAL, "ENGINE-CREATE", "Unable to create the channel engine: %s", mfm_last_error());
-            ret = A_E_DEVICE;
-            goto done;
-        }
-        MFM_MSG(SEV_INFO, "GPU-DEVICES", "Channels are sharded over %u GPU(s), first device %d%s", gc.nr_devices,
-                gc.devices[0], gc.exchange == MFM_X_RCCL ? " (RCCL exchange forced)" : "");
-        rx->ring_slots = (size_t)nr_samp_bufs;
-        if (FAILED(ret = TACALLOC(&rx->ring, rx->ring_slots, sizeof(*rx->ring), SYS_CACHE_LINE_LENGTH))) {
-            goto done;
-        }
     }
 
     demod_thread_bind_group(rx->group);
-    CONFIG_ARRAY_FOR_EACH(channel, &channels, ret, arr_ctr) {
-        const char *fifo_name = NULL, *signal_debug = NULL;
-        int nb_center_freq = -1;
-        struct demod_thread *dmt = NULL;
-        double channel_gain = 1.0, channel_gain_db = 0.0;
-
-        if (FAILED(ret = config_get_string(&channel, &fifo_name, "outFifo"))) {
-            MFM_MSG(SEV_ERROR, "MISSING-FIFO-ID", "Missing output FIFO filename, aborting.");
+    CONFIG_ARRAY_FOR_EACH(channel, &st.channels, it, ctr) {
+        if (FAILED(ret = _receiver_add_channel(rx, &channel, &st))) {
             break;
         }
-        if (FAILED(ret = config_get_integer(&channel, &nb_center_freq, "chanCenterFreq"))) {
-            MFM_MSG(SEV_ERROR, "MISSING-CENTER-FREQ", "Missing output channel center frequency.");
-            break;
-        }
-        if (!FAILED(config_get_string(&channel, &signal_debug, "signalDebugFile"))) {
-            MFM_MSG(SEV_INFO, "WRITING-SIGNAL-DEBUG", "The channel at frequency %d will have raw I/Q written to '%s'",
-                    nb_center_freq, signal_debug);
-        }
-        /* the key is case sensitive ("dbGain" in etc/pocsag_rtlsdr.json:19 is silently ignored) and the
-         * conversion is 10^(dB/10) applied to amplitude taps (multifm/receiver.c:218-220) */
-        if (!FAILED(config_get_float(&channel, &channel_gain_db, "dBGain"))) {
-            channel_gain = pow(10.0, channel_gain_db / 10.0);
-        }
-        if (FAILED(ret = demod_thread_new(&dmt, (unsigned)-1, (int32_t)nb_center_freq - center_freq, (uint32_t)sample_rate,
-                                          fifo_name, decimation_factor, lpf_taps, lpf_nr_taps, signal_debug, channel_gain))) {
-            MFM_MSG(SEV_ERROR, "FAILED-DEMOD-THREAD", "Failed to create demodulator thread, aborting.");
-            break;
-        }
-        list_append(&rx->demod_threads, &dmt->dt_node);
-        rx->nr_demod_threads++;
-        MFM_MSG(SEV_INFO, "CHANNEL", "[%zu]: %4.5f MHz Gain: %f dB -> [%s]%s%s", rx->nr_demod_threads,
-                (double)nb_center_freq / 1e6, channel_gain_db, fifo_name, (NULL != signal_debug ? " DEBUG: " : ""),
-                (NULL != signal_debug ? signal_debug : ""));
     }
     demod_thread_bind_group(NULL);
-    if (FAILED(ret)) {
+    if (FAILED(ret) || FAILED(it)) {
         MFM_MSG(SEV_ERROR, "CHANNEL-SETUP-FAILURE", "Error reading array of channels, aborting.");
-        goto done;
-    }
-    if (0 == rx->nr_demod_threads) {
+        ret = FAILED(ret) ? ret : it;
+    } else if (0 == rx->nr_demod_threads) {
         MFM_MSG(SEV_ERROR, "MISSING-CHANNELS", "Need to specify at least one channel to demodulate.");
         ret = A_E_INVAL;
     }
 
 done:
-    if (NULL != lpf_taps) {
-        TFREE(lpf_taps);
+    if (NULL != st.lpf_taps) {
+        TFREE(st.lpf_taps);
     }
     return ret;
 }
@@ -614,9 +729,12 @@ aresult_t receiver_cleanup(struct receiver **prx)
         (void)receiver_drain(rx); /* returns A_E_DEVICE instead of waiting for a thread that has given up */
         if (rx->submit_thr.started) {
             TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->submit_thr));
+            _bell_ring(&rx->ring_bell);
+            _bell_ring(&rx->room_bell);
             TSL_BUG_IF_FAILED(worker_thread_delete(&rx->submit_thr));
         }
         TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->drain_thr));
+        _bell_ring(&rx->block_bell);
         TSL_BUG_IF_FAILED(worker_thread_delete(&rx->drain_thr));
     }
     TSL_BUG_IF_FAILED(rx->cleanup_func(rx));
@@ -631,6 +749,10 @@ aresult_t receiver_cleanup(struct receiver **prx)
         TFREE(rx->ring);
     }
     TSL_BUG_IF_FAILED(frame_alloc_delete(&rx->samp_alloc));
+    sem_destroy(&rx->ring_bell.sem);
+    sem_destroy(&rx->room_bell.sem);
+    sem_destroy(&rx->block_bell.sem);
+    sem_destroy(&rx->idle_bell.sem);
     *prx = NULL;
     return A_OK;
 }

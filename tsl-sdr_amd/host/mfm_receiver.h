@@ -17,6 +17,7 @@
  */
 #pragma once
 
+#include <semaphore.h>
 #include <stdatomic.h>
 
 #include "mfm_config.h"
@@ -60,6 +61,15 @@ aresult_t sample_buf_decref(struct sample_buf *buf);
 
 struct list_entry {
     struct list_entry *prev, *next;
+};
+
+/* A doorbell between two threads: the waiter announces that it is about to sleep, looks once more, and sleeps on the
+ * semaphore; whoever produces work rings only when somebody announced (one atomic exchange, no lock, never waits - which
+ * is what receiver_sample_buf_deliver() needs).  The reference hands buffers to its channel threads through a work queue
+ * and a condition variable (multifm/demod.c:134-150); this is that hand-off with a producer side that cannot block. */
+struct mfm_doorbell {
+    sem_t sem;
+    _Atomic int sleeping;
 };
 
 struct demod_thread {
@@ -114,6 +124,10 @@ struct receiver {
     _Atomic size_t nr_bufs_delivered, nr_bufs_submitted;
     _Atomic size_t nr_blocks_drained;
     _Atomic uint64_t max_deliver_ns; /* longest receiver_sample_buf_deliver() call so far */
+    struct mfm_doorbell ring_bell;   /* front end -> submit thread: a buffer is in the ring */
+    struct mfm_doorbell room_bell;   /* drain thread -> submit thread: an output slot was released */
+    struct mfm_doorbell block_bell;  /* submit thread -> drain thread: a block was pushed to the devices */
+    struct mfm_doorbell idle_bell;   /* both -> receiver_drain(): a buffer was submitted / a block written out */
 };
 
 aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,
