@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-# "auto" = the matrix-core kernels where they apply (second generation when decimation % 32 == 0 and <= 128 taps, else
+# "auto" = the matrix-core kernels where they apply (second generation when decimation % 8 == 0 and <= 128 taps, else
 # the first), "mfma1" = first-generation matrix kernel forced, "dot2" = forced v_dot2 kernel.  All three give the same bits.
 KERNELS = ["auto", "mfma1", "dot2"]
 
@@ -32,8 +32,8 @@ def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_i
             assert variant == 1, "the first-generation matrix-core kernel should have been selected"
         else:
             assert variant in (1, 2), "a matrix-core kernel should have been selected"
-            if decim in (32, 64, 96):
-                assert variant == 2, "decimation % 32 == 0, <= 128 taps: the second-generation kernel applies"
+            if decim % 8 == 0 and decim <= 128:
+                assert variant == 2, "decimation % 8 == 0, <= 128 taps: the second-generation kernel applies"
     return eng
 
 
@@ -92,6 +92,45 @@ def test_reference_shaped_configs(pkg, ora, name, kernel):
         st = eng.stats()
         eng.close()
         assert st["kernel_variant"] == 1
+    if name == "multifm_1ch" and kernel == "auto":
+        # etc/multifm.json, etc/multifm_1ch.json: decimation 40 - a multiple of 8, not of 32: the second-generation
+        # kernel on its chunk-row LDS layout
+        eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=4096, kernel=kernel)
+        st = eng.stats()
+        eng.close()
+        assert st["kernel_variant"] == 2
+
+
+@pytest.mark.parametrize("decim,ntaps,nch,want_iq", [(40, 128, 64, False), (40, 128, 9, True), (8, 8, 3, True), (8, 60, 20, False),
+                                                     (16, 128, 5, False), (24, 100, 70, False), (48, 128, 64, True),
+                                                     (56, 56, 3, False), (72, 128, 130, False), (88, 100, 7, True),
+                                                     (104, 128, 16, False), (120, 128, 64, False)])
+def test_decimations_that_are_multiples_of_8_run_on_the_second_generation_kernel(pkg, ora, decim, ntaps, nch, want_iq):
+    """filter/direct_fir.c:328-417 has no restriction on the decimation.  Multiples of 8 that are not multiples of 32 (40:
+    the reference's own etc/multifm*.json) keep the LDS image as rows of 16-byte chunks, four outputs' worth per slot, with
+    the first three rows of a slot repeated behind the slot before (mfm_kernel.h, mfm_launch_v3::layout): every geometry
+    of that family the kernel is built for, channel counts that leave waves and slices partly empty, ragged blocks and
+    blocks shorter than a tile, mixed rotator classes, filtered-IQ output on and off, 8-bit input as bytes."""
+    fs = 1000000
+    taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
+    rng = np.random.RandomState(decim)
+    offs = np.where(rng.randint(0, 2, size=nch) == 0, (fs // decim) * rng.randint(-12, 12, size=nch),
+                    rng.randint(-450000, 450000, size=nch)).astype(np.int32)
+    n = decim * 2100 + ntaps + 13
+    iq = pkg.synth.random_iq(n, seed=decim + nch, full_scale=(decim % 16 == 8))
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 16, want_iq=want_iq)
+    st = eng.stats()
+    eng.close()
+    assert st["kernel_variant"] == 2, st
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=want_iq)
+    _check(pkg, ora, fs, decim, taps, offs, iq, decim * 130 + 7, want_iq=False)
+    if not want_iq:
+        raw = np.random.RandomState(nch).randint(0, 256, size=(n, 2)).astype(np.uint8)
+        cut = min(40000, n // 2)
+        blocks = [(raw[:cut], 3), (raw[cut:cut + 2], 3)] + [(raw[p:p + 60001], 3) for p in range(cut + 2, n, 60001)]
+        got, want, st8 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 1 << 16)
+        assert st8["kernel_variant"] == 2 and st8["launches_8bit"] == st8["launches"] > 0
+        assert got.shape == want.shape and np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -529,7 +568,7 @@ def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom)
                     "d400_t512": (400, 512), "d7_t33": (7, 33),
                     # 7 / 5 / 5 k-steps of taps held in registers (one and two staging chunks per thread)
                     "d25_t170": (25, 170), "d30_t150": (30, 150), "d24_t140": (24, 140)}[geom]
-    variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128") else 1
+    variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128", "d40_t64") else 1  # d40: chunk-row layout
     base_flags = pkg.binding.MFM_F_FORCE_MFMA_V1 if geom == "d96_t128_gen1" else 0
     taps = pkg.synth.design_lpf(ntaps, 9000.0, fs) * (3.0 if geom in ("d96_t512", "d7_t33") else 1.0)
     offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-9, 10)]

@@ -27,8 +27,8 @@
 
 #include <type_traits>
 
-#include "mfm_kernel.h"
-#include "mfm_numerics.h"
+#include "../../tsl-sdr_amd/csrc/mfm_kernel.h"
+#include "../../tsl-sdr_amd/csrc/mfm_numerics.h"
 
 typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 

@@ -165,6 +165,7 @@ struct mfm_engine {
     bool use_v3 = false;
     uint32_t v_rs = 0, v_sp_pitch = 0, v_nstage4 = 0, v_lds_bytes = 0, v_wg_per_cu = 1, v_cross[4] = { 0, 0, 0, 0 },
              v_within[4] = { 0, 0, 0, 0 };
+    uint32_t v_layout = 0, v_t_per = 0, v_t_pitch = 0; /* mfm_launch_v3::layout: chunk rows for decimations % 32 != 0 */
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
     int32_t *d_krow8[4] = { nullptr, nullptr, nullptr, nullptr }; /* [MFM_IN_*]: row constants of the 8-bit input forms */
@@ -248,6 +249,9 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
         V.cross[k] = e->v_cross[k];
         V.within[k] = e->v_within[k];
     }
+    V.layout = e->v_layout;
+    V.t_per = e->v_t_per;
+    V.t_pitch = e->v_t_pitch;
     V.nslices = e->m_nslices;
     V.nrb = e->m_nrb;
     V.nchan = (uint32_t)e->chans.size();
@@ -866,6 +870,35 @@ static int commit_locked(struct mfm_engine *e)
 
     /* ---- second-generation matrix kernel: 64-output tiles, four sub-planes per byte plane (mfm_kernel.h) ---- */
     e->use_v3 = false;
+    e->v_layout = 0;
+    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && e->m_ks <= 4u && D % 8u == 0u && (2u * D) % 64u != 0u) {
+        /* decimations that are multiples of 8 but not of 32 (40: etc/multifm.json, etc/multifm_1ch.json): the chunk-row
+         * layout (mfm_kernel.h).  t_per = chunks of four outputs; slots: one per four staged rows, plus the window's reach */
+        const uint32_t kq = e->m_ks, row_bytes = 2u * D, cpo = D / 8u, per = 4u * cpo;
+        const uint32_t extra = (64u * kq - 1u) / row_bytes;
+        const uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + extra;
+        const uint32_t nchunks16 = (rows * row_bytes + 15u) / 16u;
+        const uint32_t x_max = cpo * 3u + 4u * (kq - 1u);
+        const uint32_t pitch = std::max((nchunks16 + per - 1u) / per + 1u, 16u + 1u + x_max / per + 1u);
+        const uint32_t plane = ((per + 3u) * pitch * 16u + 63u) & ~63u;
+        const uint32_t nstage4 = rows * D / 4u; /* D % 8 == 0 */
+        const uint32_t nch = (nstage4 + 511u) / 512u;
+        const uint32_t lds = 4u * plane + 2048u + nch * 512u * 4u + 1024u + 2048u + nch * 512u * 4u;
+        if (nch <= MFM_V3_CH_MAX && lds <= 160u * 1024u) {
+            e->use_v3 = true;
+            e->v_layout = 1;
+            e->v_t_per = per;
+            e->v_t_pitch = pitch;
+            e->v_rs = 0;
+            e->v_sp_pitch = plane / 4u; /* plane pitch = 4 * sp_pitch, buffer pitch = 8 * sp_pitch, as in the sub-plane layout */
+            e->v_nstage4 = nstage4;
+            e->v_lds_bytes = lds;
+            e->v_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
+            for (uint32_t k = 0; k < 4; k++) {
+                e->v_cross[k] = e->v_within[k] = 0;
+            }
+        }
+    }
     if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && e->m_ks <= 4u && (2u * D) % 64u == 0u) {
         const uint32_t kq = e->m_ks, row_bytes = 2u * D;
         uint32_t rs_v = (row_bytes + 31u) / 32u * 32u;

@@ -141,7 +141,8 @@ struct mfm_launch_mfma {
  *   - the LDS image of a tile keeps the rows (one row = the D samples between two outputs) of equal index mod 4
  *     in four sub-planes, which makes "lane n reads row 4n + g" the same conflict-free stride pattern as
  *     "lane n reads row n" was.
- * Used when decimation % 32 == 0 (a 64-byte k-step never straddles a row), taps <= 128 and the image fits LDS.
+ * Used when decimation % 8 == 0 (decimation % 32 == 0: sub-planes, a 64-byte k-step never straddles a row; otherwise the
+ * chunk-row layout, mfm_launch_v3::layout), taps <= 128 and the image fits LDS.
  * ------------------------------------------------------------------------------------------- */
 #define MFM_V3_OT 64u          /* outputs per tile */
 #define MFM_V3_LEAD 4u         /* rows staged in front of a tile (the first tile of a chunk recomputes output -1) */
@@ -160,6 +161,15 @@ struct mfm_launch_v3 {
     uint32_t lut_off, sta_off;
     uint32_t cross[4];    /* per k-step: rows between an output's first sample and the k-step's first element */
     uint32_t within[4];   /* per k-step: byte offset of that element inside its row (for kg = 0) */
+    /* layout 1 - decimations that are multiples of 8 but not of 32 (a 64-byte k-step then straddles rows, and the
+     * sub-plane layout's address would need the row of every lane's 16 bytes): the image is kept as 16-byte plane chunks,
+     * chunk s of the tile at row s % t_per, slot s / t_per of a [t_per + 3][t_pitch] array of 16-byte cells, where
+     * t_per = 4 * D / 8 is four outputs' worth of chunks.  The window of output 4n + g starts at chunk t_per * (n + 1) +
+     * (D / 8) * g, so "lane n reads slot n (+ a constant) of row r" for every (g, k-step): 16 consecutive 16-byte cells,
+     * conflict free, and the address is again lane register + wave-uniform constant.  Rows 0..2 of each slot are kept a
+     * second time as rows t_per..t_per + 2 of the slot before, so that the four cells of a k-step (one per kg) never wrap. */
+    uint32_t layout;      /* 0: four sub-planes per byte plane (rs, sp_pitch, cross, within); 1: chunk rows (t_per, t_pitch) */
+    uint32_t t_per, t_pitch;
     uint32_t nslices, nrb;
     uint32_t ntiles;      /* ceil(n_new / 64) */
     uint32_t cl;          /* tiles per chunk */
