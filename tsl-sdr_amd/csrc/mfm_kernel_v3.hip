@@ -256,7 +256,7 @@ static __device__ __forceinline__ bool mfm3_decode_item(const mfm_launch_v3 &L, 
 #define MFM3_SH0(d, a) "v_lshrrev_b32_sdwa %[" #d "], 14, %[" #a "] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
 #define MFM3_SH1(d, a) "v_lshrrev_b32_sdwa %[" #d "], 14, %[" #a "] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
-template <bool HAS_PREV, bool HAS_NEXT, int O2, int O3, int N0, int N1>
+template <bool HAS_PREV, bool HAS_NEXT, int LO, int O2, int O3, int N0, int N1>
 static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, const mfm_v4i &al0, const mfm_v4i &al1,
                                                       const mfm_v4i &al2, const mfm_v4i &al3, const mfm_v4i &ah1,
                                                       const mfm_v4i &ah2, mfm_v4i &b0h, mfm_v4i &b0l, mfm_v4i &b1h,
@@ -266,7 +266,7 @@ static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, 
     /* Three fragment buffers (h + l each), rotating: in: b0 = k-step 0, b1 = k-step 1 of this group (requested by the
      * previous block); b2 takes k-step 2, b0 k-step 3 once k-step 0 is through; out: b1 = k-step 0, b2 = k-step 1 of the
      * next group, still in flight.  The caller rotates (b0, b1, b2) <- (b1, b2, b0) from group to group. */
-    constexpr int LO = 16384; /* high-byte plane -> low-byte plane */
+    /* LO: high-byte plane -> low-byte plane */
     mfm_v4i hh, md, ll;
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (HAS_PREV) {
@@ -474,6 +474,38 @@ static constexpr uint32_t mfm3_row_stride(uint32_t decim)
     return ((r / 32u) & 1u) ? r : r + 32u;
 }
 
+/*
+ * The LDS geometry of a decimation as compile-time constants (the DFIX instances: every B-fragment address is lane
+ * register + instruction immediate).  Decimations that are multiples of 32 use the sub-plane layout at the fixed 4096-byte
+ * pitch, the other multiples of 8 the chunk-row layout (mfm_kernel.h); the engine computes the same numbers at run time
+ * and the launcher only picks a DFIX instance when they agree.
+ */
+template <int DFIX>
+struct mfm3_geo {
+    static constexpr uint32_t D = DFIX > 0 ? (uint32_t)DFIX : 32u;
+    static constexpr bool chunk_rows = (2u * D) % 64u != 0u;
+    static constexpr uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + (64u * 4u - 1u) / (2u * D); /* 128-tap class: four k-steps */
+    /* chunk rows */
+    static constexpr uint32_t cpo = D / 8u, per = 4u * cpo;
+    static constexpr uint32_t nchunks16 = (rows * 2u * D + 15u) / 16u;
+    static constexpr uint32_t pitch_a = (nchunks16 + per - 1u) / per + 1u, pitch_b = 16u + 1u + (cpo * 3u + 12u) / per + 1u;
+    static constexpr uint32_t pitch = pitch_a > pitch_b ? pitch_a : pitch_b;
+    static constexpr uint32_t plane_t = ((per + 3u) * pitch * 16u + 63u) & ~63u;
+    /* sub-planes */
+    static constexpr uint32_t rs = mfm3_row_stride(D), sp = 4096u;
+    static constexpr uint32_t plane_pitch = chunk_rows ? plane_t : 4u * sp, buf_pitch = 2u * plane_pitch;
+    /* byte offset (from the lane's base) of the B fragment of column group g, k-step kq */
+    static constexpr uint32_t ofs(uint32_t g, uint32_t kq)
+    {
+        if (chunk_rows) {
+            const uint32_t x = cpo * g + 4u * kq;
+            return ((x % per) * pitch + 1u + x / per) * 16u;
+        }
+        const uint32_t c = (64u * kq) / (2u * D), w = (64u * kq) % (2u * D);
+        return ((g + c) & 3u) * sp + (1u + ((g + c) >> 2)) * rs + w;
+    }
+};
+
 /* KQ: k-steps of 64 elements; NCH: 16-byte staging chunks per thread and tile; AHM >= 0: ah_mask as a compile-time constant;
  * DFIX > 0: the decimation as a compile-time constant with the sub-planes at the fixed 4096-byte pitch - every B-fragment
  * address is then "lane register + instruction immediate" (ds_read has no SGPR operand: with run-time geometry each of
@@ -502,10 +534,12 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t kg = lane >> 4, n = lane & 15u;
     const uint32_t D = DFIX ? (uint32_t)DFIX : L.decim, row_bytes = 2u * D;
-    const uint32_t rs = DFIX ? mfm3_row_stride(DFIX) : L.rs;
-    const uint32_t sp_pitch = DFIX ? 4096u : L.sp_pitch;
-    const uint32_t plane_pitch = DFIX ? 4u * 4096u : L.plane_pitch, buf_pitch = DFIX ? 8u * 4096u : L.buf_pitch;
-    const bool chunk_rows = !DFIX && L.layout == 1u; /* mfm_kernel.h: the layout for decimations that are not multiples of 32 */
+    using G = mfm3_geo<DFIX>;
+    const uint32_t rs = DFIX ? G::rs : L.rs;
+    const uint32_t sp_pitch = DFIX ? G::sp : L.sp_pitch;
+    const uint32_t plane_pitch = DFIX ? G::plane_pitch : L.plane_pitch, buf_pitch = DFIX ? G::buf_pitch : L.buf_pitch;
+    const bool chunk_rows = DFIX ? G::chunk_rows : L.layout == 1u; /* mfm_kernel.h: decimations that are not multiples of 32 */
+    const uint32_t t_per = DFIX ? G::per : L.t_per, t_pitch = DFIX ? G::pitch : L.t_pitch;
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(smem + L.lut_off);
 
@@ -529,9 +563,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     for (int j = 0; j < NCH; j++) {
         const uint32_t p8 = (tid + (uint32_t)j * MFM3_NT) * (IN8 ? 16u : 8u); /* plane bytes in front of the chunk */
         if (chunk_rows) {
-            const uint32_t sc = p8 >> 4, r = sc % L.t_per, c = sc / L.t_per;
-            sta_s[j * MFM3_NT + tid] = (r * L.t_pitch + c) * 16u + (p8 & 15u);
-            sta2_s[j * MFM3_NT + tid] = (r < 3u && c >= 1u) ? ((r + L.t_per) * L.t_pitch + c - 1u) * 16u + (p8 & 15u) : 0xffffffffu;
+            const uint32_t sc = p8 >> 4, r = sc % t_per, c = sc / t_per;
+            sta_s[j * MFM3_NT + tid] = (r * t_pitch + c) * 16u + (p8 & 15u);
+            sta2_s[j * MFM3_NT + tid] = (r < 3u && c >= 1u) ? ((r + t_per) * t_pitch + c - 1u) * 16u + (p8 & 15u) : 0xffffffffu;
         } else {
             const uint32_t row = p8 / row_bytes, colb = p8 % row_bytes;
             sta_s[j * MFM3_NT + tid] = (row & 3u) * sp_pitch + (row >> 2) * rs + colb;
@@ -552,17 +586,17 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
         if (chunk_rows) {
             /* the window of output 4n + g starts t_per * (n + 1) + (t_per / 4) * g chunks into the image; k-step kq, lane
              * part kg: 4 kq + kg chunks further - row (x % t_per) + kg, slot n + 1 + x / t_per */
-            const uint32_t cpo = L.t_per >> 2;
+            const uint32_t cpo = t_per >> 2;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const uint32_t x = cpo * (uint32_t)g + 4u * (uint32_t)kq;
-                ofs[g][kq] = ((x % L.t_per) * L.t_pitch + 1u + x / L.t_per) * 16u;
+                ofs[g][kq] = ((x % t_per) * t_pitch + 1u + x / t_per) * 16u;
             }
             const uint32_t xw = cpo * 3u + 4u * (uint32_t)kq; /* column group 3, four outputs earlier: slot n */
-            ofs_w[kq] = ((xw % L.t_per) * L.t_pitch + xw / L.t_per) * 16u;
+            ofs_w[kq] = ((xw % t_per) * t_pitch + xw / t_per) * 16u;
         }
     }
-    const uint32_t lb0 = chunk_rows ? 16u * n + 16u * L.t_pitch * kg : n * rs + 16u * kg;
+    const uint32_t lb0 = chunk_rows ? 16u * n + 16u * t_pitch * kg : n * rs + 16u * kg;
 
     auto stage_load = [&](uint32_t tile, int j) -> uint4 {
         /* 4 samples of the image of `tile`, which starts LEAD rows in front of the tile's first output.  Only a
@@ -939,12 +973,12 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 }
             }
 
-            if constexpr (DFIX == 96 && KQ == 4 && AHM == 0x6 && IN8 == 0) {
+            if constexpr (DFIX != 0 && KQ == 4 && AHM == 0x6 && IN8 == 0) {
                 /* ---- the four column groups as hand-scheduled blocks (mfm3_group_d96): software pipelined by one group,
                  *      B fragments requested two k-steps ahead ---- */
-                constexpr int RS = (int)mfm3_row_stride(96), SP = 4096;
-                /* ofs[g][kq] as compile-time constants: cross = (0, 0, 0, 1), within = (0, 64, 128, 0) */
-#define MFM3_OFS(g, kq) ((((g) + ((kq) == 3 ? 1 : 0)) & 3) * SP + (1 + (((g) + ((kq) == 3 ? 1 : 0)) >> 2)) * RS + ((kq) == 3 ? 0 : 64 * (kq)))
+                /* ofs[g][kq] as compile-time constants */
+#define MFM3_OFS(g, kq) ((int)G::ofs((g), (kq)))
+                constexpr int LO = (int)G::plane_pitch;
                 const uint32_t ka = (uint32_t)(uintptr_t)krow_s;
                 mfm_v4i ph, pl, qh, ql, rh = { 0, 0, 0, 0 }, rl = { 0, 0, 0, 0 }; /* three rotating fragment buffers */
                 /* k-steps 0, 1 of group 0 (the blocks request those of the following group themselves) */
@@ -953,23 +987,23 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                              "ds_read_b128 %[x1h], %[lb] offset:%[b]\n\t"
                              "ds_read_b128 %[x1l], %[lb] offset:%[bl]\n\t"
                              : [x0h] "=&v"(ph), [x0l] "=&v"(pl), [x1h] "=&v"(qh), [x1l] "=&v"(ql)
-                             : [lb] "v"(lb), [a] "n"(MFM3_OFS(0, 0)), [al] "n"(MFM3_OFS(0, 0) + 16384), [b] "n"(MFM3_OFS(0, 1)),
-                               [bl] "n"(MFM3_OFS(0, 1) + 16384)
+                             : [lb] "v"(lb), [a] "n"(MFM3_OFS(0, 0)), [al] "n"(MFM3_OFS(0, 0) + LO), [b] "n"(MFM3_OFS(0, 1)),
+                               [bl] "n"(MFM3_OFS(0, 1) + LO)
                              : "memory");
                 mfm_v4i acc0[3], acc1[3];
                 uint32_t t[4];
                 const mfm_v4i none[3] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-                mfm3_group_d96<false, true, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
+                mfm3_group_d96<false, true, LO, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
                     lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, none, acc0, t);
-                mfm3_group_d96<true, true, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
+                mfm3_group_d96<true, true, LO, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
                     lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qh, ql, rh, rl, ph, pl, acc0, acc1, t);
                 f[0][0] = t[0];
                 f[0][1] = t[2];
-                mfm3_group_d96<true, true, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
+                mfm3_group_d96<true, true, LO, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
                     lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rh, rl, ph, pl, qh, ql, acc1, acc0, t);
                 f[1][0] = t[0];
                 f[1][1] = t[2];
-                mfm3_group_d96<true, false, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                mfm3_group_d96<true, false, LO, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
                     lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, acc0, acc1, t);
                 f[2][0] = t[0];
                 f[2][1] = t[2];
@@ -988,10 +1022,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 settle();
                 finish(acc1, f[3]);
 #undef MFM3_OFS
-            } else if constexpr (DFIX == 96 && KQ == 4 && AHM == 0x6 && IN8 != 0) {
+            } else if constexpr (DFIX != 0 && KQ == 4 && AHM == 0x6 && IN8 != 0) {
                 /* ---- the same pipeline for one sample plane (mfm3_group_d96_b8) ---- */
-                constexpr int RS = (int)mfm3_row_stride(96), SP = 4096;
-#define MFM3_OFS(g, kq) ((((g) + ((kq) == 3 ? 1 : 0)) & 3) * SP + (1 + (((g) + ((kq) == 3 ? 1 : 0)) >> 2)) * RS + ((kq) == 3 ? 0 : 64 * (kq)))
+#define MFM3_OFS(g, kq) ((int)G::ofs((g), (kq)))
                 const uint32_t ka = (uint32_t)(uintptr_t)krow_s;
                 mfm_v4i pb, qb, rb2 = { 0, 0, 0, 0 }; /* three rotating fragment buffers */
                 asm volatile("ds_read_b128 %[x0], %[lb] offset:%[a]\n\t"
@@ -1289,6 +1322,8 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
         if (L->decim == 96 && L->kq == 4 && nch == 2 && L->ah_mask == 0x6u && L->rs == mfm3_row_stride(96) &&      \
             L->sp_pitch == 4096u) {                                                                          \
             MFM3_LAUNCH_RC(4, 2, 0x6, 96, IN8_);                                                             \
+        } else if (L->decim == 40 && L->kq == 4 && nch == 1 && L->ah_mask == 0x6u && geo40) {                \
+            MFM3_LAUNCH_F(4, false, 1, 0x6, 40, IN8_);                                                       \
         } else {                                                                                             \
             switch (L->kq) {                                                                                 \
             case 1: MFM3_LAUNCH_8(1, IN8_); break;                                                           \
@@ -1298,6 +1333,9 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
             }                                                                                                \
         }                                                                                                    \
     } while (0)
+    /* decimation 40 (etc/multifm.json, etc/multifm_1ch.json at 1 MS/s) with the engine's chunk-row numbers */
+    const bool geo40 = L->layout == 1u && L->t_per == mfm3_geo<40>::per && L->t_pitch == mfm3_geo<40>::pitch &&
+                       L->plane_pitch == mfm3_geo<40>::plane_pitch && L->buf_pitch == mfm3_geo<40>::buf_pitch;
     if (L->in8) {
         if (dbg_iq || nch > 4 || (L->in8 != 7u && L->in8 != 14u)) {
             return hipErrorInvalidValue;
@@ -1315,6 +1353,10 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
     if (L->decim == 96 && L->kq == 4 && nch == 4 && !dbg_iq && L->ah_mask == 0x6u && L->rs == mfm3_row_stride(96) &&
         L->sp_pitch == 4096u) {
         MFM3_LAUNCH_RC(4, 4, 0x6, 96, 0);
+        return hipSuccess;
+    }
+    if (L->decim == 40 && L->kq == 4 && nch == 2 && !dbg_iq && L->ah_mask == 0x6u && geo40) {
+        MFM3_LAUNCH_F(4, false, 2, 0x6, 40, 0);
         return hipSuccess;
     }
 #endif
