@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/r03 (tools/prof_r03.sh) into the files kept under profiles/ (r03_*), and regenerate from them - and from
+nothing else - the numbers quoted in the text: the section between `<!-- r03:begin -->` and `<!-- r03:end -->` of
+profiles/README.md and of DESIGN.md section 6, and the header of profiles/r03_rocprofv3_pmc_summary.txt.  VERDICT r02 found
+README / DESIGN / the summary header quoting numbers of an earlier collection; with this script a number is never typed."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+b = os.path.join(R, "gpurun_out", "r03")
+P = os.path.join(R, "profiles")
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+# ---- bench lines ----------------------------------------------------------------------------------------------------
+lines = {}
+for f in sorted(glob.glob(os.path.join(b, "bench_*.json"))):
+    name = os.path.basename(f)[6:-5]
+    try:
+        lines[name] = last_json(f)
+    except Exception as e:
+        print("skip", f, e)
+head = lines["driverflags"]
+open(os.path.join(P, "r03_bench_n1.json"), "w").write(json.dumps(head) + "\n")
+with open(os.path.join(P, "r03_bench_lines.jsonl"), "w") as fo:
+    for k, d in lines.items():
+        d = dict(d)
+        d["_run"] = k
+        fo.write(json.dumps(d) + "\n")
+order = ["driverflags", "default", "grid64", "mfma1", "dot2", "c128", "c256", "c1024", "grid1024", "cfg5_256", "pocsag_d25",
+         "multifm_d40", "multifm_d40_mfma1"]
+what = {"driverflags": "cfg2, driver's flags", "default": "cfg2, defaults", "grid64": "cfg2 geometry, every channel on the 12.5 kHz raster",
+        "mfma1": "cfg2, first-generation kernel", "dot2": "cfg2, v_dot2 kernel", "c128": "128 channels (configs[2] shard)",
+        "c256": "256 channels", "c1024": "1024 channels on one GPU", "grid1024": "1024 channels on the 12.5 kHz raster",
+        "cfg5_256": "configs[4] per-GPU share: 256 ch, D = 400, 512 taps", "pocsag_d25": "etc/pocsag_rtlsdr.json geometry: 64 ch, D = 25",
+        "multifm_d40": "etc/multifm.json geometry: 64 ch, 1 MS/s, D = 40", "multifm_d40_mfma1": "the same, first-generation kernel"}
+hdr = "run                kernel                     value(MSamp/s x ch)  ms/step  kernel_ms  min     median  p95     hbm_frac  compute_frac  issued  verified"
+rows = [hdr]
+table_md = ["| run | kernel | value (MSamp/s x ch) | ms per step | kernel ms (min / median / p95) | roofline.frac | int8 frac (issued) | verified |",
+            "|---|---|---|---|---|---|---|---|"]
+for k in order + [k for k in lines if k not in order]:
+    if k not in lines:
+        continue
+    d = lines[k]
+    r, c = d["roofline"], d["compute_roofline"]
+    rows.append(f"{k:18s} {r['kernel']:26s} {d['value']:14.4g}      {d['ms_per_step']:.4f}   {r['kernel_ms']:.4f}   {r['kernel_ms_min']:.4f}  "
+                f"{r['kernel_ms_median']:.4f}  {r['kernel_ms_p95']:.4f}  {r['frac']:.3f}     {c['frac']:.3f}         "
+                f"{c.get('frac_issued', float('nan')):.3f}   {d.get('verified')}")
+    table_md.append(f"| {what.get(k, k)} | {r['kernel'].replace('mfm_channel_kernel', 'kernel')} | {d['value'] / 1e6:.1f} M | {d['ms_per_step']:.4f} | "
+                    f"{r['kernel_ms']:.4f} ({r['kernel_ms_min']:.4f} / {r['kernel_ms_median']:.4f} / {r['kernel_ms_p95']:.4f}) | {r['frac']:.3f} | "
+                    f"{c['frac']:.3f} ({c.get('frac_issued', float('nan')):.3f}) | {d.get('verified')} |")
+open(os.path.join(P, "r03_bench_table.txt"), "w").write("\n".join(rows) + "\n")
+print("\n".join(rows))
+
+# ---- rocprofv3 kernel stats of the headline command -------------------------------------------------------------------
+trace = {}
+for tag in ("kstats", "kstats1024"):
+    for f in glob.glob(os.path.join(b, tag, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(P, f"r03_rocprofv3_kernel_stats{'' if tag == 'kstats' else '_1024ch'}.csv"))
+    tr = glob.glob(os.path.join(b, tag, "**", "*kernel_trace.csv"), recursive=True)
+    if tr:
+        rr = [r for r in csv.DictReader(open(tr[0])) if "channel_kernel" in r["Kernel_Name"]]
+        du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000 for r in sorted(rr, key=lambda r: int(r["Start_Timestamp"]))]
+        trace[tag] = {"launches": len(du), "last20_us": sum(du[-20:]) / 20, "all_us": sum(du) / len(du), "name": rr[0]["Kernel_Name"]}
+        print(tag, trace[tag])
+        if tag == "kstats":
+            open(os.path.join(P, "r03_kernel_duration_series.txt"), "w").write(
+                "# launch durations (us) of the channel kernel in the rocprofv3 trace of `bench.py --gpus 1 --steps 20 --warmup 5`:\n"
+                "# settle phase first, the last 25 launches are warm-up + timed region\n" + "\n".join("%.1f" % x for x in du) + "\n")
+
+
+def stats_avg(path, needle):
+    for r in csv.DictReader(open(path)):
+        if needle in r["Name"]:
+            return float(r["AverageNs"]) / 1000, int(r["Calls"]), r["Name"]
+    return None
+
+
+ks = stats_avg(os.path.join(P, "r03_rocprofv3_kernel_stats.csv"), "channel_kernel")
+ks1024 = stats_avg(os.path.join(P, "r03_rocprofv3_kernel_stats_1024ch.csv"), "channel_kernel")
+
+# ---- PMC passes -------------------------------------------------------------------------------------------------------
+pm = {}
+out = []
+for p in ("p1", "p2", "p3"):
+    fs = glob.glob(os.path.join(b, p, "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    kn = ""
+    for r in csv.DictReader(open(fs[0])):
+        if "channel_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kn = r["Kernel_Name"]
+    out.append(f"## pass {p}: {kn[:90]}")
+    for k, v in sorted(acc.items()):
+        m = sum(v[len(v) // 2:]) / len(v[len(v) // 2:])
+        pm[k] = m
+        out.append(f"{k:28s} launches={len(v):3d} mean={m:.6g}")
+open(os.path.join(P, "r03_rocprofv3_pmc_raw.txt"), "w").write("\n".join(out) + "\n")
+
+# ---- HBM traffic ------------------------------------------------------------------------------------------------------
+res = {}
+for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    fs = glob.glob(os.path.join(b, d, "**", "*counter_collection.csv"), recursive=True)
+    rr = list(csv.DictReader(open(fs[0])))
+    vals = [float(r["Counter_Value"]) for r in rr if "channel_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    vals = vals[len(vals) // 2:]
+    res[name] = sum(vals) / max(1, len(vals))
+    shutil.copy(fs[0], os.path.join(P, f"r03_pmc_{name}.csv"))
+alg = head["roofline"]["bytes_per_launch"]
+tr = {"kernel": head["roofline"]["kernel"], "workload": head["config"]["workload"],
+      "FETCH_SIZE_kb_per_launch": res["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": res["WRITE_SIZE"],
+      "correction": "gfx950: FETCH_SIZE counts 16 B/lane streaming reads at half their bytes (MI355X_MICROARCH.md): x2",
+      "hbm_bytes_per_launch": (res["FETCH_SIZE"] * 2 + res["WRITE_SIZE"]) * 1024, "algorithmic_bytes_per_launch": alg}
+tr["ratio"] = tr["hbm_bytes_per_launch"] / alg
+json.dump(tr, open(os.path.join(P, "r03_hbm_traffic.json"), "w"), indent=1)
+
+# ---- the PMC summary, every figure derived here -------------------------------------------------------------------------
+simds = 1024.0
+wave_cyc = pm.get("SQ_WAVE_CYCLES", float("nan"))
+launch_cyc = pm.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0  # summed over the 8 XCDs
+mfma_busy = pm.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan"))
+n_mfma, n_valu = pm.get("SQ_INSTS_MFMA", float("nan")), pm.get("SQ_INSTS_VALU", float("nan"))
+other_valu = n_valu - n_mfma
+mfma_frac = mfma_busy / (simds * launch_cyc)
+valu_frac = other_valu * 4.0 / (simds * launch_cyc)  # upper bound: every other VALU instruction charged a full 4-cycle issue
+valu_frac3 = other_valu * 3.0 / (simds * launch_cyc)  # round 2's convention (its 38 %): 3 cycles per instruction on average
+valu_frac2 = other_valu * 2.0 / (simds * launch_cyc)  # lower bound: everything in the 2-cycle class
+pairs = head["config"]["channels_per_gpu"] * (head["config"]["block_samples"] // 96)
+summ = [
+    "# rocprofv3 --pmc summary, round 3 (tools/prof_r03.sh: `bench.py --steps 8 --warmup 3 --settle-seconds 0.3`, cfg2: 64 ch, block 2^26);",
+    "# mean per launch over the second half of the profiled launches.  GENERATED by tools/collect_r03.py from r03_rocprofv3_pmc_raw.txt -",
+    "# every figure below is computed from the counters in this file, none is typed.",
+    f"#   kernel                               {out[0][11:] if out else '?'}",
+    f"#   launch length                        GRBM_GUI_ACTIVE / 8 XCDs = {launch_cyc:.4g} cycles",
+    f"#   SQ_INSTS_VALU (incl. MFMA)           {n_valu:.4g}   SQ_INSTS_MFMA {n_mfma:.4g}   other VALU {other_valu:.4g} "
+    f"= {other_valu * 64 / pairs:.1f} lane-instructions per (channel, output)",
+    f"#   matrix pipe busy                     SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch) = {100 * mfma_frac:.1f} %",
+    f"#   other VALU                           {100 * valu_frac2:.1f} / {100 * valu_frac3:.1f} / {100 * valu_frac:.1f} % at 2 / 3 / 4 cycles per instruction (fp32 mul/add/fma and "
+    "32-bit add/logic issue in 2, the rest in ~4: profiles/r02_ubench_ops.txt; round 2 quoted the 3-cycle figure)",
+    f"#   neither (3-cycle convention)         {100 * (1 - mfma_frac - valu_frac3):.1f} %   (round 2: 36 %)",
+    f"#   MFMA time with a VALU instruction beside it   SQ_VALU_MFMA_COEXEC_CYCLES / MFMA_BUSY = "
+    f"{100 * pm.get('SQ_VALU_MFMA_COEXEC_CYCLES', float('nan')) / mfma_busy:.0f} %",
+    f"#   waves waiting (any reason)           SQ_WAIT_ANY / SQ_WAVE_CYCLES = {100 * pm.get('SQ_WAIT_ANY', float('nan')) / wave_cyc:.0f} %;"
+    f" for an issue slot: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {100 * pm.get('SQ_WAIT_INST_ANY', float('nan')) / wave_cyc:.0f} %",
+    f"#   LDS bank conflicts                   SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = "
+    f"{100 * pm.get('SQ_LDS_BANK_CONFLICT', float('nan')) / pm.get('SQ_LDS_IDX_ACTIVE', float('nan')):.0f} %",
+    f"#   VMEM instructions                    {pm.get('SQ_INSTS_VMEM_RD', float('nan')):.4g} loads, {pm.get('SQ_INSTS_VMEM_WR', float('nan')):.4g} stores",
+    f"#   HBM traffic (separate passes)        {tr['hbm_bytes_per_launch'] / 1e6:.1f} MB = {tr['ratio']:.3f} x algorithmic ({alg / 1e6:.1f} MB)",
+    "#",
+]
+open(os.path.join(P, "r03_rocprofv3_pmc_summary.txt"), "w").write("\n".join(summ + out) + "\n")
+print("\n".join(summ))
+
+# ---- generated text: profiles/README.md and DESIGN.md section 6 ----------------------------------------------------------
+host = open(os.path.join(b, "host.txt")).read().split("\n") if os.path.exists(os.path.join(b, "host.txt")) else ["?", "?"]
+cb = head.get("cpu_baseline", {})
+gen = []
+gen.append(f"Generated by `tools/collect_r03.py` from `gpurun_out/r03` (`tools/prof_r03.sh`, one box, one `gpurun` call); edit the script, not this text.")
+gen.append("")
+gen.append(f"* Headline (`r03_bench_n1.json`, the driver's command `python bench.py --gpus 1 --steps 20 --warmup 5`): "
+           f"**{head['value'] / 1e6:.1f} M MSamp/s x channels**, `ms_per_step` {head['ms_per_step']:.4f}, kernel {head['roofline']['kernel_ms']:.4f} ms "
+           f"(HIP events on {head['roofline'].get('timed_launches')} of {head['roofline'].get('launches')} timed launches), `roofline.frac` "
+           f"**{head['roofline']['frac']:.3f}**, `verified` {head.get('verified')} ({head.get('verification', {}).get('outputs_checked')} outputs of the last "
+           f"timed launch against the oracle), {head.get('rotators', {}).get('exact_channels')} of {head['config']['channels_per_gpu']} rotators exact.")
+if ks:
+    gen.append(f"* `rocprofv3 --kernel-trace --stats` of the same command (`r03_rocprofv3_kernel_stats.csv`): `{ks[2][:60]}` averages "
+               f"**{ks[0]:.1f} us** over {ks[1]} launches (settle phase included); the last 20 launches of the trace average "
+               f"{trace.get('kstats', {}).get('last20_us', float('nan')):.1f} us (`r03_kernel_duration_series.txt`).")
+if ks1024:
+    gen.append(f"* 1024 channels on one GPU (`r03_rocprofv3_kernel_stats_1024ch.csv`): {ks1024[0] / 1000:.3f} ms per launch in the trace, "
+               f"{lines['c1024']['roofline']['kernel_ms']:.3f} ms by the engine's events in the un-profiled run.")
+gen.append(f"* HBM traffic (`r03_hbm_traffic.json`; FETCH_SIZE and WRITE_SIZE each in its own `--pmc` pass, FETCH_SIZE doubled for gfx950): "
+           f"{res['FETCH_SIZE']:.0f} KB and {res['WRITE_SIZE']:.0f} KB per launch -> **{tr['hbm_bytes_per_launch'] / 1e6:.1f} MB = "
+           f"{tr['ratio']:.3f} x algorithmic** ({alg / 1e6:.1f} MB).")
+gen.append(f"* SQ counters (`r03_rocprofv3_pmc_summary.txt`): matrix pipe busy {100 * mfma_frac:.1f} % of the launch's SIMD cycles, other VALU "
+           f"{100 * valu_frac3:.1f} % (3 cycles per instruction, round 2's convention; {100 * valu_frac2:.1f} .. {100 * valu_frac:.1f} % at 2 .. 4), "
+           f"neither {100 * (1 - mfma_frac - valu_frac3):.1f} % (round 2: 36 %); "
+           f"{other_valu * 64 / pairs:.1f} lane-instructions per (channel, output).")
+if cb:
+    gen.append(f"* CPU baseline in the same run: {cb.get('value', 0):.0f} MSamp/s x channels on {cb.get('cores')} threads of a "
+               f"{cb.get('host_cores')}-core host ({cb.get('host_cpu')}); one channel on one core: {cb.get('msamp_per_s_one_channel_one_core', 0):.0f} MSamp/s.")
+gen.append("")
+gen += table_md
+gen_text = "\n".join(gen)
+open(os.path.join(P, "r03_summary.md"), "w").write(gen_text + "\n")
+
+for path in (os.path.join(P, "README.md"), os.path.join(R, "DESIGN.md")):
+    s = open(path).read()
+    if "<!-- r03:begin -->" not in s:
+        print("no r03 markers in", path)
+        continue
+    s = re.sub(r"<!-- r03:begin -->.*?<!-- r03:end -->", "<!-- r03:begin -->\n" + gen_text + "\n<!-- r03:end -->", s, flags=re.S)
+    open(path, "w").write(s)
+    print("regenerated the r03 section of", path)
