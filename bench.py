@@ -347,9 +347,10 @@ def main():
             b.copy_(torch.from_numpy(host))
     torch.cuda.synchronize()
 
-    # the exchange step: RCCL broadcast by default; MFM_EXCHANGE=scatter_allgather | auto selects the large-message
-    # form (tsl-sdr_amd/dist.py) - written for point-to-point xGMI, gloo-tested, not yet run on a multi-GPU node
-    exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "broadcast")) if use_dist else None
+    # the exchange step: "auto" times the RCCL broadcast and the scatter + all-gather form once on the real buffer and keeps
+    # the faster (tsl-sdr_amd/dist.py; DESIGN.md section 7: a broadcast delivers at one xGMI link's rate per GPU, the
+    # all-gather uses all of them); MFM_EXCHANGE=broadcast | scatter_allgather pins one
+    exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "auto")) if use_dist else None
 
     last = {"which": 0, "tail": 0}
 
@@ -487,7 +488,7 @@ def main():
             # as the GPUs take them, so this - not the kernel - is what an N > 1 line is usually bound by (a live
             # 2.4 MS/s stream is 10 MB/s).  xGMI: 7 links x ~153 GB/s per GPU, point to point.
             "exchange": None if not use_dist else {
-                "algo": exchange.algo, "bytes_per_step_per_peer": block * 4, "peers": world - 1,
+                "algo": exchange.algo, "algo_timings_s": exchange.timings, "bytes_per_step_per_peer": block * 4, "peers": world - 1,
                 # what every peer would have to receive for the exchange to hide behind the kernel (a step then costs
                 # max(exchange, kernel)): one block per kernel time
                 "needed_GBps_per_peer": block * 4 / (k_ms * 1e-3) / 1e9,

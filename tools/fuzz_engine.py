@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def case(pkg, ora, rng):
     b = pkg.binding
-    decim = int(rng.choice([25, 32, 40, 64, 96, 96, 96, 100, 128, 400, int(rng.randint(6, 200))]))
+    decim = int(rng.choice([25, 32, 40, 40, 64, 96, 96, 96, 100, 128, 400, 8 * int(rng.randint(1, 16)), int(rng.randint(6, 200))]))
     fs = int(rng.choice([1000000, 1200000, 2400000, 10000000]))
     ntaps = int(rng.choice([decim, 128, 128, 129, 200, 256, 512, decim + int(rng.randint(0, 100))]))
     ntaps = max(ntaps, decim)
@@ -29,6 +29,12 @@ def case(pkg, ora, rng):
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     offs = rng.randint(-fs // 2, fs // 2, size=nch)
     offs[: min(nch, 4)] = [0, 25000, -37500, 3125][: min(nch, 4)]
+    if fs % (4 * decim) == 0 and rng.rand() < 0.6:
+        # channels on the raster of a quarter of the output rate: exact rotators (identity, sign flip, quarter turns), all of
+        # them or a random share, so that launches, slices and waves of every class mix occur
+        q = fs // (4 * decim)
+        snap = rng.rand(nch) < float(rng.choice([1.0, 0.9, 0.5]))
+        offs = np.where(snap, q * rng.randint(-2 * decim + 1, 2 * decim, size=nch), offs)
     gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
     kernel = str(rng.choice(["auto", "auto", "mfma1", "dot2"]))
     want_iq = bool(rng.rand() < 0.5)
@@ -82,6 +88,12 @@ def case8(pkg, ora, rng):
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     offs = rng.randint(-fs // 2, fs // 2, size=nch)
     offs[: min(nch, 4)] = [0, 25000, -37500, 3125][: min(nch, 4)]
+    if fs % (4 * decim) == 0 and rng.rand() < 0.6:
+        # channels on the raster of a quarter of the output rate: exact rotators (identity, sign flip, quarter turns), all of
+        # them or a random share, so that launches, slices and waves of every class mix occur
+        q = fs // (4 * decim)
+        snap = rng.rand(nch) < float(rng.choice([1.0, 0.9, 0.5]))
+        offs = np.where(snap, q * rng.randint(-2 * decim + 1, 2 * decim, size=nch), offs)
     gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
     max_block = int(rng.choice([65536, 8192, 100000]))
     flags = b.MFM_F_WIDEN_8BIT if rng.rand() < 0.15 else 0
