@@ -331,5 +331,6 @@ def test_group_push_is_all_or_nothing_and_fetch_never_sees_half_a_push(tmp_path)
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread", "-o", str(exe),
                         os.path.join(ROOT, "tests", "hoststub", "group_seq_test.cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}  # tools/sanitize_cpu.sh preloads ASan: not into a TSan binary
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "all checks held" in r.stdout, (r.stdout + r.stderr)[-3000:]
