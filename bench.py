@@ -257,9 +257,10 @@ def ingest_8bit(pkg, fs, decim, taps, offs, gains, block, int16_kernel_ms, steps
             "time_vs_int16_kernel": ms / int16_kernel_ms}
 
 
-def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=24, iters=30):
-    """Kernel time of the floating-point IQ path (mfm_f32_*) on 2^24-sample blocks resident in HBM, HIP events on
-    the launch stream; the integer kernel's time is scaled to the same block length for the ratio."""
+def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=26, iters=12):
+    """Kernel time of the floating-point IQ path (mfm_f32_*) on blocks of the headline's length resident in HBM (round 3:
+    2^26 samples like the integer path it is compared with - on 2^24-sample blocks a workgroup runs 5.4 tiles and the
+    kernel's start and end weigh 10 % of the launch, profiles/r03_f32_block_sizes.txt), HIP events on the launch stream."""
     blk = 1 << block_log2
     base = pkg.synth.synth_iq(1 << 20, fs, offs[:: max(1, len(offs) // 8)][:8], seed=7).astype(np.float32)
     d_f = torch.from_numpy(np.tile(base, (blk // base.shape[0], 1)).reshape(-1)).cuda()
@@ -506,7 +507,7 @@ def main():
         # BASELINE configs[4] "fp32 vs int16 IQ path": the same channels on float32 IQ, outside the timed region,
         # reported next to the headline (never part of `value`)
         line["fp32_iq_path"] = fp32_path(pkg, torch, fs, decim, taps, offs, gains, line["roofline"]["kernel_ms"],
-                                         block)
+                                         block, block_log2=args.block_log2)
     if rank == 0 and world == 1 and not args.no_chain and decim == 96:
         line["flex_chain"] = flex_chain(pkg, torch, fs, decim, taps, offs, gains, block)
         if line["roofline"]["kernel"].startswith("mfm_channel_kernel_v3"):
