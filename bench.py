@@ -260,7 +260,8 @@ def ingest_8bit(pkg, fs, decim, taps, offs, gains, block, int16_kernel_ms, steps
 def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_block, block_log2=26, iters=30):
     """Kernel time of the floating-point IQ path (mfm_f32_*) on blocks of the headline's length resident in HBM (round 3:
     2^26 samples like the integer path it is compared with - on 2^24-sample blocks a workgroup runs 5.4 tiles and the
-    kernel's start and end weigh 10 % of the launch, profiles/r03_f32_block_sizes.txt), HIP events on the launch stream."""
+    kernel's start and end weigh 10 % of the launch, profiles/r03_f32_block_sizes.txt), behind a settle phase like the
+    headline's, HIP events on the launch stream."""
     blk = 1 << block_log2
     base = pkg.synth.synth_iq(1 << 20, fs, offs[:: max(1, len(offs) // 8)][:8], seed=7).astype(np.float32)
     d_f = torch.from_numpy(np.tile(base, (blk // base.shape[0], 1)).reshape(-1)).cuda()

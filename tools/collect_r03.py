@@ -186,6 +186,11 @@ gen.append(f"* SQ counters (`r03_rocprofv3_pmc_summary.txt`): matrix pipe busy {
            f"{100 * valu_frac3:.1f} % (3 cycles per instruction, round 2's convention; {100 * valu_frac2:.1f} .. {100 * valu_frac:.1f} % at 2 .. 4), "
            f"neither {100 * (1 - mfma_frac - valu_frac3):.1f} % (round 2: 36 %); "
            f"{other_valu * 64 / pairs:.1f} lane-instructions per (channel, output).")
+fp = head.get("fp32_iq_path")
+if fp:
+    gen.append(f"* Float path in the same run (`fp32_iq_path`: {fp['block_samples']}-sample blocks like the headline, settle phase first): "
+               f"{fp['ms_per_block']:.4f} ms per block = {fp['achieved_tflops']:.1f} TFLOP/s = **{fp['frac']:.3f} of the fp32 matrix peak**, "
+               f"{fp['time_vs_int16_path']:.2f} x the integer kernel's time.")
 if cb:
     gen.append(f"* CPU baseline in the same run: {cb.get('value', 0):.0f} MSamp/s x channels on {cb.get('cores')} threads of a "
                f"{cb.get('host_cores')}-core host ({cb.get('host_cpu')}); one channel on one core: {cb.get('msamp_per_s_one_channel_one_core', 0):.0f} MSamp/s.")
