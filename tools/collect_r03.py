@@ -199,11 +199,32 @@ gen += table_md
 gen_text = "\n".join(gen)
 open(os.path.join(P, "r03_summary.md"), "w").write(gen_text + "\n")
 
+# single values quoted in running text: <!--r03:KEY-->value<!--/r03-->
+d40v3, d40v1 = lines["multifm_d40"]["roofline"]["kernel_ms"], lines["multifm_d40_mfma1"]["roofline"]["kernel_ms"]
+vals = {"ms_step": f"{head['ms_per_step']:.4f}", "kernel_ms": f"{head['roofline']['kernel_ms']:.4f}", "frac": f"{head['roofline']['frac']:.3f}",
+        "gap_us": f"{(head['ms_per_step'] - head['roofline']['kernel_ms']) * 1e3:.1f}", "d40_v3": f"{d40v3:.4f}", "d40_v1": f"{d40v1:.4f}",
+        "d40_gain": f"−{100 * (1 - d40v3 / d40v1):.0f} %"}
+# the exchange table of DESIGN.md section 7
+blk_mb = head["config"]["block_samples"] * 4 / 1e6
+xt = ["| channels per GPU | kernel per block | needed per peer (int16 / 8-bit) | broadcast (≈ 153 GB/s per GPU) | all-gather on 7 links (≈ 940 GB/s at N = 8) |",
+      "|---|---|---|---|---|"]
+for key, lab in (("driverflags", "64"), ("c128", "128 (configs[2]: 1024 on 8 GPUs)"), ("c256", "256"), ("c1024", "1024")):
+    if key not in lines:
+        continue
+    k = lines[key]["roofline"]["kernel_ms"]
+    need = blk_mb / k  # MB per ms = GB/s
+    f = lambda have, n: "hidden" if n <= have else f"{n / have:.1f} x short"
+    xt.append(f"| {lab} | {k:.3f} ms | {need:.0f} / {need / 2:.0f} GB/s | {f(153.0, need)} | {f(940.0, need)} (8-bit: {f(940.0, need / 2)}) |")
+xt_text = "\n".join(xt)
+
 for path in (os.path.join(P, "README.md"), os.path.join(R, "DESIGN.md")):
     s = open(path).read()
     if "<!-- r03:begin -->" not in s:
         print("no r03 markers in", path)
         continue
     s = re.sub(r"<!-- r03:begin -->.*?<!-- r03:end -->", "<!-- r03:begin -->\n" + gen_text + "\n<!-- r03:end -->", s, flags=re.S)
+    s = re.sub(r"<!-- r03x:begin -->.*?<!-- r03x:end -->", "<!-- r03x:begin -->\n" + xt_text + "\n<!-- r03x:end -->", s, flags=re.S)
+    for k, v in vals.items():
+        s = re.sub(r"<!--r03:%s-->.*?<!--/r03-->" % k, "<!--r03:%s-->%s<!--/r03-->" % (k, v), s)
     open(path, "w").write(s)
     print("regenerated the r03 section of", path)
