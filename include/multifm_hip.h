@@ -67,6 +67,9 @@ extern "C" {
 #define MFM_F_TIMING_SPARSE 0x20u /* with MFM_F_TIMING: bracket one launch in four only (a back-to-back stream then runs
                                      without an event pair between most kernels; mfm_stats.timed_launches says how many
                                      durations kernel_ms sums) */
+#define MFM_F_GROUP_SHARED_DEVICE 0x40u /* mfm_group_config only, a TEST AID: the same device may be listed several times, so that
+                                           a group of several shards runs on a one-GPU box (real RCCL refuses such a communicator;
+                                           tests/hoststub/fake_rccl.cpp stands in for it) */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 

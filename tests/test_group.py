@@ -134,6 +134,71 @@ def test_group_exchanges_8bit_blocks_as_bytes(pkg, ora, exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shards,mode,nch", [(2, "rccl", 70), (3, "allgather", 70), (8, "allgather", 130), (8, "rccl", 64),
+                                             (4, "allgather", 3), (2, "auto", 16)])
+def test_group_of_several_shards_on_one_device_through_a_fake_transport(tmp_path, shards, mode, nch):
+    """No multi-GPU node is available to this project, so the S > 1 paths of the device group are checked for CORRECTNESS
+    on the one GPU of the box: MFM_F_GROUP_SHARED_DEVICE lets a group list the device several times, and a test double of
+    the RCCL calls (tests/hoststub/fake_rccl.cpp, built as librccl.so into a directory put first in LD_LIBRARY_PATH of a
+    fresh process) moves the bytes with device-to-device copies.  What that exercises for real: contiguous shard ranges,
+    one engine per shard, the exchange's pointer arithmetic in both modes (which part of the block goes to which shard, the
+    in-place all-gather, the remainder broadcast), 8-bit blocks travelling as bytes, submit order, per-shard fetch and the
+    concatenated PCM - all against the oracle.  It says nothing about links or speed."""
+    so = tmp_path / "librccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
+                        os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(["python3", os.path.join(ROOT, "tests", "hoststub", "multi_shard_run.py"), str(shards), mode, str(nch)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "multi-shard ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["rccl", "allgather"])
+def test_multifm_driver_with_three_shards_on_one_device(tmp_path, pkg, ora, exchange):
+    """multifm_amd with "gpuDevices": [0, 0, 0] (test aid "gpuTestSharedDevice") over the fake transport: the C host's
+    multi-shard path - one submit thread pushing to the group, one drain thread fetching a block per shard and writing
+    channel c from row c - first(shard) of its shard's block - with seven channels over three shards; every FIFO byte
+    stream must be the oracle's PCM."""
+    so = tmp_path / "librccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
+                        os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fs, decim, center = 1000000, 40, 929500000
+    offs = [112500, -200000, 3125, 250000, -25000, 0, 77777]
+    taps_file = os.path.join(ROOT, "etc", "lpf_25khz_1000k_128.json")
+    taps = np.array(json.load(open(taps_file))["lpfTaps"])
+    n = 4096 * 33 + 1001
+    iq = pkg.synth.synth_iq(n, fs, offs[:4], seed=15)
+    cap = tmp_path / "cap.bin"
+    cap.write_bytes(iq.tobytes())
+    cfg = {"device": {"type": "file", "filename": str(cap), "fileFormat": "cs16"}, "sampleRateHz": fs, "centerFreqHz": center,
+           "nrSampBufs": 16, "decimationFactor": decim, "gpuDevices": [0, 0, 0], "gpuTestSharedDevice": True,
+           "gpuExchange": exchange, "channels": []}
+    outs = []
+    for i, f in enumerate(offs):
+        o = tmp_path / f"ch{i}.pcm"
+        o.write_bytes(b"")
+        cfg["channels"].append({"outFifo": str(o), "chanCenterFreq": int(center + f)})
+        outs.append(o)
+    cj = tmp_path / "cfg.json"
+    cj.write_text(json.dumps(cfg))
+    exe = os.path.join(ROOT, "tsl-sdr_amd", "host", "multifm_amd")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(cj), taps_file], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "sharded over 3 GPU(s)" in r.stderr
+    cre = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[0] for o in offs])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, 1.0)[1] for o in offs])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    for i, o in enumerate(outs):
+        got = np.frombuffer(o.read_bytes(), dtype=np.int16)
+        assert np.array_equal(got, ref[i]), i
+
+
+@pytest.mark.gpu
 def test_group_with_more_devices_than_the_box_has_fails_cleanly(pkg):
     import torch
     n = torch.cuda.device_count()

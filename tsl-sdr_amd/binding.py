@@ -20,6 +20,7 @@ MFM_F_FORCE_DOT2 = 0x4
 MFM_F_FORCE_MFMA_V1 = 0x8
 MFM_F_WIDEN_8BIT = 0x10
 MFM_F_TIMING_SPARSE = 0x20
+MFM_F_GROUP_SHARED_DEVICE = 0x40
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)

@@ -158,7 +158,7 @@ int mfm_group_create(struct mfm_group **pg, const struct mfm_group_config *cfg)
     if (cfg->nr_devices < 1 || cfg->nr_devices > MFM_GROUP_MAX_DEVICES) {
         return gfail(MFM_E_INVAL, "a device group has 1..%d devices, not %u", MFM_GROUP_MAX_DEVICES, cfg->nr_devices);
     }
-    for (uint32_t i = 0; i < cfg->nr_devices; i++) {
+    for (uint32_t i = 0; i < cfg->nr_devices && !(cfg->flags & MFM_F_GROUP_SHARED_DEVICE); i++) {
         for (uint32_t j = 0; j < i; j++) {
             if (cfg->devices[i] == cfg->devices[j]) {
                 return gfail(MFM_E_INVAL, "device %d listed twice", cfg->devices[i]);

@@ -503,6 +503,14 @@ static aresult_t _settings_devices(struct config *cfg, struct mfm_group_config *
         }
         (void)it;
     }
+    {
+        /* test aid: "gpuTestSharedDevice": true lets 'gpuDevices' list a device several times (MFM_F_GROUP_SHARED_DEVICE),
+         * which is how the multi-shard paths of this file are run on a one-GPU box against a test double of RCCL */
+        bool shared = false;
+        if (!FAILED(config_get_boolean(cfg, &shared, "gpuTestSharedDevice")) && shared) {
+            gc->flags |= MFM_F_GROUP_SHARED_DEVICE;
+        }
+    }
     if (0 == gc->nr_devices) {
         (void)config_get_integer(cfg, &gpu, "gpuDevice");
         gc->devices[0] = gpu;
