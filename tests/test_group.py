@@ -155,6 +155,21 @@ def test_group_of_several_shards_on_one_device_through_a_fake_transport(tmp_path
 
 
 @pytest.mark.gpu
+def test_two_shard_group_pushed_and_fetched_from_two_threads(tmp_path):
+    """a drain thread calling mfm_group_fetch between shard 0's and shard 1's submit got "shards out of
+    step" and took the receiver down.  Real engines, two shards on the one device over the fake transport, 400 blocks of 2048
+    samples pushed by one thread while another one fetches: only "nothing yet" or whole blocks, and the oracle's PCM."""
+    so = tmp_path / "librccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
+                        os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(["python3", os.path.join(ROOT, "tests", "hoststub", "multi_shard_threads.py")], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "threads ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", ["rccl", "allgather"])
 def test_multifm_driver_with_three_shards_on_one_device(tmp_path, pkg, ora, exchange):
     """multifm_amd with "gpuDevices": [0, 0, 0] (test aid "gpuTestSharedDevice") over the fake transport: the C host's
