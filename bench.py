@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--settle-seconds", type=float, default=0.75)
     ap.add_argument("--channels-per-gpu", type=int, default=None,
                     help="default 64 at N = 1 (BASELINE configs[1]), 128 at N > 1 (configs[2]: 1024 channels on 8 GPUs)")
-    ap.add_argument("--kernel", choices=["auto", "mfma1", "dot2"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "mfma1", "mfma1s", "dot2"], default="auto",
                     help="mfma1 / dot2 = the first-generation matrix kernel / the v_dot2 kernel through the "
                          "MFM_F_FORCE_* flags (A/B timing)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
@@ -338,7 +338,8 @@ def main():
                      flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
                      (pkg.binding.MFM_F_TIMING_SPARSE if args.steps >= 16 else 0) |
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
-                     (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0),
+                     (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0) |
+                     (pkg.binding.MFM_F_STREAM_TAPS if args.kernel == "mfma1s" else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))

@@ -54,7 +54,8 @@ extern "C" {
 #define MFM_E_DONE (-6)   /* nothing to fetch (A_E_DONE analogue) */
 
 #define MFM_ABI_VERSION 3 /* 2: mfm_resampler_config grew flags + reserved; mfm_flex_*, mfm_group_* added
-                             3: mfm_stats grew timed_launches, rot_class_*; MFM_F_TIMING_SPARSE; mfm_group_config.exchange */
+                             3: mfm_stats grew timed_launches, rot_exact_channels, rot_fast_slices, k_steps, tap_hi_mask, taps_resident; MFM_F_TIMING_SPARSE, MFM_F_STREAM_TAPS;
+                                mfm_group_config.exchange */
 
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
@@ -70,6 +71,9 @@ extern "C" {
 #define MFM_F_GROUP_SHARED_DEVICE 0x40u /* mfm_group_config only, a TEST AID: the same device may be listed several times, so that
                                            a group of several shards runs on a one-GPU box (real RCCL refuses such a communicator;
                                            tests/hoststub/fake_rccl.cpp stands in for it) */
+#define MFM_F_STREAM_TAPS 0x80u /* filters of 129..512 taps on the matrix kernel: re-read the taps from L2 in every iteration
+                                  (the round-1 form: 128 registers, two workgroups per CU) instead of keeping all of them in
+                                  registers (256 registers, one workgroup per CU); same bits; parity tests and A/B timing */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 
@@ -120,6 +124,10 @@ struct mfm_stats {
     uint32_t k_steps;          /* matrix kernels: k-steps of 64 int16 elements (32 complex taps) per output, padded */
     uint32_t tap_hi_mask;      /* matrix kernels: bit k set = k-step k has taps beyond one byte, so its two products with
                                   the high-byte tap plane are issued (4 matrix instructions for that k-step, else 2) */
+    uint32_t taps_resident;    /* first-generation matrix kernel, filters of 129..512 taps: 1 = int16 blocks run an instance that
+                                  keeps every k-step of taps in registers, 0 = the taps are streamed from L2 (MFM_F_STREAM_TAPS,
+                                  or no resident instance for the geometry) */
+    uint32_t reserved0;
 };
 
 /* Size in bytes of one input staging buffer for this configuration and tap count. */

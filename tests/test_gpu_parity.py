@@ -19,6 +19,8 @@ def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_i
         flags |= pkg.binding.MFM_F_FORCE_DOT2
     if kernel == "mfma1":
         flags |= pkg.binding.MFM_F_FORCE_MFMA_V1
+    if kernel == "mfma1s":  # filters of 129..512 taps: the streamed-taps form instead of the resident one
+        flags |= pkg.binding.MFM_F_STREAM_TAPS
     eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
     gains = gains if gains is not None else [1.0] * len(offs)
     for o, g in zip(offs, gains):
@@ -188,6 +190,57 @@ def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntap
     assert eng.stats()["kernel_variant"] == 1, "long filters should run on the (first-generation) matrix kernel too"
     eng.close()
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
+
+
+@pytest.mark.parametrize("shape", ["lpf", "lpf_x8", "dense"])
+@pytest.mark.parametrize("decim,ntaps", [(96, 512), (96, 256), (96, 300), (48, 129), (400, 512), (320, 512), (200, 256),
+                                         (256, 256), (136, 160), (448, 512), (100, 400)])
+def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape):
+    """Filters of 129..512 taps without a filtered-IQ consumer run the RESIDENT instances of the first-generation matrix
+    kernel (all 8 / 16 k-steps of taps in registers, 256 registers, one workgroup per CU); MFM_F_STREAM_TAPS selects the
+    round-1 form that re-reads them from L2.  Both against the oracle, over the instance families: two-iteration and
+    single-iteration tiles, 2..8 staging chunks per thread, padded rows (D = 100), and the three tap-plane masks an
+    instance can be built for - a plain low-pass (high bytes in the middle k-steps only), the same at 18 dB (more of
+    them), and dense random taps (every plane)."""
+    fs = 4000000
+    rng = np.random.RandomState(decim + ntaps)
+    taps = {"lpf": lambda: pkg.synth.design_lpf(ntaps, 12500.0, fs),
+            "lpf_x8": lambda: pkg.synth.design_lpf(ntaps, 12500.0, fs) * 8.0,
+            "dense": lambda: rng.uniform(-0.3, 0.3, ntaps)}[shape]()
+    offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-10, 11)]
+    iq = pkg.synth.synth_iq(decim * 400 + ntaps + 7, fs, offs[:3], seed=decim)
+    masks = {}
+    for kernel, resident in (("auto", 1), ("mfma1s", 0)):
+        eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 16, want_iq=False, kernel=kernel)
+        st = eng.stats()
+        eng.close()
+        assert st["kernel_variant"] == 1 and st["taps_resident"] == resident, st
+        masks[kernel] = st["tap_hi_mask"]
+        _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=False, kernel=kernel)
+        _check(pkg, ora, fs, decim, taps, offs, iq, 30001, want_iq=False, kernel=kernel)
+    if shape == "dense":  # high bytes in every k-step that holds taps: the all-planes instance
+        assert masks["auto"] & ~(0x0ff0 if st["k_steps"] == 16 else 0x3c), hex(masks["auto"])
+    # a filtered-IQ consumer: the streamed form (the resident instances are not built with the IQ store)
+    eng = _mk_engine(pkg, fs, decim, taps, offs[:5], max_block=1 << 16, want_iq=True)
+    assert eng.stats()["taps_resident"] == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+@pytest.mark.parametrize("decim,ntaps,gain", [(96, 512, 1.0), (96, 400, 8.0), (400, 512, 1.0), (200, 500, 30.0)])
+def test_long_filters_on_8bit_blocks_resident_and_streamed(pkg, ora, fmt, decim, ntaps, gain):
+    """The same for 8-bit blocks read as bytes (one sample plane, sixteen k-steps of taps in registers)."""
+    fs = 2400000
+    taps = pkg.synth.design_lpf(ntaps, 9000.0, fs) * gain
+    offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-9, 10)]
+    rng = np.random.RandomState(decim + fmt)
+    blocks = [(rng.randint(0, 256, size=(m, 2)).astype(np.uint8), fmt) for m in (65536, 4096, 30000, 50000, 12346)]
+    got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536)
+    assert st["kernel_variant"] == 1 and st["launches_8bit"] == st["launches"] > 0 and st["taps_resident"] == 1
+    assert got.shape == want.shape and np.array_equal(got, want)
+    got2, _, st2 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536, flags=pkg.binding.MFM_F_STREAM_TAPS)
+    assert st2["launches_8bit"] == st2["launches"] > 0 and st2["taps_resident"] == 0
+    assert np.array_equal(got2, want)
 
 
 @pytest.mark.parametrize("nch", [1, 7, 61, 65, 130])

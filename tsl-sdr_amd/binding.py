@@ -21,6 +21,7 @@ MFM_F_FORCE_MFMA_V1 = 0x8
 MFM_F_WIDEN_8BIT = 0x10
 MFM_F_TIMING_SPARSE = 0x20
 MFM_F_GROUP_SHARED_DEVICE = 0x40
+MFM_F_STREAM_TAPS = 0x80
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
@@ -82,7 +83,8 @@ class Stats(C.Structure):
                 ("kernel_variant", C.c_uint32), ("pending_blocks", C.c_uint32),
                 ("launches_8bit", C.c_uint64), ("timed_launches", C.c_uint64),
                 ("rot_exact_channels", C.c_uint32), ("rot_fast_slices", C.c_uint32),
-                ("k_steps", C.c_uint32), ("tap_hi_mask", C.c_uint32)]
+                ("k_steps", C.c_uint32), ("tap_hi_mask", C.c_uint32),
+                ("taps_resident", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class PocsagConfig(C.Structure):

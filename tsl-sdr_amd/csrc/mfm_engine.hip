@@ -31,7 +31,8 @@
  * instance's LDS limit is raised once) and launch (through that pointer) */
 extern "C" hipError_t mfm_select_channel_kernel(int opl, int dbg_iq, const void **kfn_out);
 extern "C" hipError_t mfm_launch_channel_kernel(const void *kfn, const mfm_launch *L, uint32_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out);
+extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out,
+                                                     uint32_t *waves_per_simd_out);
 extern "C" hipError_t mfm_launch_channel_kernel_mfma(const void *kfn, const mfm_launch_mfma *L, uint32_t lds_bytes,
                                                      uint32_t grid, hipStream_t stream);
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out);
@@ -158,6 +159,8 @@ struct mfm_engine {
     uint32_t m_row_bytes = 0, m_nstage = 0;
     uint32_t m_ks = 0, m_ot = 0, m_rs = 0, m_plane_bytes = 0, m_lut_off = 0, m_krow_off = 0, m_nrb = 0,
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
+    uint32_t m_wg_fmt[4] = { 1, 1, 1, 1 }; /* workgroups per CU of the instance each input format runs (select_kernels) */
+    bool m_resident_taps = false;
     bool m_fixed_planes = false;
     uint32_t m_ah_mask = 0; /* k-steps whose high-byte tap plane is not all zero */
     uint32_t m_kq_used = 0; /* k-steps that hold taps at all */
@@ -296,6 +299,7 @@ void fill_mfma(const mfm_engine *e, int fmt, mfm_launch_mfma &M)
     M.nchan = C;
     M.out_stride = e->out_stride;
     M.ah_mask = e->m_ah_mask;
+    M.stream_taps = (e->cfg.flags & MFM_F_STREAM_TAPS) ? 1u : 0u;
     M.afrag = e->d_afrag;
     M.krow = e->d_krow;
     M.info = e->d_info;
@@ -328,8 +332,14 @@ int select_kernels(mfm_engine *e)
         } else if (e->use_mfma) {
             mfm_launch_mfma M{};
             fill_mfma(e, fmt, M);
-            HIP_TRY(mfm_select_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, &fn));
+            uint32_t wps = 4;
+            HIP_TRY(mfm_select_channel_kernel_mfma(&M, e->any_iq ? 1 : 0, &fn, &wps));
             lds = e->m_lds_bytes;
+            /* a resident long-filter instance takes a SIMD's registers with two waves: one workgroup per CU */
+            e->m_wg_fmt[fmt] = wps < 4u ? 1u : e->m_wg_per_cu;
+            if (fmt == MFM_IN_CS16) {
+                e->m_resident_taps = wps < 4u;
+            }
         } else {
             HIP_TRY(mfm_select_channel_kernel(e->opl, e->any_iq ? 1 : 0, &fn));
             lds = e->lds_bytes;
@@ -1401,7 +1411,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             if (raw8) {
                 e->launches_8bit++;
             }
-            const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_per_cu);
+            const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_fmt[fmt]);
             HIP_TRY(mfm_launch_channel_kernel_mfma(e->kfn[fmt], &M, e->m_lds_bytes, grid, e->s_compute));
             L.ntiles = grid; /* for grid_last below */
             L.nslices = 1;
@@ -1713,6 +1723,8 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->rot_fast_slices = e->rot_fast_slices;
     st->k_steps = e->use_mfma ? e->m_ks : 0u;
     st->tap_hi_mask = e->use_mfma ? e->m_ah_mask : 0u;
+    st->taps_resident = (e->use_mfma && !e->use_v3 && e->m_resident_taps) ? 1u : 0u;
+    st->reserved0 = 0;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
     st->outputs_per_tile = e->use_v3 ? MFM_V3_OT : e->use_mfma ? e->m_ot : 64u * e->opl;

@@ -77,7 +77,8 @@ struct mfm_launch {
  * ------------------------------------------------------------------------------------------- */
 #define MFM_MFMA_NW 8            /* waves per workgroup; each owns 16 GEMM rows = 8 channels */
 #define MFM_MFMA_KQ_MAX 4        /* k-steps of 64 int16 elements (= 32 complex taps) held in registers */
-#define MFM_MFMA_KQ_STREAM_MAX 16 /* longer filters (up to 512 taps): the A operand is streamed from L2 in chunks of 4 k-steps */
+#define MFM_MFMA_KQ_STREAM_MAX 16 /* longer filters (up to 512 taps): all k-steps in registers at two waves per SIMD (the
+                                     resident instances), or the A operand streamed from L2 in chunks of 4 k-steps */
 
 #define MFM_M_PLANE_DIST 16384u
 #define MFM_M_CH_MAX 8u /* at most this many 16-byte staging chunks per thread and tile */
@@ -115,6 +116,9 @@ struct mfm_launch_mfma {
                              the first rounding's shift and krow the matching row constants; x_last4 then is the last
                              sample index at which an 8-byte load stays inside the buffer */
     uint32_t in8_xor;     /* 0x80808080 when the bytes are unsigned (RTL-SDR), else 0 */
+    uint32_t stream_taps; /* filters of 129..512 taps (kq 8 / 16): 1 = re-read the taps from L2 in every iteration (128-register
+                             instances, two workgroups per CU where LDS allows); 0 = the resident instances (all taps in
+                             registers, 256 registers, one workgroup per CU) where one is built for the geometry */
     uint32_t *tail_dst;   /* ... at the front of the other input buffer (workgroup 0 copies them) */
     const uint32_t *afrag;   /* [nrb][kq][plane hi,lo][lane][4 dwords] */
     const int32_t *krow;     /* [nrb][16]: 128 * sum_k W[row][k] + 8192 */
@@ -182,6 +186,9 @@ struct mfm_launch_v3 {
                              x_last4, tail_* count samples all the same), the value is the first rounding's shift and
                              krow the matching row constants (mfm_kernel_v3.hip) */
     uint32_t in8_xor;     /* 0x80808080 when the bytes are unsigned (RTL-SDR), else 0 */
+    uint32_t stream_taps; /* filters of 129..512 taps (kq 8 / 16): 1 = re-read the taps from L2 in every iteration (128-register
+                             instances, two workgroups per CU where LDS allows); 0 = the resident instances (all taps in
+                             registers, 256 registers, one workgroup per CU) where one is built for the geometry */
     uint32_t *tail_dst;
     const uint32_t *afrag;
     const int32_t *krow;

@@ -43,6 +43,12 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #define MFM_M_NT (MFM_MFMA_NW * 64)
 
 #define MFM_M_NEW 31 /* new outputs per 32-column iteration */
+#ifndef MFM_RES_PF
+#define MFM_RES_PF 4 /* resident long-filter instances: k-steps of B fragments in flight ahead of the matrix instructions */
+#endif
+#ifndef MFM_RES_EARLY
+#define MFM_RES_EARLY 1 /* resident instances, single-iteration tiles: next tile's samples requested in front of the matrix phase */
+#endif
 /* sched_barrier mask: ALU | VALU | SALU | MFMA | DS | DS-read | DS-write may cross, vector memory may not */
 #define MFM_SCHED_ALL_BUT_VMEM 0x38F
 
@@ -120,6 +126,35 @@ static __device__ __forceinline__ void mfm_conj_mul(uint32_t q, uint32_t p, int 
     *s_im = (int)((uint32_t)u - (uint32_t)t); /* q_im*p_re - q_re*p_im */
 }
 
+/* "at most `younger` LDS requests issued after the ones that fill h (and l) are still outstanding": the wait in front of the
+ * products of a B fragment that was requested by inline asm.  The operands tie the wait to the registers, so the
+ * products cannot be scheduled in front of it. */
+template <bool ONE_PLANE>
+static __device__ __forceinline__ void mfm_wait_fragments(int younger, mfm_v4i &h, mfm_v4i &l)
+{
+#define MFM_WAIT_CASE(N_)                                                      \
+    case N_:                                                                   \
+        if (ONE_PLANE) {                                                       \
+            asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(h)::"memory");    \
+        } else {                                                               \
+            asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(h), "+v"(l)::"memory"); \
+        }                                                                      \
+        break;
+    switch (younger) {
+        MFM_WAIT_CASE(1) MFM_WAIT_CASE(2) MFM_WAIT_CASE(3) MFM_WAIT_CASE(4) MFM_WAIT_CASE(5) MFM_WAIT_CASE(6) MFM_WAIT_CASE(7)
+        MFM_WAIT_CASE(8) MFM_WAIT_CASE(9) MFM_WAIT_CASE(10) MFM_WAIT_CASE(11) MFM_WAIT_CASE(12) MFM_WAIT_CASE(13)
+        MFM_WAIT_CASE(14) MFM_WAIT_CASE(15)
+    default:
+        if (ONE_PLANE) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h)::"memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h), "+v"(l)::"memory");
+        }
+        break;
+    }
+#undef MFM_WAIT_CASE
+}
+
 /* Launder a value the compiler would otherwise use to hoist address arithmetic of rarely executed code (slice
  * change, first / last tile of a pass) out of the tile loop: those 64-bit addresses then sit in VGPRs for the whole
  * loop and push hot values into scratch, and every scratch reload is a VMEM access that costs a vmcnt(0). */
@@ -149,9 +184,20 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
  * NIT = iterations (31 new outputs each) per tile: 2, or 1 when a 62-output tile does not fit LDS (large decimations).
  * AHM >= 0: L.ah_mask as a compile-time constant (no branches between the MFMAs of a k-step); -1: read at run time.
  * IN8: the input is 8-bit IQ off the wire (two bytes per sample): one sample plane, two products per k-step, the first
- * rounding's shift in L.in8 (mfm_kernel_v3.hip has the arithmetic).  A staging chunk stays 4 samples - an 8-byte load. */
+ * rounding's shift in L.in8 (mfm_kernel_v3.hip has the arithmetic).  A staging chunk stays 4 samples - an 8-byte load.
+ *
+ * Waves per SIMD.  Instances that keep up to four (int16) or eight (8-bit) k-steps of taps in registers are built for 128
+ * vector registers, i.e. two workgroups per CU.  The RESIDENT long-filter instances (KC = 1 with KQ = 8 or 16: filters of
+ * 129..512 taps, all of whose taps stay in registers - up to 64 + 64 of them) are built for 256 registers and one workgroup
+ * per CU: what a long filter loses in occupancy it more than gets back by not re-reading 16..32 KB of taps per wave and
+ * iteration from L2. */
+constexpr int mfm_m_waves_per_simd(int KQ, int KC, bool IN8)
+{
+    return (KC == 1 && (KQ >= 16 || (KQ >= 8 && !IN8))) ? 2 : 4;
+}
+
 template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM, int NIT, bool IN8>
-__global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
+__global__ __launch_bounds__(MFM_M_NT, mfm_m_waves_per_simd(KQ, KC, IN8)) void mfm_channel_kernel_mfma(const mfm_launch_mfma L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -165,6 +211,10 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
     const uint32_t in8_sh = (uint32_t)__builtin_amdgcn_readfirstlane(L.in8);
+    /* the resident long-filter instances are built for decimations that are multiples of 4 only (a staging chunk never
+     * straddles two rows): the per-sample store path and the shuffles of the straddling load are not in their code */
+    constexpr bool RESIDENT = mfm_m_waves_per_simd(KQ, KC, IN8) == 2;
+    const bool split_rows = RESIDENT ? false : L.split_rows != 0u;
     /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
      * offset field of the LDS instructions instead of costing a v_add each (ds_read has no SGPR offset) */
     const uint32_t plane_dist = FIXP ? MFM_M_PLANE_DIST : L.plane_bytes;
@@ -239,13 +289,13 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 1));
             uint64_t w = (uint64_t)w2.x | ((uint64_t)w2.y << 32);
             const int sh8 = -g0;
-            if (L.split_rows && sh8 > 0 && sh8 < 4) {
+            if (split_rows && sh8 > 0 && sh8 < 4) {
                 w <<= 16 * sh8; /* the chunk that straddles the stream start keeps its real samples in place */
             }
             return make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
         }
         uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
-        if (L.split_rows) {
+        if (split_rows) {
             /* chunks start at any sample here: the one that straddles the stream start (g0 = -1 .. -3) holds real
              * samples behind the missing ones and must keep them in place (the clamp above moved them) */
             const int sh = -g0;
@@ -262,7 +312,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 const uint2 hi = make_uint2(v.x ^ m, v.y ^ m);
                 const uint32_t st = sta_s[j * MFM_M_NT + tid];
                 uint8_t *base = smem + buf * buf_bytes + (st & 0xffffu);
-                if (!L.split_rows) {
+                if (!split_rows) {
                     *reinterpret_cast<uint2 *>(base) = hi;
                 } else {
                     const uint32_t in_row = st >> 16, hop = rs - 2u * D;
@@ -282,7 +332,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
             lo.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u) ^ 0x80808080u;
             const uint32_t st = sta_s[j * MFM_M_NT + tid];
             uint8_t *base = smem + buf * buf_bytes + (st & 0xffffu); /* own slot: no barrier needed */
-            if (!L.split_rows) {
+            if (!split_rows) {
                 *reinterpret_cast<uint2 *>(base) = hi;
                 *reinterpret_cast<uint2 *>(base + plane_dist) = lo;
             } else {
@@ -455,7 +505,7 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
          * for the full tile instead of one iteration (a workgroup's last tile re-reads its own samples and stages them
          * into the idle buffer). */
         uint4 pre[NCH];
-        if (KC == 1 && NIT == 2) {
+        if (KC == 1 && (NIT == 2 || (RESIDENT && MFM_RES_EARLY))) { /* (the resident instances have the registers with one iteration too) */
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
                 pre[j] = stage_load(have_n ? tile_n : tile, j);
@@ -557,6 +607,61 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                 __builtin_amdgcn_sched_barrier(0);
                 finish_group(0, hh2[0], md2[0], ll2[0]);
                 finish_group(1, hh2[1], md2[1], ll2[1]);
+            } else if constexpr (RESIDENT) {
+                /* ---- resident long filters: two waves per SIMD do not cover an LDS round trip between one k-step's reads
+                 *      and its products the way four do, so the B fragments are requested MFM_RES_PF k-steps ahead - across
+                 *      the boundary of the two column groups - with the requests and their waits spelled out (left to
+                 *      itself the compiler sinks every read to just in front of its use).  lgkmcnt counts in order for
+                 *      LDS: a wait for "at most N younger requests outstanding" can only wait too long when the compiler
+                 *      has LDS traffic of its own in flight, never too briefly. ---- */
+                /* (the int16 instances that keep every high-byte tap plane have 128 tap registers: two k-steps ahead there;
+                 * measured, two and four and six are the same to within the noise - profiles/r03_resident_taps.txt) */
+                constexpr bool kAllPlanes = !IN8 && AHM == (1 << KQ) - 1 && KQ == 16;
+                constexpr int PF = kAllPlanes ? 2 : MFM_RES_PF, RPK = IN8 ? 1 : 2, SLOTS = PF + 1, NS = 2 * KQ;
+                static_assert(PF * RPK <= 15, "lgkmcnt is a 4-bit counter");
+                mfm_v4i hh[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } }, md[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } }, ll[2] = { krow, krow };
+                mfm_v4i bh[SLOTS], bl[SLOTS];
+                const uint32_t lds_h = (uint32_t)(uintptr_t)plane_h + it * MFM_M_NEW * rs;
+                auto request = [&](int st) { /* step st = column group st / KQ, k-step st % KQ */
+                    const uint32_t at = lds_h + (uint32_t)(st / KQ) * 16u * rs + boff[st % KQ];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bh[st % SLOTS]) : "v"(at) : "memory");
+                    if (!IN8) {
+                        const uint32_t at_l = at + plane_dist;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(bl[st % SLOTS]) : "v"(at_l) : "memory");
+                    }
+                };
+#pragma unroll
+                for (int st = 0; st < PF && st < NS; st++) {
+                    request(st);
+                }
+#pragma unroll
+                for (int st = 0; st < NS; st++) {
+                    const int gq = st / KQ, kq = st % KQ, cb = st % SLOTS;
+                    if (st + PF < NS) {
+                        request(st + PF);
+                    }
+                    mfm_wait_fragments<IN8>((NS - 1 - st < PF ? NS - 1 - st : PF) * RPK, bh[cb], bl[cb]);
+                    if (IN8) {
+                        if ((ah_mask >> kq) & 1u) {
+                            hh[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh[gq], 0, 0, 0);
+                        }
+                        ll[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], ll[gq], 0, 0, 0);
+                    } else {
+                        if ((ah_mask >> kq) & 1u) {
+                            hh[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bh[cb], hh[gq], 0, 0, 0);
+                            md[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq], bl[cb], md[gq], 0, 0, 0);
+                        }
+                        ll[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll[gq], 0, 0, 0);
+                        md[gq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md[gq], 0, 0, 0);
+                    }
+                    if (kq == KQ - 1) {
+                        /* MFMA -> VALU read hazard, see below; group 0 is finished while group 1's fragments arrive */
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish_group(gq, hh[gq], md[gq], ll[gq]);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) {
@@ -597,11 +702,11 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-    
+
                     finish_group(gq, hh, md, ll);
                 }
             }
-            if (KC == 1 && NIT == 1) {
+            if (KC == 1 && NIT == 1 && !(RESIDENT && MFM_RES_EARLY)) {
                 /* single-iteration tiles are the big ones (up to 8 chunks per thread): requested behind the matrix
                  * work, when the accumulators are about to die */
 #pragma unroll
@@ -730,11 +835,79 @@ __global__ __launch_bounds__(MFM_M_NT, 4) void mfm_channel_kernel_mfma(const mfm
 /* Which instance runs a launch description - decided by geometry fields that are fixed at commit (and the input format);
  * the engine asks once per format at commit, raises the instance's LDS limit there and launches through the pointer
  * (mfm_kernel_v3.hip has the same pair). */
-extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out)
+/*
+ * The resident long-filter instance for a launch description, or nullptr when none is built for it.  The tap-plane mask
+ * of an instance only has to COVER the filter's (a k-step whose high-byte plane is zero multiplies zeros, exactly): the
+ * four and the eight middle k-steps of sixteen (two and four of eight) are what windowed low-pass filters of 129..512
+ * taps produce at the gains multifm runs them at; anything else keeps every plane.  Staging chunks per thread round up
+ * to a built count (a surplus chunk is loaded and not stored).
+ */
+template <int KQ, int AHM, int NIT, bool IN8>
+static const void *mfm_resident_instance_nch(uint32_t nch)
+{
+    if constexpr (NIT == 2) {
+        return nch <= 2 ? reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ, false, false, 2, 1, AHM, NIT, IN8>)
+                        : reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ, false, false, 4, 1, AHM, NIT, IN8>);
+    } else {
+        return nch <= 4   ? reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ, false, false, 4, 1, AHM, NIT, IN8>)
+               : nch <= 6 ? reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ, false, false, 6, 1, AHM, NIT, IN8>)
+               : nch == 7 ? reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ, false, false, 7, 1, AHM, NIT, IN8>)
+                          : reinterpret_cast<const void *>(&mfm_channel_kernel_mfma<KQ, false, false, 8, 1, AHM, NIT, IN8>);
+    }
+}
+
+template <int KQ, int AHM, bool IN8>
+static const void *mfm_resident_instance_nit(const mfm_launch_mfma *L, uint32_t nch)
+{
+    return L->ot == MFM_M_NEW ? mfm_resident_instance_nch<KQ, AHM, 1, IN8>(nch) : mfm_resident_instance_nch<KQ, AHM, 2, IN8>(nch);
+}
+
+template <int KQ, bool IN8>
+static const void *mfm_resident_instance_mask(const mfm_launch_mfma *L, uint32_t nch)
+{
+    constexpr int kMid4 = KQ == 16 ? 0x03c0 : 0x18, kMid8 = KQ == 16 ? 0x0ff0 : 0x3c, kAll = KQ == 16 ? 0xffff : 0xff;
+    if ((L->ah_mask & ~(uint32_t)kMid4) == 0u) {
+        return mfm_resident_instance_nit<KQ, kMid4, IN8>(L, nch);
+    }
+    if ((L->ah_mask & ~(uint32_t)kMid8) == 0u) {
+        return mfm_resident_instance_nit<KQ, kMid8, IN8>(L, nch);
+    }
+    return mfm_resident_instance_nit<KQ, kAll, IN8>(L, nch);
+}
+
+static const void *mfm_resident_instance(const mfm_launch_mfma *L, int dbg_iq, uint32_t nch)
+{
+    if (dbg_iq || L->stream_taps || L->fixed_planes || L->split_rows || (L->kq != 8u && L->kq != 16u)) {
+        return nullptr;
+    }
+    if (L->ot != MFM_M_NEW && nch > 4u) {
+        return nullptr;
+    }
+    if (L->kq == 16u) {
+        return L->in8 ? mfm_resident_instance_mask<16, true>(L, nch) : mfm_resident_instance_mask<16, false>(L, nch);
+    }
+    /* eight k-steps: the 8-bit form has 128-register instances that hold them (below); the int16 form gets them here */
+    return L->in8 ? nullptr : mfm_resident_instance_mask<8, false>(L, nch);
+}
+
+/* waves_per_simd_out: what the chosen instance is built for (4: two workgroups of 8 waves per CU where LDS allows, 2: one) */
+extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out,
+                                                     uint32_t *waves_per_simd_out)
 {
     *kfn_out = nullptr;
+    *waves_per_simd_out = 4;
     if (L->in8 && dbg_iq) {
         return hipErrorInvalidValue;
+    }
+    {
+        const uint32_t nch_r = ((L->nstage >> 2) + MFM_M_NT - 1) / MFM_M_NT;
+        /* the 128-register int16 instances of five and six k-steps (below) multiply less than a resident eight would */
+        const void *fn = nch_r >= 1 && nch_r <= MFM_M_CH_MAX ? mfm_resident_instance(L, dbg_iq, nch_r) : nullptr;
+        if (fn && !(L->kq == 8u && (L->kq_used == 5u || L->kq_used == 6u) && nch_r == 1 && L->ot != MFM_M_NEW)) {
+            *kfn_out = fn;
+            *waves_per_simd_out = 2;
+            return hipSuccess;
+        }
     }
 #define MFM_LAUNCH_N(KQ_, DBG_, FIXP_, NCH_)                                                                 \
     do {                                                                                                     \
