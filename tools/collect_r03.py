@@ -35,12 +35,15 @@ with open(os.path.join(P, "r03_bench_lines.jsonl"), "w") as fo:
         d = dict(d)
         d["_run"] = k
         fo.write(json.dumps(d) + "\n")
-order = ["driverflags", "default", "grid64", "mfma1", "dot2", "c128", "c256", "c1024", "grid1024", "cfg5_256", "pocsag_d25",
-         "multifm_d40", "multifm_d40_mfma1"]
+order = ["driverflags", "default", "grid64", "mfma1", "dot2", "c128", "c256", "c1024", "grid1024", "cfg5_256", "cfg5_256_streamed",
+         "t512_auto", "t512_mfma1s", "t256_auto", "t256_mfma1s", "pocsag_d25", "multifm_d40", "multifm_d40_mfma1"]
 what = {"driverflags": "cfg2, driver's flags", "default": "cfg2, defaults", "grid64": "cfg2 geometry, every channel on the 12.5 kHz raster",
         "mfma1": "cfg2, first-generation kernel", "dot2": "cfg2, v_dot2 kernel", "c128": "128 channels (configs[2] shard)",
         "c256": "256 channels", "c1024": "1024 channels on one GPU", "grid1024": "1024 channels on the 12.5 kHz raster",
-        "cfg5_256": "configs[4] per-GPU share: 256 ch, D = 400, 512 taps", "pocsag_d25": "etc/pocsag_rtlsdr.json geometry: 64 ch, D = 25",
+        "cfg5_256": "configs[4] per-GPU share: 256 ch, D = 400, 512 taps (taps resident)",
+        "cfg5_256_streamed": "the same, taps streamed from L2 (MFM_F_STREAM_TAPS, the round-1/2 form)",
+        "t512_auto": "64 ch, D = 96, 512 taps (taps resident)", "t512_mfma1s": "the same, taps streamed",
+        "t256_auto": "64 ch, D = 96, 256 taps (taps resident)", "t256_mfma1s": "the same, taps streamed", "pocsag_d25": "etc/pocsag_rtlsdr.json geometry: 64 ch, D = 25",
         "multifm_d40": "etc/multifm.json geometry: 64 ch, 1 MS/s, D = 40", "multifm_d40_mfma1": "the same, first-generation kernel"}
 hdr = "run                kernel                     value(MSamp/s x ch)  ms/step  kernel_ms  min     median  p95     hbm_frac  compute_frac  issued  verified"
 rows = [hdr]
@@ -204,6 +207,11 @@ d40v3, d40v1 = lines["multifm_d40"]["roofline"]["kernel_ms"], lines["multifm_d40
 vals = {"ms_step": f"{head['ms_per_step']:.4f}", "kernel_ms": f"{head['roofline']['kernel_ms']:.4f}", "frac": f"{head['roofline']['frac']:.3f}",
         "gap_us": f"{(head['ms_per_step'] - head['roofline']['kernel_ms']) * 1e3:.1f}", "d40_v3": f"{d40v3:.4f}", "d40_v1": f"{d40v1:.4f}",
         "d40_gain": f"−{100 * (1 - d40v3 / d40v1):.0f} %"}
+for key, a, b_ in (("cfg5", "cfg5_256", "cfg5_256_streamed"), ("t512", "t512_auto", "t512_mfma1s"), ("t256", "t256_auto", "t256_mfma1s")):
+    if a in lines and b_ in lines:
+        ra, rb = lines[a]["roofline"]["kernel_ms"], lines[b_]["roofline"]["kernel_ms"]
+        vals[key + "_res"], vals[key + "_str"], vals[key + "_gain"] = f"{ra:.4f}", f"{rb:.4f}", f"−{100 * (1 - ra / rb):.0f} %"
+        vals[key + "_mfma"] = f"{lines[a]['compute_roofline']['frac']:.2f}"
 # the exchange table of DESIGN.md section 7
 blk_mb = head["config"]["block_samples"] * 4 / 1e6
 xt = ["| channels per GPU | kernel per block | needed per peer (int16 / 8-bit) | broadcast (≈ 153 GB/s per GPU) | all-gather on 7 links (≈ 940 GB/s at N = 8) |",

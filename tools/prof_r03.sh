@@ -17,6 +17,10 @@ for c in 128 256 1024; do
 done
 timeout 600 python bench.py --config cfg3_1024ch_grid --channels-per-gpu 1024 --steps 40 --warmup 5 $N > $O/bench_grid1024.json 2> $O/bench_grid1024.err
 timeout 600 python bench.py --config cfg5_airspy --channels-per-gpu 256 --steps 40 --warmup 5 $N > $O/bench_cfg5_256.json 2> $O/bench_cfg5_256.err
+timeout 600 python bench.py --config cfg5_airspy --channels-per-gpu 256 --kernel mfma1s --steps 40 --warmup 5 $N > $O/bench_cfg5_256_streamed.json 2> $O/bench_cfg5_256_streamed.err
+for t in 512 256; do for k in auto mfma1s; do
+  timeout 600 python bench.py --config cfg2_64ch_${t}taps --kernel $k --steps 40 --warmup 5 $N > $O/bench_t${t}_$k.json 2> $O/bench_t${t}_$k.err
+done; done
 timeout 600 python bench.py --config pocsag_rtlsdr --channels-per-gpu 64 --steps 60 --warmup 5 $N > $O/bench_pocsag_d25.json 2> $O/bench_pocsag_d25.err
 timeout 600 python bench.py --config multifm_1ch --channels-per-gpu 64 --steps 60 --warmup 5 $N > $O/bench_multifm_d40.json 2> $O/bench_multifm_d40.err
 timeout 600 python bench.py --config multifm_1ch --channels-per-gpu 64 --kernel mfma1 --steps 60 --warmup 5 $N > $O/bench_multifm_d40_mfma1.json 2> $O/bench_multifm_d40_mfma1.err
