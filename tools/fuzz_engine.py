@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def case(pkg, ora, rng):
+def case(pkg, ora, rng, long_only=False):
     b = pkg.binding
     decim = int(rng.choice([25, 32, 40, 40, 64, 96, 96, 96, 100, 128, 400, 8 * int(rng.randint(1, 16)), int(rng.randint(6, 200))]))
     fs = int(rng.choice([1000000, 1200000, 2400000, 10000000]))
@@ -25,8 +25,15 @@ def case(pkg, ora, rng):
     ntaps = max(ntaps, decim)
     if ntaps > 600:
         ntaps = 512 if decim <= 512 else decim
+    if long_only:
+        # filters of 129..512 taps at any decimation up to 460: the resident and the streamed instances of the first-generation
+        # matrix kernel over their staging-chunk counts, tile forms and tap-plane masks
+        decim = int(rng.choice([int(rng.randint(8, 461)), 4 * int(rng.randint(2, 116)), 8 * int(rng.randint(1, 58)), 96, 400]))
+        ntaps = max(decim, int(rng.choice([int(rng.randint(129, 513)), 129, 160, 256, 257, 400, 512])))
     nch = int(rng.choice([1, 2, 5, 8, 9, 16, 33, 64, 65, 130, int(rng.randint(1, 300))]))
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
+    if long_only and rng.rand() < 0.25:
+        taps = rng.uniform(-0.3, 0.3, ntaps)  # high bytes in every k-step: the all-planes instances
     offs = rng.randint(-fs // 2, fs // 2, size=nch)
     offs[: min(nch, 4)] = [0, 25000, -37500, 3125][: min(nch, 4)]
     if fs % (4 * decim) == 0 and rng.rand() < 0.6:
@@ -38,13 +45,17 @@ def case(pkg, ora, rng):
     gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
     kernel = str(rng.choice(["auto", "auto", "mfma1", "dot2"]))
     want_iq = bool(rng.rand() < 0.5)
+    stream = bool(rng.rand() < 0.2)
+    if long_only:
+        kernel, want_iq = "auto", bool(rng.rand() < 0.15)
     n = int(rng.randint(ntaps, 400000))
     if rng.rand() < 0.5:
         iq = pkg.synth.random_iq(n, seed=int(rng.randint(1 << 30)))
     else:
         iq = pkg.synth.synth_iq(n, fs, offs[: min(nch, 6)], seed=int(rng.randint(1 << 30)))
     max_block = int(rng.choice([n, 65536, 8192, 100000]))
-    flags = (b.MFM_F_FORCE_DOT2 if kernel == "dot2" else 0) | (b.MFM_F_FORCE_MFMA_V1 if kernel == "mfma1" else 0)
+    flags = (b.MFM_F_FORCE_DOT2 if kernel == "dot2" else 0) | (b.MFM_F_FORCE_MFMA_V1 if kernel == "mfma1" else 0) | \
+            (b.MFM_F_STREAM_TAPS if stream else 0)
     try:
         eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
         for o, g in zip(offs, gains):
@@ -53,6 +64,7 @@ def case(pkg, ora, rng):
     except pkg.MfmError as e:
         return None, "refused: %s" % e
     variant = eng.stats()["kernel_variant"]
+    resident = eng.stats()["taps_resident"]
     cre = np.stack([eng.get_channel(c)[0] for c in range(nch)])
     cim = np.stack([eng.get_channel(c)[1] for c in range(nch)])
     incr = np.stack([eng.get_channel(c)[2] for c in range(nch)])
@@ -67,16 +79,17 @@ def case(pkg, ora, rng):
     eng.close()
     got = np.concatenate(outs, axis=1)
     ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=8, want_iq=want_iq)
-    desc = "fs %d D %d T %d C %d kernel %s/%d n %d max_block %d iq %s" % (fs, decim, ntaps, nch, kernel, variant, n, max_block, want_iq)
+    desc = "fs %d D %d T %d C %d kernel %s/%d resident %d n %d max_block %d iq %s" % (fs, decim, ntaps, nch, kernel, variant, resident, n,
+                                                                                      max_block, want_iq)
     if got.shape != ref.shape or not np.array_equal(got, ref):
         return "PCM differs: " + desc, desc
     qs = [q for q in outq if q is not None]
     if want_iq and refq is not None and refq.shape[1] > 0 and (not qs or not np.array_equal(np.concatenate(qs, axis=1), refq)):
         return "filtered IQ differs: " + desc, desc
-    return None, variant
+    return None, 3 if resident else variant
 
 
-def case8(pkg, ora, rng):
+def case8(pkg, ora, rng, long_only=False):
     """8-bit ingest: a stream of blocks in the reference's 8-bit formats (mostly one format, now and then another one or
     int16), each block widened for the oracle the way the reference's front ends widen it; geometries drawn so that the
     kernel that reads bytes runs in most cases."""
@@ -84,6 +97,9 @@ def case8(pkg, ora, rng):
     decim = int(rng.choice([32, 64, 96, 96, 96, 128, 160, 25, 40]))
     fs = int(rng.choice([1200000, 2400000]))
     ntaps = max(decim, int(rng.choice([32, 64, 128, 128, 100, 96])))
+    if long_only:
+        decim = int(rng.choice([4 * int(rng.randint(2, 116)), 8 * int(rng.randint(1, 58)), 96, 400]))
+        ntaps = max(decim, int(rng.choice([int(rng.randint(257, 513)), 300, 400, 512])))
     nch = int(rng.choice([1, 3, 8, 9, 16, 64, 65, 130]))
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     offs = rng.randint(-fs // 2, fs // 2, size=nch)
@@ -96,7 +112,7 @@ def case8(pkg, ora, rng):
         offs = np.where(snap, q * rng.randint(-2 * decim + 1, 2 * decim, size=nch), offs)
     gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
     max_block = int(rng.choice([65536, 8192, 100000]))
-    flags = b.MFM_F_WIDEN_8BIT if rng.rand() < 0.15 else 0
+    flags = (b.MFM_F_WIDEN_8BIT if rng.rand() < 0.15 else 0) | (b.MFM_F_STREAM_TAPS if rng.rand() < 0.2 else 0)
     try:
         eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
         for o, g in zip(offs, gains):
@@ -149,6 +165,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ingest8", action="store_true", help="8-bit ingest streams (mfm_engine_push_bytes) instead")
+    ap.add_argument("--long", action="store_true", help="filters of 129..512 taps only (resident and streamed tap instances)")
     args = ap.parse_args()
     from __graft_entry__ import load_package
     import oracle_lib as ora
@@ -157,7 +174,7 @@ def main():
     t0 = time.time()
     counts = {}
     while time.time() - t0 < args.seconds:
-        err, info = case8(pkg, ora, rng) if args.ingest8 else case(pkg, ora, rng)
+        err, info = case8(pkg, ora, rng, args.long) if args.ingest8 else case(pkg, ora, rng, args.long)
         if err:
             print("FAIL", err, "after", counts)
             return 1
@@ -167,7 +184,7 @@ def main():
             continue
         key = info if isinstance(info, (int, np.integer)) else "refused"
         counts[int(key) if key != "refused" else key] = counts.get(int(key) if key != "refused" else key, 0) + 1
-    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2; --ingest8: by how the blocks were read)", counts)
+    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2, 3 matrix gen 1 with resident taps; --ingest8: by how the blocks were read)", counts)
     return 0
 
 
