@@ -111,3 +111,25 @@ def test_stages_without_gpu_fail_loudly(pkg):
         assert ei.value.code == b.MFM_E_DEVICE
     with pytest.raises(pkg.MfmError):
         b.bch3121_decode(np.zeros(4, np.uint32))
+
+
+def test_asm_scheduled_instances_do_not_spill():
+    """The resident long-filter instances of the first-generation matrix kernel request their LDS fragments by
+    inline asm and wait for them explicitly: a fragment register the compiler saved to scratch between the request and the wait
+    would save what was in it before the data arrived.  So none of them may spill (tools/kernel_regs.py reads the code
+    object's notes; the build leaves the object under tsl-sdr_amd/build)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(root, "tsl-sdr_amd", "build", "mfm_kernel_mfma.o")
+    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no built object / no llvm tools here")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), obj, "mfm_channel_kernel_mfma<"],
+                         capture_output=True, text=True, check=True).stdout
+    resident = [ln for ln in out.splitlines()
+                if re.search(r"mfma<(16, false, false, \d, 1, \d+, [12], (true|false)|8, false, false, \d, 1, \d+, [12], false)>", ln)]
+    assert len(resident) >= 50, len(resident)
+    for ln in resident:
+        m = re.search(r"vgpr\s+(\d+) agpr\s+\d+ spill\s+(\d+)", ln)
+        assert m and int(m.group(1)) <= 256 and int(m.group(2)) == 0, ln

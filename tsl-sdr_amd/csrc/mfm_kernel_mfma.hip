@@ -615,9 +615,11 @@ __global__ __launch_bounds__(MFM_M_NT, mfm_m_waves_per_simd(KQ, KC, IN8)) void m
                  *      LDS: a wait for "at most N younger requests outstanding" can only wait too long when the compiler
                  *      has LDS traffic of its own in flight, never too briefly. ---- */
                 /* (the int16 instances that keep every high-byte tap plane have 128 tap registers: two k-steps ahead there;
-                 * measured, two and four and six are the same to within the noise - profiles/r03_resident_taps.txt) */
+                 * measured, two and four and six are the same to within the noise - profiles/r03_resident_taps.txt.  No
+                 * instance may spill: a fragment register saved to scratch between its request and its wait would save
+                 * what was in it before the data arrived) */
                 constexpr bool kAllPlanes = !IN8 && AHM == (1 << KQ) - 1 && KQ == 16;
-                constexpr int PF = kAllPlanes ? 2 : MFM_RES_PF, RPK = IN8 ? 1 : 2, SLOTS = PF + 1, NS = 2 * KQ;
+                constexpr int PF = kAllPlanes ? (NCH >= 8 ? 1 : 2) : MFM_RES_PF, RPK = IN8 ? 1 : 2, SLOTS = PF + 1, NS = 2 * KQ;
                 static_assert(PF * RPK <= 15, "lgkmcnt is a 4-bit counter");
                 mfm_v4i hh[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } }, md[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } }, ll[2] = { krow, krow };
                 mfm_v4i bh[SLOTS], bl[SLOTS];
