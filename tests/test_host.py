@@ -334,3 +334,33 @@ def test_group_push_is_all_or_nothing_and_fetch_never_sees_half_a_push(tmp_path)
     env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}  # tools/sanitize_cpu.sh preloads ASan: not into a TSan binary
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "all checks held" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+def test_multifm_driver_soak_ten_thousand_buffers(tmp_path, pkg, ora):
+    """The C host end to end at length: 10 000 sample_bufs of a cs8 capture (41 M samples) through file_if -> receiver ->
+    submit / drain threads -> 64 demod_thread sinks at the 2.4 MS/s / D = 96 plan.  Every sink must hold exactly the
+    stream's outputs; six channels are compared with the oracle over three windows of 2 048 outputs each (first, middle,
+    last), the first one also against the oracle's plain stream run to pin the numbering."""
+    fs, decim, center = 2400000, 96, 152000000
+    taps_file = os.path.join(ROOT, "etc", "lpf_25khz_2400k_128.json")
+    if not os.path.exists(taps_file):
+        pytest.skip("no 2.4 MS/s tap file in etc/")
+    taps = np.array(json.load(open(taps_file))["lpfTaps"])
+    offs = [int(o) for o in pkg.synth.channel_offsets(64, fs)]
+    n = 4096 * 10000 + 777
+    rng = np.random.RandomState(5)
+    b = rng.randint(0, 256, size=(n, 2)).astype(np.uint8)
+    iq = ora.unpack_bytes(b, 1).reshape(-1, 2)
+    pcm, _ = _run_multifm(tmp_path, pkg, "cs8", iq, b.tobytes(), fs, decim, center, offs, taps_file)
+    n_out = (n - len(taps)) // decim + 1
+    for c in range(64):
+        assert pcm[c].size == n_out, (c, pcm[c].size, n_out)
+    for c in (0, 7, 8, 31, 40, 63):
+        cre, cim = ora.make_taps(taps, offs[c], fs, 1.0)
+        incr = ora.rot_incr(offs[c], fs, decim)
+        head, _ = ora.run_channels(iq[:decim * 2100 + len(taps)], cre[None], cim[None], incr[None], decim)
+        assert np.array_equal(pcm[c][:2100], head[0][:2100]), f"channel {c}: head differs"
+        for w0 in (1, n_out // 2, n_out - 2048):
+            want = ora.window_pcm(iq, cre, cim, decim, incr, 0, w0, 2048)
+            assert np.array_equal(pcm[c][w0:w0 + 2048], want), f"channel {c}: window at {w0} differs"
