@@ -503,7 +503,8 @@ def main():
                 "delivered_GBps_total": block * 4 * (world - 1) / (dt / args.steps) / 1e9,
                 "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7},
             "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],
-                         "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"]},
+                         "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"],
+                         "k_steps": st1["k_steps"], "tap_hi_mask": st1["tap_hi_mask"], "taps_resident": st1["taps_resident"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, fs, decim, taps, offs, gains, args.cpu_seconds)
