@@ -192,7 +192,7 @@ def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntap
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
 
 
-@pytest.mark.parametrize("shape", ["lpf", "lpf_x8", "dense"])
+@pytest.mark.parametrize("shape", ["lpf_div8", "lpf", "lpf_x8", "dense"])
 @pytest.mark.parametrize("decim,ntaps", [(96, 512), (96, 256), (96, 300), (48, 129), (400, 512), (320, 512), (200, 256),
                                          (256, 256), (136, 160), (448, 512), (100, 400)])
 def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape):
@@ -200,11 +200,12 @@ def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape
     kernel (all 8 / 16 k-steps of taps in registers, 256 registers, one workgroup per CU); MFM_F_STREAM_TAPS selects the
     round-1 form that re-reads them from L2.  Both against the oracle, over the instance families: two-iteration and
     single-iteration tiles, 2..8 staging chunks per thread, padded rows (D = 100), and the three tap-plane masks an
-    instance can be built for - a plain low-pass (high bytes in the middle k-steps only), the same at 18 dB (more of
-    them), and dense random taps (every plane)."""
+    instance can be built for - none (a low-pass whose taps all fit one byte, the configs[4] filter at 10 MS/s), a plain
+    low-pass (high bytes in the middle k-steps only), the same at 18 dB (more of them), and dense random taps (every plane)."""
     fs = 4000000
     rng = np.random.RandomState(decim + ntaps)
-    taps = {"lpf": lambda: pkg.synth.design_lpf(ntaps, 12500.0, fs),
+    taps = {"lpf_div8": lambda: pkg.synth.design_lpf(ntaps, 12500.0, fs) / 8.0,  # every tap fits one byte: no high plane at all
+            "lpf": lambda: pkg.synth.design_lpf(ntaps, 12500.0, fs),
             "lpf_x8": lambda: pkg.synth.design_lpf(ntaps, 12500.0, fs) * 8.0,
             "dense": lambda: rng.uniform(-0.3, 0.3, ntaps)}[shape]()
     offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-10, 11)]
@@ -218,6 +219,8 @@ def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape
         masks[kernel] = st["tap_hi_mask"]
         _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=False, kernel=kernel)
         _check(pkg, ora, fs, decim, taps, offs, iq, 30001, want_iq=False, kernel=kernel)
+    if shape == "lpf_div8":
+        assert masks["auto"] == 0
     if shape == "dense":  # high bytes in every k-step that holds taps: the all-planes instance
         assert masks["auto"] & ~(0x0ff0 if st["k_steps"] == 16 else 0x3c), hex(masks["auto"])
     # a filtered-IQ consumer: the streamed form (the resident instances are not built with the IQ store)
@@ -227,7 +230,7 @@ def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape
 
 
 @pytest.mark.parametrize("fmt", [1, 2, 3])
-@pytest.mark.parametrize("decim,ntaps,gain", [(96, 512, 1.0), (96, 400, 8.0), (400, 512, 1.0), (200, 500, 30.0)])
+@pytest.mark.parametrize("decim,ntaps,gain", [(96, 512, 1.0), (96, 400, 8.0), (400, 512, 1.0), (200, 500, 30.0), (400, 512, 0.1)])
 def test_long_filters_on_8bit_blocks_resident_and_streamed(pkg, ora, fmt, decim, ntaps, gain):
     """The same for 8-bit blocks read as bytes (one sample plane, sixteen k-steps of taps in registers)."""
     fs = 2400000

@@ -839,8 +839,8 @@ __global__ __launch_bounds__(MFM_M_NT, mfm_m_waves_per_simd(KQ, KC, IN8)) void m
  * (mfm_kernel_v3.hip has the same pair). */
 /*
  * The resident long-filter instance for a launch description, or nullptr when none is built for it.  The tap-plane mask
- * of an instance only has to COVER the filter's (a k-step whose high-byte plane is zero multiplies zeros, exactly): the
- * four and the eight middle k-steps of sixteen (two and four of eight) are what windowed low-pass filters of 129..512
+ * of an instance only has to COVER the filter's (a k-step whose high-byte plane is zero multiplies zeros, exactly): none,
+ * the four and the eight middle k-steps of sixteen (two and four of eight) are what windowed low-pass filters of 129..512
  * taps produce at the gains multifm runs them at; anything else keeps every plane.  Staging chunks per thread round up
  * to a built count (a surplus chunk is loaded and not stored).
  */
@@ -868,6 +868,9 @@ template <int KQ, bool IN8>
 static const void *mfm_resident_instance_mask(const mfm_launch_mfma *L, uint32_t nch)
 {
     constexpr int kMid4 = KQ == 16 ? 0x03c0 : 0x18, kMid8 = KQ == 16 ? 0x0ff0 : 0x3c, kAll = KQ == 16 ? 0xffff : 0xff;
+    if (L->ah_mask == 0u) { /* every tap fits one byte (the 512-tap 12.5 kHz low-pass at 10 MS/s: largest tap 82): two products per k-step */
+        return mfm_resident_instance_nit<KQ, 0, IN8>(L, nch);
+    }
     if ((L->ah_mask & ~(uint32_t)kMid4) == 0u) {
         return mfm_resident_instance_nit<KQ, kMid4, IN8>(L, nch);
     }
