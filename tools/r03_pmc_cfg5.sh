@@ -20,9 +20,19 @@ for k in ("auto", "mfma1s"):
                 if "mfm_channel_kernel" in r["Kernel_Name"]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     out.append("== %s ==" % ("taps resident" if k == "auto" else "taps streamed (MFM_F_STREAM_TAPS)"))
+    m = {}
     for c, v in sorted(acc.items()):
         v = v[len(v) // 2:]
-        out.append(f"{c:30s} launches={len(v):2d} mean={sum(v) / len(v):.6g}")
+        m[c] = sum(v) / len(v)
+        out.append(f"{c:30s} launches={len(v):2d} mean={m[c]:.6g}")
+    cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+    other = m["SQ_INSTS_VALU"] - m["SQ_INSTS_MFMA"]
+    out.append(f"  launch length {cyc:.4g} cycles; matrix pipe busy {100 * m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc):.1f} % of SIMD cycles; "
+               f"other VALU {other:.4g} instructions = {100 * 3 * other / (1024 * cyc):.1f} % at 3 cycles each; "
+               f"SALU {m['SQ_INSTS_SALU']:.3g}, LDS {m['SQ_INSTS_LDS']:.3g}, VMEM reads {m['SQ_INSTS_VMEM_RD']:.3g} instructions")
+    out.append(f"  waves: issuing {100 * m['SQ_ACTIVE_INST_ANY'] / m['SQ_WAVE_CYCLES']:.0f} %, waiting for an issue slot "
+               f"{100 * m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.0f} %, waiting for data {100 * m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.0f} % of their cycles; "
+               f"HBM reads {2 * m['FETCH_SIZE'] * 1024 / 1e6:.0f} MB per launch (2 x FETCH_SIZE)")
 open("gpurun_out/r03pmc5/summary.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
 PY
