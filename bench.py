@@ -230,6 +230,54 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
             "ms_per_block": total, "value": block * len(offs) / total / 1e3, "unit": "MSamp/s x channels"}
 
 
+def other_geometries(pkg, torch, block, steps=24, settle_s=0.25):
+    """The reference's other deployed geometries on the same engine, outside the timed region (never part of `value`): the
+    int16 path of BASELINE configs[4] (per-GPU share: 256 of the 2048 Airspy channels, D = 400, 512-tap low-pass - the
+    resident long-filter instances), the channelizer geometry of configs[3] (etc/pocsag_rtlsdr.json:
+    1.2 MS/s, D = 25) and of etc/multifm.json (1 MS/s, D = 40), 64 channels each.  Same protocol as the headline: blocks
+    resident in HBM, a settle phase of back-to-back launches, kernel duration from the engine's HIP events."""
+    b = pkg.binding
+    lib = pkg.load_library()
+    out = {}
+    for key, plan, nch in (("configs4_int16_share", "cfg5_airspy", 256), ("configs3_pocsag_d25", "pocsag_rtlsdr", 64),
+                           ("multifm_json_d40", "multifm_1ch", 64)):
+        try:
+            fs, decim, taps, offs, gains = pkg.synth.plan(plan, nr_channels=nch)
+            in_bytes = lib.mfm_engine_input_bytes(block, len(taps))
+            bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+            eng = pkg.Engine(fs, decim, block, device=torch.cuda.current_device(), flags=b.MFM_F_DEVICE_ONLY | b.MFM_F_TIMING,
+                             ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
+            for o, g in zip(offs, gains):
+                eng.add_channel(int(o), taps, float(g))
+            eng.commit()
+            base = pkg.synth.synth_iq(1 << 22, fs, offs[:: max(1, len(offs) // 8)][:8], seed=11)
+            host = np.tile(base, (-(-(in_bytes // 4) // base.shape[0]), 1))[: in_bytes // 4].reshape(-1)
+            for t in bufs:
+                t.copy_(torch.from_numpy(host))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < settle_s:
+                for _ in range(8):
+                    eng.acquire_input()
+                    eng.submit(block, producer_stream=0, wait_producer=False)
+                eng.sync()
+            for _ in range(steps):
+                eng.acquire_input()
+                eng.submit(block, producer_stream=0, wait_producer=False)
+            eng.sync()
+            ms = float(np.mean(eng.launch_ms(steps)))
+            st = eng.stats()
+            eng.close()
+            del bufs
+            out[key] = {"channels": nch, "sample_rate_hz": fs, "decimation": decim, "taps": len(taps), "block_samples": block,
+                        "kernel_ms": ms, "value": block * nch / ms / 1e3, "unit": "MSamp/s x channels",
+                        "kernel_variant": st["kernel_variant"], "taps_resident": st["taps_resident"],
+                        "k_steps": st["k_steps"], "tap_hi_mask": st["tap_hi_mask"]}
+        except Exception as e:  # a side line must never take the headline down
+            out[key] = {"error": repr(e)}
+    return out
+
+
 def ingest_8bit(pkg, fs, decim, taps, offs, gains, block, int16_kernel_ms, steps=6, warmup=2):
     """the same channels fed with an RTL-SDR block (8-bit IQ, multifm/rtl_sdr_if.c:146-148) that the
     matrix kernel reads as bytes, outside the timed region; kernel duration from the engine's HIP
@@ -519,6 +567,7 @@ def main():
         line["flex_chain"] = flex_chain(pkg, torch, fs, decim, taps, offs, gains, block)
         if line["roofline"]["kernel"].startswith("mfm_channel_kernel_v3"):
             line["ingest_8bit"] = ingest_8bit(pkg, fs, decim, taps, offs, gains, block, line["roofline"]["kernel_ms"])
+        line["other_geometries"] = other_geometries(pkg, torch, block)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
