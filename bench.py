@@ -278,6 +278,84 @@ def other_geometries(pkg, torch, block, steps=24, settle_s=0.25):
     return out
 
 
+def block_series(pkg, torch, fs, decim, taps, offs, gains, total_log2=33, settle_s=0.3):
+    """SURVEY.md 8(d)'s protocol - blocks of 2^20 samples (4 MiB; >= 64 per timing), and 2^22 and 2^26 beside them - resident in
+    HBM and handed to the engine ONE BY ONE by a C producer loop (mfm_engine_replay: acquire_input + submit per block, what
+    a C host does per delivered sample_buf).  Two engines per block size: `coalesced` gathers the backlog into launches of up
+    to 2^26 samples (mfm_engine_config::coalesce_samples; a channel thread of the reference drains up to 128 queued
+    buffers in one go, multifm/demod.c:134-150,297), `per_block` launches every block on its own (coalesce_samples = 0).
+    Wall time around the loop + sync; frac = SURVEY 8(d)'s algorithmic bytes / that time / 8 TB/s.  Outside the timed region,
+    never part of `value`."""
+    b = pkg.binding
+    out = {"protocol": "blocks resident in HBM, C producer loop (mfm_engine_replay), wall clock around loop + sync after a "
+                       f"settle phase; 2^{total_log2} samples per timing", "coalesce_samples": 1 << 26, "series": []}
+    nch, T = len(offs), len(taps)
+    for blog in (20, 22, 26):
+        block = 1 << blog
+        row = {"block_samples": block, "blocks": (1 << total_log2) // block}
+        for mode, co in (("coalesced", 1 << 26), ("per_block", 0)):
+            try:
+                eng = pkg.Engine(fs, decim, block, device=torch.cuda.current_device(), flags=b.MFM_F_DEVICE_ONLY,
+                                 coalesce_samples=co)
+                for o, g in zip(offs, gains):
+                    eng.add_channel(int(o), taps, float(g))
+                eng.commit()
+                cfg = b.EngineConfig()
+                cfg.max_block_samples, cfg.coalesce_samples = block, co
+                in_bytes = eng.lib.mfm_engine_input_bytes_cfg(ctypes_byref(cfg), T, None)
+                base = torch.from_numpy(pkg.synth.synth_iq(1 << 20, fs, offs[:: max(1, nch // 8)][:8], seed=7).reshape(-1)).cuda()
+                seen = set()
+                for _ in range(3):
+                    ptr, cap = eng.acquire_input()
+                    if ptr not in seen:   # fill every input buffer once (they are the engine's own)
+                        seen.add(ptr)
+                        n16 = (in_bytes - 4 * (T + 64)) // 2
+                        dst = _as_tensor(torch, ptr, n16)
+                        reps = -(-n16 // base.numel())
+                        dst.copy_(base.repeat(reps)[:n16])
+                    torch.cuda.synchronize()
+                    eng.submit(block, producer_stream=0, wait_producer=False)
+                    eng.flush()
+                eng.sync()
+                nblk = row["blocks"]
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < settle_s:
+                    eng.replay(block, max(1, nblk // 8))
+                eng.sync()
+                st0 = eng.stats()
+                t0 = time.perf_counter()
+                eng.replay(block, nblk)
+                t_sub = time.perf_counter() - t0
+                eng.sync()
+                dt = time.perf_counter() - t0
+                st1 = eng.stats()
+                eng.close()
+                outs = st1["outputs"] - st0["outputs"]
+                alg = nblk * block * 4 + nch * outs * 2
+                row[mode] = {"launches": st1["launches"] - st0["launches"], "us_per_block": dt / nblk * 1e6,
+                             "producer_us_per_block": t_sub / nblk * 1e6,
+                             "input_msamp_per_s": nblk * block / dt / 1e6, "value": nblk * block * nch / dt / 1e6,
+                             "achieved_GBps": alg / dt / 1e9, "frac": alg / dt / 1e9 / HBM_PEAK_GBPS}
+            except Exception as e:  # a side line must never take the headline down
+                row[mode] = {"error": repr(e)}
+        out["series"].append(row)
+    return out
+
+
+def ctypes_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
+def _as_tensor(torch, ptr, n_int16):
+    """a torch view of n_int16 int16 elements of device memory at `ptr` (the engine's own input buffer)"""
+    class _Ext:
+        pass
+    holder = _Ext()
+    holder.__cuda_array_interface__ = {"shape": (n_int16,), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(holder, device="cuda")
+
+
 def ingest_8bit(pkg, fs, decim, taps, offs, gains, block, int16_kernel_ms, steps=6, warmup=2):
     """the same channels fed with an RTL-SDR block (8-bit IQ, multifm/rtl_sdr_if.c:146-148) that the
     matrix kernel reads as bytes, outside the timed region; kernel duration from the engine's HIP

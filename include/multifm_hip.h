@@ -53,9 +53,12 @@ extern "C" {
 #define MFM_E_STATE (-5)  /* call not valid in this state (e.g. add_channel after commit) */
 #define MFM_E_DONE (-6)   /* nothing to fetch (A_E_DONE analogue) */
 
-#define MFM_ABI_VERSION 3 /* 2: mfm_resampler_config grew flags + reserved; mfm_flex_*, mfm_group_* added
+#define MFM_ABI_VERSION 4 /* 2: mfm_resampler_config grew flags + reserved; mfm_flex_*, mfm_group_* added
                              3: mfm_stats grew timed_launches, rot_exact_channels, rot_fast_slices, k_steps, tap_hi_mask, taps_resident; MFM_F_TIMING_SPARSE, MFM_F_STREAM_TAPS;
-                                mfm_group_config.exchange */
+                                mfm_group_config.exchange
+                             4: mfm_engine_config / mfm_group_config grew coalesce_samples (+ a third ext_input); mfm_stats grew submits,
+                                pending_samples; mfm_engine_flush, mfm_group_flush, mfm_engine_input_bytes_cfg, mfm_engine_replay,
+                                mfm_engine_last_launch_input; MFM_F_GATHER */
 
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
@@ -74,6 +77,9 @@ extern "C" {
 #define MFM_F_STREAM_TAPS 0x80u /* filters of 129..512 taps on the matrix kernel: re-read the taps from L2 in every iteration
                                   (the round-1 form: 128 registers, two workgroups per CU) instead of keeping all of them in
                                   registers (256 registers, one workgroup per CU); same bits; parity tests and A/B timing */
+#define MFM_F_GATHER 0x100u    /* with coalesce_samples: launch only once coalesce_samples have gathered, or on mfm_engine_flush() /
+                                  mfm_engine_sync() - never because the device happens to be idle (a producer that knows when
+                                  its backlog ends and flushes then; deterministic launch boundaries for tests) */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 
@@ -84,10 +90,24 @@ struct mfm_engine_config {
     uint32_t decimation;        /* decimationFactor, receiver.c:160-172 */
     uint32_t max_block_samples; /* largest block one push()/submit() may carry */
     uint32_t flags;             /* MFM_F_* */
-    /* Optional caller-owned device memory for the two input staging buffers, each at least
-     * mfm_engine_input_bytes() bytes (lets a caller hand in torch/RCCL-registered memory).
+    /* Optional caller-owned device memory for the input staging buffers (two; three with coalesce_samples), each at
+     * least mfm_engine_input_bytes_cfg() bytes (lets a caller hand in torch/RCCL-registered memory).
      * NULL = the engine allocates. */
-    void *ext_input[2];
+    void *ext_input[3];
+    /*
+     * Backlog coalescing.  A channel thread of the reference takes whatever its work queue holds - up to 128 queued
+     * sample_bufs (multifm/demod.c:297) - and runs them back to back (demod.c:134-150): its cost per sample does not depend
+     * on the size of the buffers a front end delivers (4096 samples from file_if.c:18, 131072 from rtl_sdr_if.c:46).  A
+     * kernel launch has a fixed cost, so the engine does the same with launches: with coalesce_samples > 0 a submitted block
+     * is APPENDED to the input buffer being filled, and the buffer is launched as one pass
+     *   - at once when the device has nothing to do (a live stream keeps its latency),
+     *   - with one launch in flight, as soon as a quarter of that launch's samples have gathered (the device never runs dry),
+     *   - otherwise when coalesce_samples have gathered, or on mfm_engine_flush() / mfm_engine_sync().
+     * The output stream is the same in every case (it never depended on the blocking: filter/direct_fir.c:328-417 walks
+     * sample by sample); mfm_engine_fetch() returns one block per LAUNCH.  0 = every submit is a launch (rounds 1-3).
+     */
+    uint32_t coalesce_samples;
+    uint32_t reserved;          /* 0 */
 };
 
 struct mfm_engine; /* opaque */
@@ -128,10 +148,15 @@ struct mfm_stats {
                                   keeps every k-step of taps in registers, 0 = the taps are streamed from L2 (MFM_F_STREAM_TAPS,
                                   or no resident instance for the geometry) */
     uint32_t reserved0;
+    uint64_t submits;          /* blocks accepted (mfm_engine_submit / push); with coalesce_samples several of them share a launch */
+    uint64_t pending_samples;  /* samples accepted and not yet launched (coalesce_samples; mfm_engine_flush launches them) */
 };
 
-/* Size in bytes of one input staging buffer for this configuration and tap count. */
+/* Size in bytes of one input staging buffer for this configuration and tap count (coalesce_samples = 0). */
 size_t mfm_engine_input_bytes(uint32_t max_block_samples, uint32_t nr_taps);
+/* The same for a configuration with coalesce_samples; also how many buffers the engine uses (2, or 3 when it coalesces:
+ * one being read, one queued behind it, one being filled), i.e. how many ext_input pointers it wants. */
+size_t mfm_engine_input_bytes_cfg(const struct mfm_engine_config *cfg, uint32_t nr_taps, uint32_t *nr_buffers);
 
 int mfm_engine_create(struct mfm_engine **pe, const struct mfm_engine_config *cfg);
 void mfm_engine_destroy(struct mfm_engine **pe);
@@ -200,8 +225,23 @@ int mfm_engine_release(struct mfm_engine *e);
 int mfm_engine_last_output_device(struct mfm_engine *e, void **d_pcm, size_t *stride, size_t *nr_outputs,
                                   void **d_iq);
 
-/* Wait for everything submitted so far. */
+/* What the most recent launch read: device address of its [history tail | blocks] and the sample count (self-checks that
+ * re-run a launch's input through a reference; valid until nbuf - 1 further launches have been queued). */
+int mfm_engine_last_launch_input(struct mfm_engine *e, void **d_in, size_t *nr_samples, int *format);
+
+/* coalesce_samples: launch what has been accepted and not yet launched (MFM_E_BUSY when every output slot holds an
+ * unfetched block: fetch / release and call again).  Producer side: the thread that submits.  No-op otherwise. */
+int mfm_engine_flush(struct mfm_engine *e);
+
+/* Wait for everything submitted so far (launches pending samples first, as mfm_engine_flush). */
 int mfm_engine_sync(struct mfm_engine *e);
+
+/*
+ * A producer loop in C, for measurements: `nr_blocks` times { acquire_input(); submit(block_samples, no producer) } on
+ * whatever the input buffers hold (the caller pre-fills them), exactly what a C host does per delivered sample_buf
+ * without the per-call cost of a scripting language in between.  Stops at the first error and returns it.
+ */
+int mfm_engine_replay(struct mfm_engine *e, size_t block_samples, size_t nr_blocks);
 
 /* Forget the stream: history tail, rotator phase and discriminator state go back to a fresh
  * stream (what restarting the reference does). Pending blocks are dropped. */
@@ -247,6 +287,8 @@ struct mfm_group_config {
     uint32_t max_block_samples;
     uint32_t flags;             /* MFM_F_* handed to every engine (MFM_F_DEVICE_ONLY is not valid here) */
     uint32_t exchange;          /* MFM_X_* */
+    uint32_t coalesce_samples;  /* as mfm_engine_config::coalesce_samples; the shards launch or defer together */
+    uint32_t reserved;          /* 0 */
 };
 
 struct mfm_group; /* opaque */
@@ -270,6 +312,8 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
 /* oldest finished block of every shard into blks[0 .. nr_shards); MFM_E_DONE when nothing is pending */
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks);
 int mfm_group_release(struct mfm_group *g);
+/* coalesce_samples: launch, on every shard, what has been pushed and not yet launched (MFM_E_BUSY: fetch / release first) */
+int mfm_group_flush(struct mfm_group *g);
 int mfm_group_sync(struct mfm_group *g);
 int mfm_group_get_stats(struct mfm_group *g, uint32_t shard, struct mfm_stats *st);
 /* whether blocks travel through RCCL, how many blocks were pushed through it and how many bytes it moved to

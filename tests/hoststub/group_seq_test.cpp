@@ -10,7 +10,6 @@
 #include <thread>
 #include <vector>
 
-#define MFM_E_BUSY (-3)
 
 struct Blk {
     uint64_t first;
@@ -33,7 +32,26 @@ struct Fake {
         for (auto &a : released) a = 0;
     }
     size_t shards() { return S; }
-    int room(size_t i, size_t) { rooms++; return (int)i == room_fail_shard ? MFM_E_BUSY : MFM_OK; }
+    /* a shard whose output ring is full may not launch; `coalesce` = the shards need not launch with every block */
+    bool coalesce = false, want_launch = false;
+    std::vector<int> unl = std::vector<int>(16, 0);
+    int launches = 0, flushes = 0;
+    int plan(size_t i, size_t, bool *must, bool *may, bool *want)
+    {
+        rooms++;
+        *must = !coalesce;
+        *may = (int)i != room_fail_shard;
+        *want = want_launch;
+        return MFM_OK;
+    }
+    int conflict_fmt = -1;
+    bool conflict(size_t i, int fmt) { return unl[i] > 0 && conflict_fmt >= 0 && fmt != conflict_fmt; }
+    int unlaunched(size_t i) { return unl[i]; }
+    int flush(size_t i)
+    {
+        if (unl[i] > 0) { unl[i] = 0; submitted[i]++; flushes++; }
+        return MFM_OK;
+    }
     bool takes_bytes(size_t i, int, size_t) { return i != 2; } /* shard 2 cannot: the block must travel widened */
     bool last_raw = false;
     int acquire(size_t i, bool raw, int, void **dst, size_t *cap)
@@ -53,11 +71,17 @@ struct Fake {
         return MFM_OK;
     }
     int exchange(void *, void *const *, size_t) { exchanges++; return exchange_fail; }
-    int submit(size_t i, size_t)
+    int submit(size_t i, size_t n, bool launch)
     {
         if ((int)i == submit_fail_shard) return MFM_E_DEVICE;
         if (slow_submit_us) std::this_thread::sleep_for(std::chrono::microseconds(slow_submit_us));
-        submitted[i]++;
+        if (launch) {
+            unl[i] = 0;
+            submitted[i]++; /* one finished-or-running block per LAUNCH */
+            launches++;
+        } else {
+            unl[i] += (int)n;
+        }
         return MFM_OK;
     }
     int pending(size_t i) { return submitted[i] - released[i]; }
@@ -122,6 +146,27 @@ int main()
         CHECK(broken && f.total_submits() == 2);
         f.submit_fail_shard = -1;
         CHECK(mfm_group_push_seq(f, &broken, data, 1000, 0, false, &bytes) == MFM_E_DEVICE && f.total_submits() == 2);
+    }
+    { /* coalescing shards: a block that need not be launched is accepted by all and launched by none; the root's wish
+       * launches it on all; a full ring on ONE shard defers it on all (nobody must) - and refuses it when one must */
+        Fake f; bool broken = false; f.coalesce = true; Blk b[4];
+        CHECK(mfm_group_push_seq(f, &broken, data, 1000, 0, false, &bytes) == MFM_OK);
+        CHECK(f.launches == 0 && f.unl[0] == 1000 && f.unl[3] == 1000 && mfm_group_fetch_seq(f, &broken, b) == MFM_E_DONE);
+        f.want_launch = true;
+        CHECK(mfm_group_push_seq(f, &broken, data, 1000, 0, false, &bytes) == MFM_OK && f.launches == 4 && f.unl[2] == 0);
+        CHECK(mfm_group_fetch_seq(f, &broken, b) == MFM_OK);
+        f.room_fail_shard = 1; /* shard 1's ring is full */
+        CHECK(mfm_group_push_seq(f, &broken, data, 1000, 0, false, &bytes) == MFM_OK && f.launches == 4 && f.unl[1] == 1000);
+        CHECK(mfm_group_flush_seq(f, &broken) == MFM_E_BUSY && f.flushes == 0 && !broken);
+        f.coalesce = false; /* now every shard must launch with the next block: refused, nothing accepted */
+        CHECK(mfm_group_push_seq(f, &broken, data, 1000, 0, false, &bytes) == MFM_E_BUSY && f.unl[0] == 1000 && f.stages == 3);
+        f.room_fail_shard = -1;
+        CHECK(mfm_group_flush_seq(f, &broken) == MFM_OK && f.flushes == 4 && f.unl[0] == 0);
+        /* a block of another sample format behind accepted ones: those go out first, on every shard */
+        f.coalesce = true; f.want_launch = false;
+        CHECK(mfm_group_push_seq(f, &broken, data, 1000, 0, false, &bytes) == MFM_OK && f.unl[0] == 1000);
+        f.conflict_fmt = 0; f.S = 2; /* shards 0, 1 read bytes: the 8-bit block would stay bytes */
+        CHECK(mfm_group_push_seq(f, &broken, data, 500, 3, true, &bytes) == MFM_OK && f.flushes == 6 && f.unl[0] == 500);
     }
     { /* fetch: nothing pending = MFM_E_DONE; a block = one per shard, same position */
         Fake f; bool broken = false; Blk b[4];

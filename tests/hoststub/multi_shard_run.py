@@ -1,6 +1,6 @@
 """Run by tests/test_group.py in a fresh process whose LD_LIBRARY_PATH starts with a directory holding the fake librccl.so
 (tests/hoststub/fake_rccl.cpp): a device group of several shards on ONE GPU (MFM_F_GROUP_SHARED_DEVICE), blocks in int16
-and 8-bit formats through the chosen exchange mode, PCM of all shards against the oracle.  argv: nr_shards mode nr_channels."""
+and 8-bit formats through the chosen exchange mode, PCM of all shards against the oracle.  argv: nr_shards mode nr_channels [coalesce_samples [gather]]."""
 import os
 import sys
 
@@ -15,8 +15,11 @@ import oracle_lib as ora  # noqa: E402
 pkg = load_package()
 b = pkg.binding
 S, mode, nch = int(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+coalesce = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+gather = len(sys.argv) > 5 and sys.argv[5] == "gather"
 fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=nch)
-grp = b.Group(fs, decim, 1 << 16, devices=(0,) * S, flags=b.MFM_F_GROUP_SHARED_DEVICE,
+grp = b.Group(fs, decim, 1 << 16, devices=(0,) * S, flags=b.MFM_F_GROUP_SHARED_DEVICE | (b.MFM_F_GATHER if gather else 0),
+              coalesce_samples=coalesce,
               exchange={"rccl": b.MFM_X_RCCL, "allgather": b.MFM_X_RCCL_ALLGATHER, "auto": b.MFM_X_AUTO}[mode])
 for o, g in zip(offs, gains):
     grp.add_channel(int(o), taps, float(g))
@@ -36,12 +39,16 @@ for blk, fmt in blocks:
     iq.append(blk if fmt == 0 else ora.unpack_bytes(blk, fmt).reshape(-1, 2))
     while grp.push(blk, fmt) == b.MFM_E_BUSY:
         parts.append(grp.fetch()[1])
-grp.sync()
 while True:
-    got = grp.fetch()
-    if got is None:
+    rc = grp.flush()  # a coalescing group may hold accepted blocks it has not launched
+    while True:
+        got = grp.fetch()
+        if got is None:
+            break
+        parts.append(got[1])
+    if rc == 0:
         break
-    parts.append(got[1])
+grp.sync()
 uses, nblk, moved = grp.exchange_info()
 st = [grp.stats(s) for s in range(grp.nr_shards)]
 grp.close()
@@ -55,5 +62,10 @@ assert pcm.shape == ref.shape, (pcm.shape, ref.shape)
 bad = np.argwhere(pcm != ref)
 assert len(bad) == 0, f"{len(bad)} PCM samples differ, first at (chan, n) = {bad[0]}"
 assert uses and nblk == len(blocks) and moved > 0, (uses, nblk, moved)
+if coalesce:
+    # the shards launch or defer together: same launches, same positions
+    assert len(set(s["launches"] for s in st)) == 1 and len(set(s["submits"] for s in st)) == 1, st
+    if gather:
+        assert st[0]["launches"] < st[0]["submits"], (st[0]["launches"], st[0]["submits"])
 print(f"multi-shard ok: {grp.nr_shards} shards, mode {mode}, {nch} channels, {pcm.shape[1]} outputs, {moved} bytes exchanged, "
       f"8-bit launches per shard {[s['launches_8bit'] for s in st]}")

@@ -59,6 +59,7 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks) { (void)g, (void)blks; return MFM_E_DONE; }
 int mfm_group_release(struct mfm_group *g) { (void)g; return MFM_OK; }
 int mfm_group_sync(struct mfm_group *g) { (void)g; return MFM_OK; }
+int mfm_group_flush(struct mfm_group *g) { (void)g; return MFM_OK; }
 int mfm_group_get_stats(struct mfm_group *g, uint32_t s, struct mfm_stats *st)
 {
     (void)g, (void)s;

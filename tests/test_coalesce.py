@@ -1,0 +1,212 @@
+"""Backlog coalescing (mfm_engine_config::coalesce_samples): blocks accepted into the buffer being filled and launched as
+one pass.  The reference's channel thread takes whatever its work queue holds - up to 128 sample_bufs of 4096 (file_if.c:18),
+131072 (rtl_sdr_if.c:46) or 262144 (airspy_if.c:244-245) samples - and runs them back to back (multifm/demod.c:48-121,
+134-150, :297): its output does not depend on the buffers' sizes, and neither may the engine's depend on which blocks
+shared a launch.  Bit-exact against the oracle, through the C ABI."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tables(ora, taps, offs, fs, decim, gains=None):
+    gains = gains if gains is not None else [1.0] * len(offs)
+    cre = np.stack([ora.make_taps(taps, int(o), fs, float(g))[0] for o, g in zip(offs, gains)])
+    cim = np.stack([ora.make_taps(taps, int(o), fs, float(g))[1] for o, g in zip(offs, gains)])
+    incr = np.stack([ora.rot_incr(int(o), fs, decim) for o in offs])
+    return cre, cim, incr
+
+
+def _drain(eng, parts, qparts):
+    while True:
+        got = eng.fetch()
+        if got is None:
+            return
+        if parts and got[0] != parts[-1][0] + parts[-1][1].shape[1]:
+            raise AssertionError(f"block starts at output {got[0]}, the previous one ended at "
+                                 f"{parts[-1][0] + parts[-1][1].shape[1]}")
+        parts.append((got[0], got[1]))
+        if got[2] is not None:
+            qparts.append(got[2])
+
+
+def _finish(eng, parts, qparts):
+    while True:
+        rc = eng.flush()
+        _drain(eng, parts, qparts)
+        if rc == 0:
+            break
+    eng.sync()
+    _drain(eng, parts, qparts)
+
+
+SIZES = [1, 1, 100, 26, 1, 4096, 4096, 4096, 131072, 16384, 7919, 5, 127, 128, 129, 60000, 1000, 4096, 4096, 262144]
+
+
+@pytest.mark.parametrize("kernel", ["auto", "mfma1", "dot2"])
+@pytest.mark.parametrize("policy", ["gather", "auto"])
+def test_coalesced_ragged_buffers_against_the_oracle(pkg, ora, kernel, policy):
+    """Front-end sized buffers (file_if 4096, rtl_sdr 131072, uhd 16384, airspy 262144), single samples and blocks shorter
+    than the filter, gathered into launches of up to 300 000 samples: same PCM and filtered IQ as the oracle on the whole
+    stream; with MFM_F_GATHER the launch boundaries are those of the gathered sample count, not of the blocks."""
+    b = pkg.binding
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=9)
+    n = 1200000
+    iq = pkg.synth.synth_iq(n, fs, offs[:3], seed=41)
+    flags = {"auto": 0, "mfma1": b.MFM_F_FORCE_MFMA_V1, "dot2": b.MFM_F_FORCE_DOT2}[kernel]
+    flags |= b.MFM_F_GATHER if policy == "gather" else 0
+    eng = pkg.Engine(fs, decim, 262144, device=0, flags=flags, coalesce_samples=300000)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g), want_iq=True)
+    eng.commit()
+    cre = np.stack([eng.get_channel(c)[0] for c in range(len(offs))])
+    cim = np.stack([eng.get_channel(c)[1] for c in range(len(offs))])
+    incr = np.stack([eng.get_channel(c)[2] for c in range(len(offs))])
+    ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=4, want_iq=True)
+    parts, qparts, pos, k = [], [], 0, 0
+    while pos < n:
+        m = min(SIZES[k % len(SIZES)], n - pos)
+        rc = eng.push(iq[pos:pos + m])
+        if rc == b.MFM_E_BUSY:
+            _drain(eng, parts, qparts)
+            continue
+        assert rc == 0, eng.lib.mfm_last_error()
+        pos += m
+        k += 1
+    _finish(eng, parts, qparts)
+    st = eng.stats()
+    eng.close()
+    pcm = np.concatenate([p[1] for p in parts], axis=1)
+    q = np.concatenate(qparts, axis=1)
+    assert parts[0][0] == 0 and pcm.shape == ref.shape
+    assert np.array_equal(pcm, ref) and np.array_equal(q, refq)
+    assert st["samples_in"] == n and st["outputs"] == ref.shape[1] and st["submits"] == k and st["pending_samples"] == 0
+    assert st["launches"] <= st["submits"]
+    if policy == "gather":
+        # a launch per 300 000 gathered samples (plus the block that crossed the mark), and the flush at the end
+        assert st["launches"] <= n // 300000 + 1, st["launches"]
+        assert all(p[1].shape[1] >= 300000 // decim - 2 for p in parts[:-1])
+
+
+@pytest.mark.parametrize("policy", ["gather", "auto"])
+def test_coalesced_8bit_blocks_and_format_changes(pkg, ora, policy):
+    """8-bit blocks read as bytes by the matrix kernel gather like int16 ones; a block of another format behind accepted
+    ones (int16 behind RTL-SDR bytes, cs8 behind cu8, a cu8 block of odd length) sends what was gathered out as a launch
+    of its own and the stream goes on - the oracle on the reference's host-side widening sees one stream."""
+    b = pkg.binding
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 9000.0, fs)
+    offs = [-300000, 12500, 412500]
+    rng = np.random.RandomState(78)
+
+    def raw(m):
+        return rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+
+    def s16(m):
+        return rng.randint(-32768, 32768, size=(m, 2)).astype(np.int16)
+
+    blocks = [(raw(20000), 3), (raw(20002), 3), (raw(4096), 3), (s16(7777), 0), (s16(4096), 0), (raw(9000), 3), (raw(4096), 1),
+              (raw(4098), 1), (raw(4097), 2), (raw(4098), 2), (raw(10), 1), (s16(96 * 50), 0), (raw(30000), 1), (raw(30000), 1)]
+    eng = pkg.Engine(fs, decim, 32768, device=0, flags=b.MFM_F_GATHER if policy == "gather" else 0, coalesce_samples=100000)
+    for o in offs:
+        eng.add_channel(int(o), taps, 1.0)
+    eng.commit()
+    iq, parts, qparts = [], [], []
+    for blk, fmt in blocks:
+        iq.append(blk.astype(np.int16).reshape(-1, 2) if fmt == 0 else ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+        while True:
+            rc = eng.push(blk.reshape(-1)) if fmt == 0 else eng.push_bytes(blk, fmt)
+            if rc == 0:
+                break
+            assert rc == b.MFM_E_BUSY
+            _drain(eng, parts, qparts)
+    _finish(eng, parts, qparts)
+    st = eng.stats()
+    eng.close()
+    iq = np.concatenate(iq)
+    cre, cim, incr = _tables(ora, taps, offs, fs, decim)
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim)
+    got = np.concatenate([p[1] for p in parts], axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert st["submits"] == len(blocks) and st["launches"] <= st["submits"]
+    if policy == "gather":
+        assert 2 <= st["launches_8bit"] < st["launches"] < st["submits"]
+
+
+@pytest.mark.parametrize("nch,block_log2,coalesce_log2", [(64, 12, 20), (16, 17, 22), (130, 14, 18)])
+def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coalesce_log2):
+    """mfm_engine_replay: the producer loop of a C host - acquire_input, submit - on blocks that are already in HBM (what
+    bench.py's block_series times), with the engine's own launch policy.  Every launch's PCM in HBM against the oracle on
+    the samples that launch read (mfm_engine_last_launch_input), rotators stepped to the launch's first output."""
+    b = pkg.binding
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=nch)
+    block, co = 1 << block_log2, 1 << coalesce_log2
+    eng = pkg.Engine(fs, decim, block, device=0, flags=b.MFM_F_DEVICE_ONLY, coalesce_samples=co)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    cfg = b.EngineConfig()
+    cfg.max_block_samples, cfg.coalesce_samples = block, co
+    nb = C.c_uint32()
+    in_bytes = eng.lib.mfm_engine_input_bytes_cfg(C.byref(cfg), len(taps), C.byref(nb))
+    assert nb.value == 3 and in_bytes >= 4 * (block + co + len(taps))
+    # every input buffer holds the same synthetic samples (the buffers are the engine's own: fill them where it says)
+    base = pkg.synth.synth_iq(in_bytes // 4, fs, offs[:4], seed=5).reshape(-1)
+    seen = set()
+    for _ in range(3):
+        ptr, cap = eng.acquire_input()
+        assert cap == block
+        if ptr not in seen:
+            seen.add(ptr)
+            assert hip.hipMemcpy(ptr, base.ctypes.data, in_bytes - 4 * (len(taps) + 64), 1) == 0
+        eng.submit(block, producer_stream=0, wait_producer=False)
+        eng.flush()
+    eng.sync()
+    eng.reset()
+    checked = 0
+    for rounds, blocks in ((1, 1), (1, 7), (3, 150), (2, 1000)):
+        for _ in range(rounds):
+            eng.replay(block, blocks)
+        eng.sync()
+        st = eng.stats()
+        dptr, stride, nout, _ = eng.last_output_device()
+        iptr, n_in, fmt = eng.last_launch_input()
+        assert fmt == 0 and nout == (n_in - len(taps)) // decim + 1
+        host_in = np.empty((n_in, 2), np.int16)
+        assert hip.hipMemcpy(host_in.ctypes.data, iptr, 4 * n_in, 2) == 0
+        before = st["outputs"] - nout
+        for c in sorted(set([0, nch // 2, nch - 1])):
+            row = np.empty(nout, np.int16)
+            assert hip.hipMemcpy(row.ctypes.data, C.c_void_p(dptr + 2 * stride * c), 2 * nout, 2) == 0
+            cre, cim, incr = eng.get_channel(c)
+            for w0 in sorted(set([1, max(1, nout // 2), max(1, nout - 700)])):
+                cnt = min(700, nout - w0)
+                want = ora.window_pcm(host_in, cre, cim, decim, incr, before, w0, cnt)
+                assert np.array_equal(row[w0:w0 + cnt], want), (c, w0, blocks)
+                checked += cnt
+    st = eng.stats()
+    eng.close()
+    assert checked > 0 and st["submits"] >= 3 * 150 + 2 * 1000 and st["pending_samples"] == 0
+    assert st["launches"] < st["submits"]  # 2000 blocks handed over faster than the device takes single ones
+
+
+@pytest.mark.parametrize("shards,mode,nch,gather", [(2, "rccl", 70, "gather"), (3, "allgather", 70, "auto"), (8, "allgather", 130, "gather")])
+def test_coalescing_group_of_several_shards_through_a_fake_transport(tmp_path, shards, mode, nch, gather):
+    """The device group with coalesce_samples over the test double of RCCL (tests/test_group.py): every shard accepts and
+    launches the same blocks together (one decision per block for all shards, mfm_group_seq.h), int16 and 8-bit blocks,
+    format changes flushed on every shard at once; concatenated PCM against the oracle."""
+    so = tmp_path / "librccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
+                        os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(["python3", os.path.join(ROOT, "tests", "hoststub", "multi_shard_run.py"), str(shards), mode, str(nch),
+                        "150000", gather], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "multi-shard ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

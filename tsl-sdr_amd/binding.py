@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFM_LIB") or os.path.join(_HERE, "libmultifm_hip.so")
 
 MFM_OK, MFM_E_INVAL, MFM_E_NOMEM, MFM_E_BUSY, MFM_E_DEVICE, MFM_E_STATE, MFM_E_DONE = 0, -1, -2, -3, -4, -5, -6
-MFM_ABI_VERSION = 3
+MFM_ABI_VERSION = 4
 MFM_F_DEVICE_ONLY = 0x1
 MFM_F_TIMING = 0x2
 MFM_F_FORCE_DOT2 = 0x4
@@ -22,11 +22,14 @@ MFM_F_WIDEN_8BIT = 0x10
 MFM_F_TIMING_SPARSE = 0x20
 MFM_F_GROUP_SHARED_DEVICE = 0x40
 MFM_F_STREAM_TAPS = 0x80
+MFM_F_GATHER = 0x100
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
 ABI_SYMBOLS = [
-    "mfm_engine_input_bytes", "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
+    "mfm_engine_input_bytes", "mfm_engine_input_bytes_cfg", "mfm_engine_flush", "mfm_engine_replay", "mfm_group_flush",
+    "mfm_engine_last_launch_input",
+    "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
     "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
     "mfm_engine_acquire_input_bytes",
     "mfm_engine_submit", "mfm_engine_push", "mfm_engine_push_bytes", "mfm_engine_fetch", "mfm_engine_release",
@@ -58,13 +61,14 @@ class MfmError(RuntimeError):
 class EngineConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("sample_rate_hz", C.c_uint32),
                 ("decimation", C.c_uint32), ("max_block_samples", C.c_uint32), ("flags", C.c_uint32),
-                ("ext_input", C.c_void_p * 2)]
+                ("ext_input", C.c_void_p * 3), ("coalesce_samples", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GroupConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("nr_devices", C.c_uint32), ("devices", C.c_int32 * 16),
                 ("sample_rate_hz", C.c_uint32), ("decimation", C.c_uint32), ("max_block_samples", C.c_uint32),
-                ("flags", C.c_uint32), ("exchange", C.c_uint32)]
+                ("flags", C.c_uint32), ("exchange", C.c_uint32), ("coalesce_samples", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 MFM_X_AUTO, MFM_X_RCCL, MFM_X_RCCL_ALLGATHER = 0, 1, 2
@@ -84,7 +88,8 @@ class Stats(C.Structure):
                 ("launches_8bit", C.c_uint64), ("timed_launches", C.c_uint64),
                 ("rot_exact_channels", C.c_uint32), ("rot_fast_slices", C.c_uint32),
                 ("k_steps", C.c_uint32), ("tap_hi_mask", C.c_uint32),
-                ("taps_resident", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("taps_resident", C.c_uint32), ("reserved0", C.c_uint32),
+                ("submits", C.c_uint64), ("pending_samples", C.c_uint64)]
 
 
 class PocsagConfig(C.Structure):
@@ -163,6 +168,12 @@ def load_library():
     vp, i16p = C.c_void_p, C.POINTER(C.c_int16)
     lib.mfm_engine_input_bytes.restype = C.c_size_t
     lib.mfm_engine_input_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.mfm_engine_input_bytes_cfg.restype = C.c_size_t
+    lib.mfm_engine_input_bytes_cfg.argtypes = [C.POINTER(EngineConfig), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mfm_engine_flush.argtypes = [vp]
+    lib.mfm_engine_replay.argtypes = [vp, C.c_size_t, C.c_size_t]
+    lib.mfm_engine_last_launch_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    lib.mfm_group_flush.argtypes = [vp]
     lib.mfm_engine_create.argtypes = [C.POINTER(vp), C.POINTER(EngineConfig)]
     lib.mfm_engine_destroy.argtypes = [C.POINTER(vp)]
     lib.mfm_engine_destroy.restype = None
@@ -270,7 +281,8 @@ def _i16p(a):
 class Engine:
     """One multifm channel engine (struct mfm_engine) on one GPU."""
 
-    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, flags=0, ext_input=None):
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, device=0, flags=0, ext_input=None,
+                 coalesce_samples=0):
         self.lib = load_library()
         self.h = C.c_void_p()
         cfg = EngineConfig()
@@ -280,8 +292,10 @@ class Engine:
         cfg.decimation = decimation
         cfg.max_block_samples = max_block_samples
         cfg.flags = flags
+        cfg.coalesce_samples = coalesce_samples
         if ext_input is not None:
-            cfg.ext_input[0], cfg.ext_input[1] = ext_input
+            for i, ptr in enumerate(ext_input):
+                cfg.ext_input[i] = ptr
         self.sample_rate_hz, self.decimation, self.max_block_samples = sample_rate_hz, decimation, max_block_samples
         self.nr_taps = 0
         self.nr_channels = 0
@@ -406,6 +420,9 @@ class Engine:
                 continue
             self._chk(rc, "mfm_engine_push")
             pos += n
+        # a coalescing engine may hold accepted blocks it has not launched yet
+        while self.flush() == MFM_E_BUSY:
+            drain()
         drain()
         nch = self.nr_channels
         pcm = np.concatenate(pcm_parts, axis=1) if pcm_parts else np.zeros((nch, 0), np.int16)
@@ -417,6 +434,24 @@ class Engine:
         self._chk(self.lib.mfm_engine_last_output_device(self.h, C.byref(p), C.byref(st), C.byref(n), C.byref(q)),
                   "mfm_engine_last_output_device")
         return p.value, st.value, n.value, q.value
+
+    def flush(self):
+        """launch what a coalescing engine has accepted and not launched; returns 0 or MFM_E_BUSY"""
+        rc = self.lib.mfm_engine_flush(self.h)
+        if rc == MFM_E_BUSY:
+            return rc
+        return self._chk(rc, "mfm_engine_flush")
+
+    def replay(self, block_samples, nr_blocks):
+        """nr_blocks x { acquire_input; submit(block_samples) } in C on whatever the input buffers hold"""
+        self._chk(self.lib.mfm_engine_replay(self.h, block_samples, nr_blocks), "mfm_engine_replay")
+
+    def last_launch_input(self):
+        """(device address, samples, MFM_IN_* format) of what the most recent launch read"""
+        p, n, f = C.c_void_p(), C.c_size_t(), C.c_int()
+        self._chk(self.lib.mfm_engine_last_launch_input(self.h, C.byref(p), C.byref(n), C.byref(f)),
+                  "mfm_engine_last_launch_input")
+        return p.value, n.value, f.value
 
     def sync(self):
         self._chk(self.lib.mfm_engine_sync(self.h), "mfm_engine_sync")
@@ -451,7 +486,8 @@ def shard_range(nr_channels, nr_shards, shard):
 class Group:
     """mfm_group_*: one channel set on several devices of a node (RCCL broadcast of every block)."""
 
-    def __init__(self, sample_rate_hz, decimation, max_block_samples, devices=(0,), flags=0, exchange=MFM_X_AUTO):
+    def __init__(self, sample_rate_hz, decimation, max_block_samples, devices=(0,), flags=0, exchange=MFM_X_AUTO,
+                 coalesce_samples=0):
         self.lib = load_library()
         self.h = C.c_void_p()
         cfg = GroupConfig()
@@ -461,6 +497,7 @@ class Group:
             cfg.devices[i] = d
         cfg.sample_rate_hz, cfg.decimation, cfg.max_block_samples = sample_rate_hz, decimation, max_block_samples
         cfg.flags, cfg.exchange = flags, exchange
+        cfg.coalesce_samples = coalesce_samples
         rc = self.lib.mfm_group_create(C.byref(self.h), C.byref(cfg))
         if rc < 0:
             raise MfmError(rc, "mfm_group_create", self.lib.mfm_last_error().decode())
@@ -521,6 +558,13 @@ class Group:
         first = blks[0].first_output
         self._chk(self.lib.mfm_group_release(self.h), "mfm_group_release")
         return first, np.concatenate(parts, axis=0)
+
+    def flush(self):
+        """launch, on every shard, what has been pushed and not launched; returns 0 or MFM_E_BUSY"""
+        rc = self.lib.mfm_group_flush(self.h)
+        if rc == MFM_E_BUSY:
+            return rc
+        return self._chk(rc, "mfm_group_flush")
 
     def sync(self):
         self._chk(self.lib.mfm_group_sync(self.h), "mfm_group_sync")

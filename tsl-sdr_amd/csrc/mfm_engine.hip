@@ -66,6 +66,7 @@ int fail(int code, const char *fmt, ...)
 constexpr uint64_t MFM_ATAN_TABLE_FNV1A = 0x674d1aab1787b44bull;
 
 constexpr int kOutSlots = 4;      /* output ring depth (2 in device-only mode) */
+constexpr int kMaxInBufs = 3;     /* input buffers: 2, or 3 when the engine coalesces (mfm_engine_config::coalesce_samples) */
 constexpr int kTimingPairs = 256; /* event pairs kept before the oldest is folded into the total */
 constexpr uint64_t kSparseTiming = 4; /* MFM_F_TIMING_SPARSE: one launch in this many is bracketed */
 constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine_get_launch_ms() */
@@ -186,20 +187,28 @@ struct mfm_engine {
     mfm_chan_state *d_state[2] = { nullptr, nullptr };
     uint64_t rot_entries = 0;
 
-    /* input staging */
-    uint32_t *d_in[2] = { nullptr, nullptr };
+    /* input staging: nbuf buffers used in turn, each [history tail | blocks accepted since the last launch] */
+    uint32_t *d_in[kMaxInBufs] = { nullptr, nullptr, nullptr };
     bool own_in = false;
-    uint32_t *h_in[2] = { nullptr, nullptr }; /* pinned, for push() */
-    uint16_t *d_raw[2] = { nullptr, nullptr }; /* push_bytes(): 8-bit IQ pairs as they came off the wire */
-    hipEvent_t in_free[2] = { nullptr, nullptr };
-    hipEvent_t in_free_wait[2] = { nullptr, nullptr }; /* what acquire_input() waits on: in_free[i], or the timing
-                                                          event recorded at the same point of the stream */
+    uint32_t *h_in[kMaxInBufs] = { nullptr, nullptr, nullptr }; /* pinned, for push() */
+    uint16_t *d_raw[kMaxInBufs] = { nullptr, nullptr, nullptr }; /* push_bytes(): 8-bit IQ pairs as they came off the wire */
+    hipEvent_t in_free[kMaxInBufs] = { nullptr, nullptr, nullptr };
+    hipEvent_t in_free_wait[kMaxInBufs] = { nullptr, nullptr, nullptr }; /* the end of the launch that last read buffer i:
+                                                          in_free[i], or the timing event recorded at the same point of
+                                                          the stream.  acquire_input() waits on it, the coalescing policy
+                                                          queries it */
     hipEvent_t in_ready = nullptr;
+    int nbuf = 2;      /* 3 with coalesce_samples: one being read, one queued behind it, one being filled */
     int cur_in = 0;
     uint32_t tail = 0; /* samples of history at the front of d_in[cur_in] */
+    uint32_t pend = 0; /* samples accepted into d_in[cur_in] behind the history and not yet launched (coalesce_samples) */
+    uint32_t last_launch_samples = 0; /* what the most recent launch read: a second launch is queued behind one in flight
+                                         once a quarter of that has gathered */
+    uint64_t submits = 0;
+    int last_launch_buf = -1, last_launch_fmt = MFM_IN_CS16;
     /* 8-bit blocks may sit in the input buffers as they came off the wire (2 bytes per sample, push_bytes): the format of
      * what was staged into each buffer, and of the history at the front of d_in[cur_in] */
-    int in_fmt[2] = { MFM_IN_CS16, MFM_IN_CS16 };
+    int in_fmt[kMaxInBufs] = { MFM_IN_CS16, MFM_IN_CS16, MFM_IN_CS16 };
     int tail_fmt = MFM_IN_CS16;
     uint16_t *d_tailtmp = nullptr; /* a history kept as bytes is widened through here when an int16 block follows it */
     uint64_t launches_8bit = 0;
@@ -390,6 +399,8 @@ void free_device(mfm_engine *e)
     (void)hipFree(e->d_lut);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(e->d_state[i]);
+    }
+    for (int i = 0; i < kMaxInBufs; i++) {
         if (e->own_in) {
             (void)hipFree(e->d_in[i]);
         }
@@ -449,6 +460,8 @@ void free_device(mfm_engine *e)
     e->d_lut = nullptr;
     for (int i = 0; i < 2; i++) {
         e->d_state[i] = nullptr;
+    }
+    for (int i = 0; i < kMaxInBufs; i++) {
         e->d_in[i] = nullptr;
         e->d_raw[i] = nullptr;
         e->h_in[i] = nullptr;
@@ -463,12 +476,13 @@ void free_device(mfm_engine *e)
     e->committed = false;
 }
 
-uint32_t input_capacity(uint32_t max_block, uint32_t nr_taps)
+uint64_t input_capacity(uint32_t max_block, uint32_t coalesce, uint32_t nr_taps)
 {
     /* history tail (< nr_taps samples) + block + one 16-byte staging chunk of slack (a chunk that starts on the last
      * real sample must still be readable in place: decimations that are not multiples of 4 start their chunks at any
-     * sample), rounded to 64 samples */
-    return (max_block + nr_taps + 4u + 63u) & ~63u;
+     * sample), rounded to 64 samples.  A coalescing engine launches once coalesce_samples have gathered: fewer than that
+     * plus one more block of any size always fit. */
+    return ((uint64_t)max_block + coalesce + nr_taps + 4u + 63u) & ~63ull;
 }
 
 int write_state_fresh(mfm_engine *e)
@@ -572,7 +586,18 @@ __attribute__((visibility("hidden"))) void mfm_internal_set_error(const char *ms
 
 size_t mfm_engine_input_bytes(uint32_t max_block_samples, uint32_t nr_taps)
 {
-    return (size_t)input_capacity(max_block_samples, nr_taps) * sizeof(uint32_t);
+    return (size_t)input_capacity(max_block_samples, 0, nr_taps) * sizeof(uint32_t);
+}
+
+size_t mfm_engine_input_bytes_cfg(const struct mfm_engine_config *cfg, uint32_t nr_taps, uint32_t *nr_buffers)
+{
+    if (!cfg) {
+        return 0;
+    }
+    if (nr_buffers) {
+        *nr_buffers = cfg->coalesce_samples ? 3u : 2u;
+    }
+    return (size_t)input_capacity(cfg->max_block_samples, cfg->coalesce_samples, nr_taps) * sizeof(uint32_t);
 }
 
 int mfm_engine_create(struct mfm_engine **pe, const struct mfm_engine_config *cfg)
@@ -590,8 +615,13 @@ int mfm_engine_create(struct mfm_engine **pe, const struct mfm_engine_config *cf
     if (cfg->max_block_samples > (1u << 30)) {
         return fail(MFM_E_INVAL, "max_block_samples %u too large", cfg->max_block_samples);
     }
-    if ((cfg->ext_input[0] == nullptr) != (cfg->ext_input[1] == nullptr)) {
-        return fail(MFM_E_INVAL, "ext_input needs both buffers or neither");
+    if ((cfg->ext_input[0] == nullptr) != (cfg->ext_input[1] == nullptr) ||
+        (cfg->coalesce_samples && (cfg->ext_input[0] == nullptr) != (cfg->ext_input[2] == nullptr))) {
+        return fail(MFM_E_INVAL, "ext_input needs every buffer (two; three with coalesce_samples) or none");
+    }
+    if ((uint64_t)cfg->max_block_samples + cfg->coalesce_samples > (1u << 30)) {
+        return fail(MFM_E_INVAL, "max_block_samples + coalesce_samples = %llu too large",
+                    (unsigned long long)cfg->max_block_samples + cfg->coalesce_samples);
     }
     mfm_engine *e = new (std::nothrow) mfm_engine();
     if (!e) {
@@ -692,7 +722,7 @@ int mfm_engine_commit(struct mfm_engine *e)
     if (e->committed) {
         return fail(MFM_E_STATE, "already committed");
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kMaxInBufs; i++) {
         if (e->cfg.ext_input[i] && (reinterpret_cast<uintptr_t>(e->cfg.ext_input[i]) & 15u)) {
             return fail(MFM_E_INVAL, "ext_input buffers must be 16-byte aligned");
         }
@@ -753,7 +783,8 @@ static int commit_locked(struct mfm_engine *e)
     e->ngroups = (C + MFM_CG - 1) / MFM_CG;
     e->gpw = std::min<uint32_t>(MFM_NW, e->ngroups);
     e->nslices = (e->ngroups + e->gpw - 1) / e->gpw;
-    e->cap_in = input_capacity(e->cfg.max_block_samples, T);
+    e->cap_in = (uint32_t)input_capacity(e->cfg.max_block_samples, e->cfg.coalesce_samples, T);
+    e->nbuf = e->cfg.coalesce_samples ? 3 : 2;
     /* a multiple of 8 outputs: channel rows of the PCM buffer start 16-byte aligned (8-byte PCM / 16-byte IQ stores) */
     e->out_stride = ((e->cap_in - T) / D + 1 + 7) & ~7u;
     e->any_iq = false;
@@ -1158,7 +1189,7 @@ static int commit_locked(struct mfm_engine *e)
 
     const size_t in_bytes = (size_t)e->cap_in * 4;
     e->own_in = e->cfg.ext_input[0] == nullptr;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < e->nbuf; i++) {
         if (e->own_in) {
             HIP_TRY(hipMalloc(&e->d_in[i], in_bytes));
         } else {
@@ -1202,94 +1233,91 @@ static int commit_locked(struct mfm_engine *e)
     return MFM_OK;
 }
 
-int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacity_samples)
+/* ---- the data path: accept blocks into the buffer being filled, launch it ---- */
+
+} /* extern "C" */
+
+namespace {
+
+/* format of what the buffer being filled holds ([history | accepted blocks]); -1 = nothing, any format can start it */
+int buffer_format(const mfm_engine *e)
 {
-    if (!e || !d_dst) {
-        return fail(MFM_E_INVAL, "NULL argument");
+    if (e->pend) {
+        return e->in_fmt[e->cur_in];
     }
-    if (!e->committed) {
-        return fail(MFM_E_STATE, "commit first");
-    }
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    /* the kernel that last read this buffer (two submits ago) must be done with it */
-    if (e->in_free_wait[e->cur_in]) {
-        HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
-    }
-    e->in_fmt[e->cur_in] = MFM_IN_CS16; /* what a device producer writes; mfm_engine_stage() says otherwise for raw bytes */
-    *d_dst = e->d_in[e->cur_in] + e->tail;
-    if (capacity_samples) {
-        *capacity_samples = e->cap_in - e->tail;
-    }
-    return MFM_OK;
+    return e->tail ? e->tail_fmt : -1;
 }
 
-/* would the engine keep an 8-bit block of this format as bytes now?  (mfm_engine_internal.h) */
-int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_samples)
+bool event_done(hipEvent_t ev)
 {
-    /* not a cu8 block of odd length (file_if.c:146-150 widens its last sample differently), not behind a history of
-     * another format */
-    return e && e->committed && e->raw8_ok && (format == MFM_IN_CS8 || format == MFM_IN_CU8 || format == MFM_IN_RTLSDR_U8) &&
-           !(format == MFM_IN_CU8 && (nr_samples & 1u)) && (0 == e->tail || e->tail_fmt == format);
+    if (!ev) {
+        return true;
+    }
+    if (hipEventQuery(ev) == hipErrorNotReady) {
+        (void)hipGetLastError(); /* "not ready" must not surface in somebody's hipGetLastError() check */
+        return false;
+    }
+    return true;
 }
 
-int mfm_engine_acquire_input_bytes(struct mfm_engine *e, int format, void **d_dst, size_t *capacity_samples)
+/* launches queued or running: 0, 1, or 2 for "two or more".  The launch before the one that last read buffer b ended
+ * before it (one compute stream, in order). */
+int launches_in_flight(mfm_engine *e)
 {
-    if (!e || !d_dst) {
-        return fail(MFM_E_INVAL, "NULL argument");
+    const int b1 = (e->cur_in + e->nbuf - 1) % e->nbuf, b2 = (e->cur_in + e->nbuf - 2) % e->nbuf;
+    if (event_done(e->in_free_wait[b1])) {
+        return 0;
     }
-    if (!e->committed) {
-        return fail(MFM_E_STATE, "commit first");
+    if (b2 == e->cur_in) {
+        return 1; /* two buffers: acquire_input() waited for the launch before that one */
     }
-    if (format != MFM_IN_CS8 && format != MFM_IN_CU8 && format != MFM_IN_RTLSDR_U8) {
-        return fail(MFM_E_INVAL, "not an 8-bit sample format: %d", format);
-    }
-    if (!mfm_engine_can_take_bytes(e, format, 0)) {
-        return fail(MFM_E_STATE, "this engine cannot read format %d as bytes now (kernel variant, or a history of another "
-                                 "format): widen the block and use mfm_engine_acquire_input", format);
-    }
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    if (e->in_free_wait[e->cur_in]) {
-        HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
-    }
-    e->in_fmt[e->cur_in] = format;
-    *d_dst = reinterpret_cast<uint8_t *>(e->d_in[e->cur_in]) + (size_t)e->tail * 2;
-    if (capacity_samples) {
-        *capacity_samples = e->cap_in - e->tail; /* the block limit is that of int16 blocks */
-    }
-    return MFM_OK;
+    return event_done(e->in_free_wait[b2]) ? 1 : 2;
 }
 
-int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer)
-{
-    if (!e) {
-        return fail(MFM_E_INVAL, "NULL engine");
-    }
-    if (!e->committed) {
-        return fail(MFM_E_STATE, "commit first");
-    }
-    if (0 == nr_samples) {
-        /* receiver_sample_buf_deliver() treats an empty buffer as a bug (receiver.c:84) */
-        return fail(MFM_E_INVAL, "empty block");
-    }
-    if (nr_samples > e->cap_in - e->tail || nr_samples > e->cfg.max_block_samples) {
-        return fail(MFM_E_INVAL, "block of %zu samples exceeds max_block_samples %u", nr_samples,
-                    e->cfg.max_block_samples);
-    }
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    std::lock_guard<std::mutex> guard(e->mu);
+struct SubmitPlan {
+    bool must; /* the buffer has to be launched once this block is in (no coalescing, or coalesce_samples gathered) */
+    bool may;  /* a launch would find a free output slot */
+    bool want; /* the policy of mfm_engine_config::coalesce_samples would launch now although it does not have to */
+    uint32_t n_new;
+};
 
+/* what accepting nr_samples more (0: what is there) would mean.  Takes the lock for the slot's state. */
+void plan_block(mfm_engine *e, size_t nr_samples, SubmitPlan *p, bool locked)
+{
+    const uint32_t T = e->nr_taps, D = e->cfg.decimation, co = e->cfg.coalesce_samples;
+    const uint64_t pend_after = (uint64_t)e->pend + nr_samples;
+    const uint64_t n_avail = (uint64_t)e->tail + pend_after;
+    p->n_new = n_avail >= T ? (uint32_t)((n_avail - T) / D + 1) : 0;
+    p->must = 0 == co || pend_after >= co;
+    if (e->cfg.flags & MFM_F_DEVICE_ONLY) {
+        p->may = true;
+    } else if (locked) {
+        p->may = 0 == p->n_new || e->slots[e->submit_seq % e->nslots].state == OutSlot::FREE;
+    } else {
+        std::lock_guard<std::mutex> guard(e->mu);
+        p->may = 0 == p->n_new || e->slots[e->submit_seq % e->nslots].state == OutSlot::FREE;
+    }
+    p->want = false;
+    if (!p->must && p->n_new && !(e->cfg.flags & MFM_F_GATHER)) {
+        const int fl = launches_in_flight(e);
+        p->want = 0 == fl || (1 == fl && 4u * pend_after >= e->last_launch_samples);
+    }
+}
+
+/*
+ * One pass over d_in[cur_in] = [history tail | the blocks accepted since the last launch]: the kernel, the carry of the
+ * unconsumed samples to the front of the next buffer, the copy of the outputs to the host mirror.  Caller holds e->mu and
+ * has checked that an output slot is free.
+ */
+int launch_locked(mfm_engine *e)
+{
     const uint32_t T = e->nr_taps, D = e->cfg.decimation, C = (uint32_t)e->chans.size();
     const bool dev_only = (e->cfg.flags & MFM_F_DEVICE_ONLY) != 0;
-    const int cur = e->cur_in;
-    const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
+    const int cur = e->cur_in, nxt = (cur + 1) % e->nbuf;
+    const uint32_t n_avail = e->tail + e->pend;
     const uint32_t n_new = n_avail >= T ? (n_avail - T) / D + 1 : 0;
     const int fmt = e->in_fmt[cur];
     const bool raw8 = fmt != MFM_IN_CS16;
-    if (raw8 && !mfm_engine_can_take_bytes(e, fmt, nr_samples)) {
-        e->in_fmt[cur] = MFM_IN_CS16;
-        return fail(MFM_E_INVAL, "a block of %zu samples of format %d cannot be read as bytes here (cu8 blocks must be of "
-                                 "even length)", nr_samples, fmt);
-    }
 
     OutSlot *slot = nullptr;
     int slot_idx = -1;
@@ -1299,20 +1327,6 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         if (!dev_only && slot->state != OutSlot::FREE) {
             return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
         }
-    }
-
-    if (wait_producer) {
-        HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
-        HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
-    }
-
-    if (!raw8 && e->tail && e->tail_fmt != MFM_IN_CS16) {
-        /* the history at the front of this buffer is bytes, the block behind it int16: widen it where it stands (the
-         * kernel that wrote it is ahead of this on the compute stream; the block's own samples start 4 * tail bytes in) */
-        HIP_TRY(hipMemcpyAsync(e->d_tailtmp, e->d_in[cur], (size_t)e->tail * 2, hipMemcpyDeviceToDevice, e->s_compute));
-        hipLaunchKernelGGL(mfm_unpack_kernel, dim3((e->tail / 8u + 256u) / 256u), dim3(256), 0, e->s_compute, e->d_tailtmp,
-                           e->d_in[cur], e->tail, e->tail_fmt, 0);
-        HIP_TRY(hipGetLastError());
     }
 
     bool tail_in_kernel = false;
@@ -1379,7 +1393,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             V.nitems = ((V.nchunks + 7u) / 8u) * 8u * V.nslices;
             V.tail_src = n_new * D;
             V.tail_n = n_avail - n_new * D;
-            V.tail_dst = e->d_in[cur ^ 1];
+            V.tail_dst = e->d_in[nxt];
             tail_in_kernel = true;
             V.st_in = L.st_in;
             V.st_out = L.st_out;
@@ -1402,7 +1416,7 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
             M.nitems = ((M.ntiles + 7u) / 8u) * 8u * M.nslices;
             M.tail_src = n_new * D;
             M.tail_n = n_avail - n_new * D;
-            M.tail_dst = e->d_in[cur ^ 1];
+            M.tail_dst = e->d_in[nxt];
             tail_in_kernel = true;
             M.st_in = L.st_in;
             M.st_out = L.st_out;
@@ -1428,12 +1442,12 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         e->grid_last = e->use_mfma ? L.ntiles : ((L.ntiles + 7) / 8) * 8 * L.nslices;
     }
 
-    /* carry the unconsumed tail to the front of the other staging buffer (the MFMA kernel has done it itself) */
+    /* carry the unconsumed tail to the front of the next staging buffer (the MFMA kernels have done it themselves) */
     const uint32_t consumed = n_new * D;
     const uint32_t new_tail = n_avail - consumed;
     if (new_tail && !tail_in_kernel) {
         const size_t ss = raw8 ? 2 : 4;
-        HIP_TRY(hipMemcpyAsync(e->d_in[cur ^ 1], reinterpret_cast<const uint8_t *>(e->d_in[cur]) + (size_t)consumed * ss,
+        HIP_TRY(hipMemcpyAsync(e->d_in[nxt], reinterpret_cast<const uint8_t *>(e->d_in[cur]) + (size_t)consumed * ss,
                                (size_t)new_tail * ss, hipMemcpyDeviceToDevice, e->s_compute));
     }
     /* Every event record is a packet the command processor handles between two kernels (about 4 us each on
@@ -1469,24 +1483,212 @@ int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_st
         e->outputs += n_new;
     }
 
+    e->last_launch_samples = n_avail;
+    e->last_launch_buf = cur;
+    e->last_launch_fmt = fmt;
     e->tail = new_tail;
     e->tail_fmt = fmt;
     e->in_fmt[cur] = MFM_IN_CS16;
-    e->cur_in = cur ^ 1;
-    e->samples_in += nr_samples;
+    e->pend = 0;
+    e->cur_in = nxt;
     return MFM_OK;
 }
 
-/* would a block of nr_samples find a free output slot?  (refused before anything is staged, so a caller can drain
- * and retry) */
+/* the buffer being filled holds blocks of another format than the one about to be accepted (a capture that changes its
+ * sample format mid-stream; a cu8 block of odd length): what is there goes out as a launch of its own first */
+int flush_for_format(mfm_engine *e, int fmt)
+{
+    if (0 == e->pend || e->in_fmt[e->cur_in] == fmt) {
+        return MFM_OK;
+    }
+    std::lock_guard<std::mutex> guard(e->mu);
+    return launch_locked(e);
+}
+
+} /* namespace */
+
+extern "C" {
+
+int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacity_samples)
+{
+    if (!e || !d_dst) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int rc = flush_for_format(e, MFM_IN_CS16);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    /* the kernel that last read this buffer (nbuf launches ago) must be done with it */
+    if (e->in_free_wait[e->cur_in]) {
+        HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
+        e->in_free_wait[e->cur_in] = nullptr; /* waited for: later blocks of this buffer need not ask again */
+    }
+    if (0 == e->pend) {
+        e->in_fmt[e->cur_in] = MFM_IN_CS16; /* what a device producer writes; mfm_engine_stage() says otherwise for raw bytes */
+    }
+    *d_dst = e->d_in[e->cur_in] + e->tail + e->pend;
+    if (capacity_samples) {
+        *capacity_samples = std::min<size_t>(e->cap_in - e->tail - e->pend, e->cfg.max_block_samples);
+    }
+    return MFM_OK;
+}
+
+/* would the engine keep an 8-bit block of this format as bytes now?  (mfm_engine_internal.h) */
+int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_samples)
+{
+    /* not a cu8 block of odd length (file_if.c:146-150 widens its last sample differently), not behind a history or
+     * behind accepted blocks of another format */
+    if (!e || !e->committed || !e->raw8_ok || !(format == MFM_IN_CS8 || format == MFM_IN_CU8 || format == MFM_IN_RTLSDR_U8) ||
+        (format == MFM_IN_CU8 && (nr_samples & 1u))) {
+        return 0;
+    }
+    const int bf = buffer_format(e);
+    return bf == -1 || bf == format;
+}
+
+int mfm_engine_acquire_input_bytes(struct mfm_engine *e, int format, void **d_dst, size_t *capacity_samples)
+{
+    if (!e || !d_dst) {
+        return fail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (format != MFM_IN_CS8 && format != MFM_IN_CU8 && format != MFM_IN_RTLSDR_U8) {
+        return fail(MFM_E_INVAL, "not an 8-bit sample format: %d", format);
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int rc = flush_for_format(e, format);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    if (!mfm_engine_can_take_bytes(e, format, 0)) {
+        return fail(MFM_E_STATE, "this engine cannot read format %d as bytes now (kernel variant, or a history of another "
+                                 "format): widen the block and use mfm_engine_acquire_input", format);
+    }
+    if (e->in_free_wait[e->cur_in]) {
+        HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
+        e->in_free_wait[e->cur_in] = nullptr;
+    }
+    e->in_fmt[e->cur_in] = format;
+    *d_dst = reinterpret_cast<uint8_t *>(e->d_in[e->cur_in]) + ((size_t)e->tail + e->pend) * 2;
+    if (capacity_samples) {
+        *capacity_samples = std::min<size_t>(e->cap_in - e->tail - e->pend, e->cfg.max_block_samples); /* the block limit is that of int16 blocks */
+    }
+    return MFM_OK;
+}
+
+/* mode: MFM_SUBMIT_AUTO - the engine decides whether the buffer is launched now (mfm_engine_config::coalesce_samples);
+ * _DEFER / _LAUNCH - a device group has decided for all its shards (mfm_engine_internal.h) */
+int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer, int mode)
+{
+    if (!e) {
+        return fail(MFM_E_INVAL, "NULL engine");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (0 == nr_samples) {
+        /* receiver_sample_buf_deliver() treats an empty buffer as a bug (receiver.c:84) */
+        return fail(MFM_E_INVAL, "empty block");
+    }
+    if (nr_samples > (size_t)e->cap_in - e->tail - e->pend || nr_samples > e->cfg.max_block_samples) {
+        return fail(MFM_E_INVAL, "block of %zu samples exceeds max_block_samples %u", nr_samples,
+                    e->cfg.max_block_samples);
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    std::lock_guard<std::mutex> guard(e->mu);
+
+    const int cur = e->cur_in;
+    const int fmt = e->in_fmt[cur];
+    const bool raw8 = fmt != MFM_IN_CS16;
+    if (raw8 && !mfm_engine_can_take_bytes(e, fmt, nr_samples)) {
+        if (0 == e->pend) {
+            e->in_fmt[cur] = MFM_IN_CS16;
+        }
+        return fail(MFM_E_INVAL, "a block of %zu samples of format %d cannot be read as bytes here (cu8 blocks must be of "
+                                 "even length)", nr_samples, fmt);
+    }
+
+    SubmitPlan plan;
+    plan_block(e, nr_samples, &plan, true);
+    const bool launch = mode == MFM_SUBMIT_LAUNCH || (mode == MFM_SUBMIT_AUTO && (plan.must || (plan.want && plan.may)));
+    if (launch && !plan.may) {
+        return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
+    }
+
+    if (wait_producer) {
+        HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
+        HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
+    }
+
+    if (!raw8 && 0 == e->pend && e->tail && e->tail_fmt != MFM_IN_CS16) {
+        /* the history at the front of this buffer is bytes, the block behind it int16: widen it where it stands (the
+         * kernel that wrote it is ahead of this on the compute stream; the block's own samples start 4 * tail bytes in) */
+        HIP_TRY(hipMemcpyAsync(e->d_tailtmp, e->d_in[cur], (size_t)e->tail * 2, hipMemcpyDeviceToDevice, e->s_compute));
+        hipLaunchKernelGGL(mfm_unpack_kernel, dim3((e->tail / 8u + 256u) / 256u), dim3(256), 0, e->s_compute, e->d_tailtmp,
+                           e->d_in[cur], e->tail, e->tail_fmt, 0);
+        HIP_TRY(hipGetLastError());
+        e->tail_fmt = MFM_IN_CS16;
+    }
+
+    e->pend += (uint32_t)nr_samples;
+    e->samples_in += nr_samples;
+    e->submits++;
+    return launch ? launch_locked(e) : MFM_OK;
+}
+
+int mfm_engine_submit(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer)
+{
+    return mfm_engine_submit_mode(e, nr_samples, producer_stream, wait_producer, MFM_SUBMIT_AUTO);
+}
+
+/* what accepting a block of nr_samples would mean for this engine (mfm_engine_internal.h) */
+int mfm_engine_plan(struct mfm_engine *e, size_t nr_samples, int *must, int *may, int *want)
+{
+    if (!e || !e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (hipSetDevice(e->cfg.device) != hipSuccess) {
+        return fail(MFM_E_DEVICE, "hipSetDevice(%d) failed", e->cfg.device);
+    }
+    SubmitPlan p;
+    plan_block(e, nr_samples, &p, false);
+    *must = p.must ? 1 : 0;
+    *may = p.may ? 1 : 0;
+    *want = p.want ? 1 : 0;
+    return MFM_OK;
+}
+
+int mfm_engine_format_conflict(struct mfm_engine *e, int fmt)
+{
+    return (e && e->committed && e->pend && e->in_fmt[e->cur_in] != fmt) ? 1 : 0;
+}
+
+int mfm_engine_flush(struct mfm_engine *e)
+{
+    if (!e || !e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    if (0 == e->pend) {
+        return MFM_OK;
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    std::lock_guard<std::mutex> guard(e->mu);
+    return launch_locked(e);
+}
+
+/* would a block of nr_samples be accepted?  (refused before anything is staged, so a caller can drain and retry) */
 static int check_output_room(struct mfm_engine *e, size_t nr_samples)
 {
-    if (!(e->cfg.flags & MFM_F_DEVICE_ONLY)) {
-        std::lock_guard<std::mutex> guard(e->mu);
-        const uint32_t n_avail = e->tail + (uint32_t)nr_samples;
-        if (n_avail >= e->nr_taps && e->slots[e->submit_seq % e->nslots].state != OutSlot::FREE) {
-            return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
-        }
+    SubmitPlan p;
+    plan_block(e, nr_samples, &p, false);
+    if (p.must && !p.may) {
+        return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
     }
     return MFM_OK;
 }
@@ -1511,42 +1713,51 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
     if (0 == nr_samples || nr_samples > e->cfg.max_block_samples) {
         return fail(MFM_E_INVAL, "block of %zu samples (max %u)", nr_samples, e->cfg.max_block_samples);
     }
-    int rc = check_output_room(e, nr_samples);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    /* the matrix kernel reads the bytes themselves (mfm_kernel_v3.hip, IN8): half the HBM bytes, half the matrix
+     * instructions, no widening pass.  Everything else goes the int16 way. */
+    const bool raw = allow_raw && mfm_engine_can_take_bytes(e, format, nr_samples);
+    int rc = flush_for_format(e, raw ? format : MFM_IN_CS16);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    rc = check_output_room(e, nr_samples);
     if (rc != MFM_OK) {
         return rc;
     }
     void *dst = nullptr;
     size_t cap = 0;
-    rc = mfm_engine_acquire_input(e, &dst, &cap);
+    rc = raw ? mfm_engine_acquire_input_bytes(e, format, &dst, &cap) : mfm_engine_acquire_input(e, &dst, &cap);
     if (rc != MFM_OK) {
         return rc;
     }
+    if (cap < nr_samples) {
+        return fail(MFM_E_INVAL, "the input buffer has room for %zu samples, the block has %zu", cap, nr_samples);
+    }
     const int cur = e->cur_in;
     if (!e->h_in[cur]) {
-        HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cfg.max_block_samples * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cap_in * 4, hipHostMallocDefault));
     }
-    /* acquire_input() waited for the kernel that consumed the previous contents of this pair */
-    if (allow_raw && mfm_engine_can_take_bytes(e, format, nr_samples)) {
-        /* the matrix kernel reads the bytes themselves (mfm_kernel_v3.hip, IN8): half the HBM bytes, half the matrix
-         * instructions, no widening pass.  Everything else goes the int16 way below. */
-        uint8_t *raw = reinterpret_cast<uint8_t *>(e->d_in[cur]) + (size_t)e->tail * 2;
-        memcpy(e->h_in[cur], data, nr_samples * 2);
-        HIP_TRY(hipMemcpyAsync(raw, e->h_in[cur], nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
-        e->in_fmt[cur] = format;
-        dst = raw;
+    /* acquire_input() waited for the kernel that consumed the previous contents of this buffer, so the copies out of
+     * h_in[cur] that fed it are done; blocks accepted since then sit in front of this one, as they do on the device */
+    uint8_t *h = reinterpret_cast<uint8_t *>(e->h_in[cur]) + (size_t)e->pend * 4;
+    if (raw) {
+        memcpy(h, data, nr_samples * 2);
+        HIP_TRY(hipMemcpyAsync(dst, h, nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
     } else if (format == MFM_IN_CS16) {
-        memcpy(e->h_in[cur], data, nr_samples * 4);
-        HIP_TRY(hipMemcpyAsync(dst, e->h_in[cur], nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
+        memcpy(h, data, nr_samples * 4);
+        HIP_TRY(hipMemcpyAsync(dst, h, nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
     } else {
         if (!e->d_raw[cur]) {
-            HIP_TRY(hipMalloc(&e->d_raw[cur], (size_t)e->cfg.max_block_samples * 2 + 16));
+            HIP_TRY(hipMalloc(&e->d_raw[cur], (size_t)e->cap_in * 2 + 64));
         }
-        /* the unpack kernel of the previous use of d_raw[cur] ran before the kernel acquire_input() waited for */
-        memcpy(e->h_in[cur], data, nr_samples * 2);
-        HIP_TRY(hipMemcpyAsync(e->d_raw[cur], e->h_in[cur], nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
+        /* the unpack kernels of the previous use of d_raw[cur] ran before the kernel acquire_input() waited for */
+        uint16_t *draw = e->d_raw[cur] + ((e->pend + 7u) & ~7u); /* the unpack kernel reads 16-byte groups */
+        memcpy(h, data, nr_samples * 2);
+        HIP_TRY(hipMemcpyAsync(draw, h, nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
         uint32_t blocks = (uint32_t)((nr_samples / 8 + 255) / 256);
         blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-        hipLaunchKernelGGL(mfm_unpack_kernel, dim3(blocks), dim3(256), 0, e->s_in, e->d_raw[cur],
+        hipLaunchKernelGGL(mfm_unpack_kernel, dim3(blocks), dim3(256), 0, e->s_in, draw,
                            static_cast<uint32_t *>(dst), (uint32_t)nr_samples, format, 1);
         HIP_TRY(hipGetLastError());
     }
@@ -1570,12 +1781,9 @@ int mfm_engine_pending_blocks(struct mfm_engine *e)
     return (int)(e->submit_seq - e->fetch_seq);
 }
 
-int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples)
+int mfm_engine_pending_samples(struct mfm_engine *e)
 {
-    if (!e || !e->committed) {
-        return fail(MFM_E_STATE, "commit first");
-    }
-    return check_output_room(e, nr_samples);
+    return (e && e->committed) ? (int)e->pend : 0;
 }
 
 int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
@@ -1589,6 +1797,44 @@ int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_sam
     const int rc = mfm_engine_stage(e, bytes, nr_samples, format, 1, nullptr);
     return rc != MFM_OK ? rc : mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
+
+int mfm_engine_last_launch_input(struct mfm_engine *e, void **d_in, size_t *nr_samples, int *format)
+{
+    if (!e || !e->committed || e->last_launch_buf < 0) {
+        return fail(MFM_E_STATE, "no launch yet");
+    }
+    if (d_in) {
+        *d_in = e->d_in[e->last_launch_buf];
+    }
+    if (nr_samples) {
+        *nr_samples = e->last_launch_samples;
+    }
+    if (format) {
+        *format = e->last_launch_fmt;
+    }
+    return MFM_OK;
+}
+
+int mfm_engine_replay(struct mfm_engine *e, size_t block_samples, size_t nr_blocks)
+{
+    for (size_t i = 0; i < nr_blocks; i++) {
+        void *dst = nullptr;
+        size_t cap = 0;
+        int rc = mfm_engine_acquire_input(e, &dst, &cap);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+        if (cap < block_samples) {
+            return fail(MFM_E_INVAL, "replay: block of %zu samples, room for %zu", block_samples, cap);
+        }
+        rc = mfm_engine_submit(e, block_samples, nullptr, 0);
+        if (rc != MFM_OK) {
+            return rc;
+        }
+    }
+    return MFM_OK;
+}
+
 
 int mfm_engine_fetch(struct mfm_engine *e, struct mfm_block *blk)
 {
@@ -1668,6 +1914,11 @@ int mfm_engine_sync(struct mfm_engine *e)
         return fail(MFM_E_STATE, "commit first");
     }
     HIP_TRY(hipSetDevice(e->cfg.device));
+    /* what has been accepted and not launched goes out first (MFM_E_BUSY: the caller fetches / releases and syncs again) */
+    const int rc = mfm_engine_flush(e);
+    if (rc != MFM_OK) {
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(e->s_in));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
     HIP_TRY(hipStreamSynchronize(e->s_out));
@@ -1679,6 +1930,8 @@ int mfm_engine_reset(struct mfm_engine *e)
     if (!e || !e->committed) {
         return fail(MFM_E_STATE, "commit first");
     }
+    /* pending blocks are dropped, accepted-but-unlaunched samples with them */
+    e->pend = 0;
     int rc = mfm_engine_sync(e);
     if (rc != MFM_OK) {
         return rc;
@@ -1694,8 +1947,10 @@ int mfm_engine_reset(struct mfm_engine *e)
     e->last_slot = -1;
     e->tail = 0;
     e->tail_fmt = MFM_IN_CS16;
-    e->in_fmt[0] = e->in_fmt[1] = MFM_IN_CS16;
+    e->in_fmt[0] = e->in_fmt[1] = e->in_fmt[2] = MFM_IN_CS16;
     e->cur_in = 0;
+    e->last_launch_samples = 0;
+    e->last_launch_buf = -1;
     e->outputs = 0;
     e->samples_in = 0;
     return MFM_OK;
@@ -1725,6 +1980,8 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->tap_hi_mask = e->use_mfma ? e->m_ah_mask : 0u;
     st->taps_resident = (e->use_mfma && !e->use_v3 && e->m_resident_taps) ? 1u : 0u;
     st->reserved0 = 0;
+    st->submits = e->submits;
+    st->pending_samples = e->pend;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
     st->outputs_per_tile = e->use_v3 ? MFM_V3_OT : e->use_mfma ? e->m_ot : 64u * e->opl;

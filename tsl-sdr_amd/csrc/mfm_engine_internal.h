@@ -22,6 +22,19 @@ __attribute__((visibility("hidden"))) int mfm_engine_can_take_bytes(struct mfm_e
 __attribute__((visibility("hidden"))) void *mfm_engine_copy_stream(struct mfm_engine *e);
 /* blocks submitted (with outputs) and not yet released */
 __attribute__((visibility("hidden"))) int mfm_engine_pending_blocks(struct mfm_engine *e);
-/* MFM_OK when a block of nr_samples would find a free output slot, MFM_E_BUSY otherwise */
-__attribute__((visibility("hidden"))) int mfm_engine_output_room(struct mfm_engine *e, size_t nr_samples);
+/* samples accepted and not yet launched (mfm_engine_config::coalesce_samples) */
+__attribute__((visibility("hidden"))) int mfm_engine_pending_samples(struct mfm_engine *e);
+/* What accepting a block of nr_samples would mean for this engine, without doing anything: *must - the buffer has to be
+ * launched with it (no coalescing, or coalesce_samples gathered); *may - a launch would find a free output slot; *want -
+ * the engine's own policy would launch although it does not have to (device idle, or one launch in flight and a quarter
+ * of its samples gathered).  A device group asks every shard and decides once for all of them. */
+__attribute__((visibility("hidden"))) int mfm_engine_plan(struct mfm_engine *e, size_t nr_samples, int *must, int *may, int *want);
+/* 1 when the buffer being filled holds accepted blocks of another format than fmt (they have to be flushed first) */
+__attribute__((visibility("hidden"))) int mfm_engine_format_conflict(struct mfm_engine *e, int fmt);
+#define MFM_SUBMIT_AUTO 0
+#define MFM_SUBMIT_DEFER 1
+#define MFM_SUBMIT_LAUNCH 2
+/* mfm_engine_submit() with the launch decision made by the caller (a device group, for all its shards alike) */
+__attribute__((visibility("hidden"))) int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *producer_stream,
+                                                                 int wait_producer, int mode);
 }

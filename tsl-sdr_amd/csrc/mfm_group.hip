@@ -30,6 +30,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -121,7 +122,8 @@ struct mfm_group {
     std::vector<nccl_comm_t> comm;
     std::vector<hipStream_t> xs; /* exchange stream per shard (shard 0: the root engine's copy stream) */
     uint64_t blocks = 0, bytes_exchanged = 0;
-    bool broken = false; /* a push failed after the first shard had taken the block (mfm_group_seq.h) */
+    std::atomic<bool> broken{ false }; /* a push failed after the first shard had taken the block (mfm_group_seq.h); the push
+                                          thread writes it, the fetch thread reads it */
     std::mutex mu;       /* push's submit loop against fetch's "does every shard hold a block" */
 };
 
@@ -276,6 +278,7 @@ int mfm_group_commit(struct mfm_group *g)
         ec.decimation = g->cfg.decimation;
         ec.max_block_samples = g->cfg.max_block_samples;
         ec.flags = g->cfg.flags;
+        ec.coalesce_samples = g->cfg.coalesce_samples;
         mfm_engine *e = nullptr;
         rc = mfm_engine_create(&e, &ec);
         if (rc != MFM_OK) {
@@ -359,7 +362,18 @@ namespace {
 struct GroupOps {
     mfm_group *g;
     size_t shards() { return g->eng.size(); }
-    int room(size_t i, size_t n) { return mfm_engine_output_room(g->eng[i], n); }
+    int plan(size_t i, size_t n, bool *must, bool *may, bool *want)
+    {
+        int m = 0, y = 0, w = 0;
+        const int rc = mfm_engine_plan(g->eng[i], n, &m, &y, &w);
+        *must = m != 0;
+        *may = y != 0;
+        *want = w != 0;
+        return rc;
+    }
+    bool conflict(size_t i, int fmt) { return 0 != mfm_engine_format_conflict(g->eng[i], fmt); }
+    int unlaunched(size_t i) { return mfm_engine_pending_samples(g->eng[i]); }
+    int flush(size_t i) { return mfm_engine_flush(g->eng[i]); }
     bool takes_bytes(size_t i, int fmt, size_t n) { return 0 != mfm_engine_can_take_bytes(g->eng[i], fmt, n); }
     int acquire(size_t i, bool raw, int fmt, void **dst, size_t *cap)
     {
@@ -421,7 +435,10 @@ struct GroupOps {
         }
         return MFM_OK;
     }
-    int submit(size_t i, size_t n) { return mfm_engine_submit(g->eng[i], n, g->xs[i], 1); }
+    int submit(size_t i, size_t n, bool launch)
+    {
+        return mfm_engine_submit_mode(g->eng[i], n, g->xs[i], 1, launch ? MFM_SUBMIT_LAUNCH : MFM_SUBMIT_DEFER);
+    }
     int pending(size_t i) { return mfm_engine_pending_blocks(g->eng[i]); }
     int fetch(size_t i, mfm_block *blk) { return mfm_engine_fetch(g->eng[i], blk); }
     uint64_t first_output(const mfm_block &b) { return b.first_output; }
@@ -482,10 +499,28 @@ int mfm_group_release(struct mfm_group *g)
     return rc;
 }
 
+int mfm_group_flush(struct mfm_group *g)
+{
+    if (!g || !g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    if (!g->exchange) {
+        return mfm_engine_flush(g->eng[0]);
+    }
+    GroupOps ops{ g };
+    return mfm_group_flush_seq(ops, &g->broken);
+}
+
 int mfm_group_sync(struct mfm_group *g)
 {
     if (!g || !g->committed) {
         return gfail(MFM_E_STATE, "commit first");
+    }
+    {
+        const int rc = mfm_group_flush(g);
+        if (rc != MFM_OK) {
+            return rc;
+        }
     }
     for (size_t i = 0; i < g->xs.size(); i++) {
         if (i > 0 && (hipSetDevice(g->dev[i]) != hipSuccess || hipStreamSynchronize(g->xs[i]) != hipSuccess)) {

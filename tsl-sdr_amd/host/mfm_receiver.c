@@ -316,6 +316,23 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
     while (worker_thread_is_running(wthr) || rx->ring_tail != rx->ring_head) {
         const size_t tail = rx->ring_tail;
         if (tail == rx->ring_head) {
+            /* the backlog is through: what the device group accepted without launching goes out now, as the reference's
+             * channel thread runs what its queue held before it sleeps again (multifm/demod.c:134-150) */
+            while (!rx->failed) {
+                _bell_arm(&rx->room_bell);
+                const int frc = mfm_group_flush(rx->group);
+                if (MFM_E_BUSY == frc) {
+                    _bell_sleep(&rx->room_bell, MFM_IDLE_MS);
+                    continue;
+                }
+                _bell_disarm(&rx->room_bell);
+                if (MFM_OK != frc) {
+                    MFM_MSG(SEV_FATAL, "ENGINE-FLUSH", "mfm_group_flush failed: %s", mfm_last_error());
+                    rx->failed = 1;
+                }
+                break;
+            }
+            _bell_ring(&rx->block_bell);
             _bell_arm(&rx->ring_bell);
             if (tail == rx->ring_head && worker_thread_is_running(wthr)) {
                 _bell_sleep(&rx->ring_bell, MFM_IDLE_MS);
@@ -369,15 +386,8 @@ static aresult_t _receiver_drain_once(struct receiver *rx, bool *got)
     }
     if (!rx->muted) {
         list_for_each_type(dthr, &rx->demod_threads, dt_node) {
-            /* which shard holds this channel, and which row of the shard's block it is */
-            for (int s = 0; s < rx->nr_shards; s++) {
-                uint32_t first = 0, count = 0;
-                if (MFM_OK == mfm_group_shard_info(rx->group, (uint32_t)s, &first, &count, NULL) &&
-                    (uint32_t)dthr->chan_index >= first && (uint32_t)dthr->chan_index < first + count) {
-                    _demod_thread_emit(dthr, &blks[s], (size_t)dthr->chan_index - first);
-                    break;
-                }
-            }
+            /* which shard holds this channel, and which row of the shard's block it is: looked up once, at receiver_start() */
+            _demod_thread_emit(dthr, &blks[dthr->shard], dthr->shard_row);
         }
     }
     rx->nr_blocks_drained++;
@@ -565,6 +575,20 @@ static aresult_t _settings_read(struct config *cfg, size_t samples_per_buf, stru
     st->group.sample_rate_hz = (uint32_t)st->sample_rate;
     st->group.decimation = (uint32_t)st->decimation;
     st->group.max_block_samples = (uint32_t)samples_per_buf;
+    {
+        /* A channel thread of the reference runs whatever its queue holds - up to 128 sample_bufs, multifm/demod.c:297 - back
+         * to back.  The device group does that with launches: up to a pool's worth of delivered buffers (all that can be
+         * outstanding at once) share one, "gpuCoalesceSamples" overrides (0: one launch per buffer). */
+        int co = -1;
+        uint64_t want = (uint64_t)st->nr_samp_bufs * samples_per_buf;
+        if (!FAILED(config_get_integer(cfg, &co, "gpuCoalesceSamples")) && co >= 0) {
+            want = (uint64_t)co;
+        }
+        st->group.coalesce_samples = (uint32_t)(want > (1u << 26) ? (1u << 26) : want);
+        if (st->group.coalesce_samples <= samples_per_buf) {
+            st->group.coalesce_samples = 0; /* nothing to gather */
+        }
+    }
     return ret;
 }
 
@@ -710,6 +734,26 @@ aresult_t receiver_start(struct receiver *rx)
         return A_E_DEVICE;
     }
     rx->nr_shards = mfm_group_nr_shards(rx->group);
+    {
+        /* channel -> (shard, row of the shard's block): fixed once the group is committed */
+        struct demod_thread *dthr = NULL;
+        list_for_each_type(dthr, &rx->demod_threads, dt_node) {
+            bool found = false;
+            for (int s = 0; s < rx->nr_shards && !found; s++) {
+                uint32_t first = 0, count = 0;
+                if (MFM_OK == mfm_group_shard_info(rx->group, (uint32_t)s, &first, &count, NULL) &&
+                    (uint32_t)dthr->chan_index >= first && (uint32_t)dthr->chan_index < first + count) {
+                    dthr->shard = s;
+                    dthr->shard_row = (size_t)dthr->chan_index - first;
+                    found = true;
+                }
+            }
+            if (!found) {
+                MFM_MSG(SEV_ERROR, "ENGINE-COMMIT", "Channel %d is on no shard of the device group.", dthr->chan_index);
+                return A_E_DEVICE;
+            }
+        }
+    }
     if (FAILED(ret = worker_thread_new(&rx->drain_thr, _receiver_drain_thread, WORKER_THREAD_CPU_MASK_ANY))) {
         return ret;
     }

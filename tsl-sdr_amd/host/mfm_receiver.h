@@ -75,6 +75,8 @@ struct mfm_doorbell {
 struct demod_thread {
     struct list_entry dt_node;
     int chan_index;          /* channel number inside the receiver's engine */
+    int shard;               /* which shard of the device group holds it, and which row of that shard's blocks it is */
+    size_t shard_row;        /*   (set at receiver_start(), when the group is committed) */
     int fifo_fd;             /* PCM sink (demod.c:331) */
     int debug_signal_fd;     /* filtered-IQ sink or -1 (demod.c:322-328) */
     size_t total_nr_demod_samples;
