@@ -135,7 +135,8 @@ def test_coalesced_8bit_blocks_and_format_changes(pkg, ora, policy):
     assert got.shape == want.shape and np.array_equal(got, want)
     assert st["submits"] == len(blocks) and st["launches"] <= st["submits"]
     if policy == "gather":
-        assert 2 <= st["launches_8bit"] < st["launches"] < st["submits"]
+        # the three RTL-SDR blocks in front share ONE byte launch; behind an int16 history everything is widened
+        assert 1 == st["launches_8bit"] < st["launches"] < st["submits"]
 
 
 @pytest.mark.parametrize("nch,block_log2,coalesce_log2", [(64, 12, 20), (16, 17, 22), (130, 14, 18)])
