@@ -58,7 +58,7 @@ extern "C" {
                                 mfm_group_config.exchange
                              4: mfm_engine_config / mfm_group_config grew coalesce_samples (+ a third ext_input); mfm_stats grew submits,
                                 pending_samples; mfm_engine_flush, mfm_group_flush, mfm_engine_input_bytes_cfg, mfm_engine_replay,
-                                mfm_engine_last_launch_input; MFM_F_GATHER */
+                                mfm_engine_last_launch_input, mfm_engine_seek; MFM_F_GATHER, MFM_F_OVERLAP */
 
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
@@ -80,6 +80,13 @@ extern "C" {
 #define MFM_F_GATHER 0x100u    /* with coalesce_samples: launch only once coalesce_samples have gathered, or on mfm_engine_flush() /
                                   mfm_engine_sync() - never because the device happens to be idle (a producer that knows when
                                   its backlog ends and flushes then; deterministic launch boundaries for tests) */
+#define MFM_F_OVERLAP 0x200u   /* second-generation kernel: consecutive launches alternate between two compute streams.  A launch
+                                  depends on the one before it through input samples only (it recomputes the output in front of
+                                  it and finds its rotator position from the stream's output count), so the next launch's
+                                  workgroups take the slots the current one's shorter chunks free up instead of waiting for
+                                  its last tile and a dispatch.  mfm_engine_stream() then returns the stream of the most
+                                  recent launch; per-launch durations (MFM_F_TIMING) include the time a launch waits for
+                                  slots and are no longer kernel time.  Ignored by the other kernels. */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 
@@ -247,13 +254,23 @@ int mfm_engine_replay(struct mfm_engine *e, size_t block_samples, size_t nr_bloc
  * stream (what restarting the reference does). Pending blocks are dropped. */
 int mfm_engine_reset(struct mfm_engine *e);
 
+/*
+ * Resume a stream that had produced outputs_before outputs per channel (a receiver restarted from a checkpoint): as
+ * mfm_engine_reset(), except that the derotators stand where outputs_before steps of their recurrence leave them
+ * (filter/direct_fir.c:151-172 carries rot_phase across buffers; the recurrence is input independent) and
+ * mfm_block::first_output goes on counting from there.  The filter history and the discriminator's last sample start
+ * empty, as after a restart of the reference.
+ */
+int mfm_engine_seek(struct mfm_engine *e, uint64_t outputs_before);
+
 int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st);
 
 /* MFM_F_TIMING: durations (ms, HIP events on the compute stream) of the most recent launches, oldest first; at most
  * `cap` and at most the last 4096.  Returns how many were written. */
 size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap);
 
-/* The engine's compute stream (hipStream_t) for callers that order their own work after it. */
+/* The engine's compute stream (hipStream_t) - with MFM_F_OVERLAP the one the most recent launch went to - for callers that
+ * order their own work after it. */
 void *mfm_engine_stream(struct mfm_engine *e);
 
 const char *mfm_strerror(int err);

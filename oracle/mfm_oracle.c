@@ -250,6 +250,37 @@ void mfmo_chan_skip_outputs(struct mfmo_chan *ch, uint64_t nr_outputs)
         return;
     }
     int16_t re = ch->rot_re, im = ch->rot_im;
+    if (nr_outputs > (1ull << 24)) {
+        /* The recurrence is a map of a finite set (two int16) into itself and does not depend on the input, so from any
+         * state its orbit is a pre-period of mu steps followed by a cycle of lam steps, and n steps end where
+         * mu + (n - mu) mod lam steps do.  Brent's cycle search with the same step function; nothing else changes.
+         * (Bench-rate streams pass 2^32 outputs within a second: stepping one by one would take the oracle minutes.) */
+        int16_t tr = re, ti = im, hr = re, hi = im;
+        uint64_t power = 1, lam = 1, mu = 0;
+        mfmo_rot_step(&hr, &hi, ch->incr_re, ch->incr_im);
+        while (!(tr == hr && ti == hi)) {
+            if (power == lam) {
+                tr = hr;
+                ti = hi;
+                power *= 2;
+                lam = 0;
+            }
+            mfmo_rot_step(&hr, &hi, ch->incr_re, ch->incr_im);
+            lam++;
+        }
+        tr = re, ti = im, hr = re, hi = im;
+        for (uint64_t i = 0; i < lam; i++) {
+            mfmo_rot_step(&hr, &hi, ch->incr_re, ch->incr_im);
+        }
+        while (!(tr == hr && ti == hi)) {
+            mfmo_rot_step(&tr, &ti, ch->incr_re, ch->incr_im);
+            mfmo_rot_step(&hr, &hi, ch->incr_re, ch->incr_im);
+            mu++;
+        }
+        if (nr_outputs > mu) {
+            nr_outputs = mu + (nr_outputs - mu) % lam;
+        }
+    }
     for (uint64_t i = 0; i < nr_outputs; i++) {
         mfmo_rot_step(&re, &im, ch->incr_re, ch->incr_im);
     }

@@ -49,7 +49,7 @@ SIZES = [1, 1, 100, 26, 1, 4096, 4096, 4096, 131072, 16384, 7919, 5, 127, 128, 1
 
 
 @pytest.mark.parametrize("kernel", ["auto", "mfma1", "dot2"])
-@pytest.mark.parametrize("policy", ["gather", "auto"])
+@pytest.mark.parametrize("policy", ["gather", "auto", "gather+overlap", "auto+overlap"])
 def test_coalesced_ragged_buffers_against_the_oracle(pkg, ora, kernel, policy):
     """Front-end sized buffers (file_if 4096, rtl_sdr 131072, uhd 16384, airspy 262144), single samples and blocks shorter
     than the filter, gathered into launches of up to 300 000 samples: same PCM and filtered IQ as the oracle on the whole
@@ -59,7 +59,8 @@ def test_coalesced_ragged_buffers_against_the_oracle(pkg, ora, kernel, policy):
     n = 1200000
     iq = pkg.synth.synth_iq(n, fs, offs[:3], seed=41)
     flags = {"auto": 0, "mfma1": b.MFM_F_FORCE_MFMA_V1, "dot2": b.MFM_F_FORCE_DOT2}[kernel]
-    flags |= b.MFM_F_GATHER if policy == "gather" else 0
+    flags |= b.MFM_F_GATHER if policy.startswith("gather") else 0
+    flags |= b.MFM_F_OVERLAP if policy.endswith("overlap") else 0   # two compute streams (second-generation kernel only)
     eng = pkg.Engine(fs, decim, 262144, device=0, flags=flags, coalesce_samples=300000)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g), want_iq=True)
@@ -87,7 +88,7 @@ def test_coalesced_ragged_buffers_against_the_oracle(pkg, ora, kernel, policy):
     assert np.array_equal(pcm, ref) and np.array_equal(q, refq)
     assert st["samples_in"] == n and st["outputs"] == ref.shape[1] and st["submits"] == k and st["pending_samples"] == 0
     assert st["launches"] <= st["submits"]
-    if policy == "gather":
+    if policy.startswith("gather"):
         # a launch per 300 000 gathered samples (plus the block that crossed the mark), and the flush at the end
         assert st["launches"] <= n // 300000 + 1, st["launches"]
         assert all(p[1].shape[1] >= 300000 // decim - 2 for p in parts[:-1])
@@ -139,8 +140,9 @@ def test_coalesced_8bit_blocks_and_format_changes(pkg, ora, policy):
         assert 1 == st["launches_8bit"] < st["launches"] < st["submits"]
 
 
-@pytest.mark.parametrize("nch,block_log2,coalesce_log2", [(64, 12, 20), (16, 17, 22), (130, 14, 18)])
-def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coalesce_log2):
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("nch,block_log2,coalesce_log2", [(64, 12, 20), (16, 17, 22), (130, 14, 18), (64, 20, 0)])
+def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coalesce_log2, overlap):
     """mfm_engine_replay: the producer loop of a C host - acquire_input, submit - on blocks that are already in HBM (what
     bench.py's block_series times), with the engine's own launch policy.  Every launch's PCM in HBM against the oracle on
     the samples that launch read (mfm_engine_last_launch_input), rotators stepped to the launch's first output."""
@@ -148,8 +150,9 @@ def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coale
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=nch)
-    block, co = 1 << block_log2, 1 << coalesce_log2
-    eng = pkg.Engine(fs, decim, block, device=0, flags=b.MFM_F_DEVICE_ONLY, coalesce_samples=co)
+    block, co = 1 << block_log2, (1 << coalesce_log2) if coalesce_log2 else 0
+    eng = pkg.Engine(fs, decim, block, device=0, flags=b.MFM_F_DEVICE_ONLY | (b.MFM_F_OVERLAP if overlap else 0),
+                     coalesce_samples=co)
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))
     eng.commit()
@@ -157,7 +160,7 @@ def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coale
     cfg.max_block_samples, cfg.coalesce_samples = block, co
     nb = C.c_uint32()
     in_bytes = eng.lib.mfm_engine_input_bytes_cfg(C.byref(cfg), len(taps), C.byref(nb))
-    assert nb.value == 3 and in_bytes >= 4 * (block + co + len(taps))
+    assert nb.value == (3 if co else 2) and in_bytes >= 4 * (block + co + len(taps))
     # every input buffer holds the same synthetic samples (the buffers are the engine's own: fill them where it says)
     base = pkg.synth.synth_iq(in_bytes // 4, fs, offs[:4], seed=5).reshape(-1)
     seen = set()
@@ -166,13 +169,13 @@ def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coale
         assert cap == block
         if ptr not in seen:
             seen.add(ptr)
-            assert hip.hipMemcpy(ptr, base.ctypes.data, in_bytes - 4 * (len(taps) + 64), 1) == 0
+            assert hip.hipMemcpy(ptr, base.ctypes.data, in_bytes - 4 * (2 * len(taps) + 64), 1) == 0
         eng.submit(block, producer_stream=0, wait_producer=False)
         eng.flush()
     eng.sync()
     eng.reset()
     checked = 0
-    for rounds, blocks in ((1, 1), (1, 7), (3, 150), (2, 1000)):
+    for rounds, blocks in ((1, 1), (1, 7), (3, 150), (2, 1000 if block_log2 < 20 else 40)):
         for _ in range(rounds):
             eng.replay(block, blocks)
         eng.sync()
@@ -194,8 +197,11 @@ def test_device_resident_blocks_replayed_from_c(pkg, ora, nch, block_log2, coale
                 checked += cnt
     st = eng.stats()
     eng.close()
-    assert checked > 0 and st["submits"] >= 3 * 150 + 2 * 1000 and st["pending_samples"] == 0
-    assert st["launches"] < st["submits"]  # 2000 blocks handed over faster than the device takes single ones
+    assert checked > 0 and st["submits"] >= 3 * 150 + 2 * 40 and st["pending_samples"] == 0
+    if co:
+        assert st["launches"] < st["submits"]  # 2000 blocks handed over faster than the device takes single ones
+    else:
+        assert st["launches"] == st["submits"]
 
 
 @pytest.mark.parametrize("shards,mode,nch,gather", [(2, "rccl", 70, "gather"), (3, "allgather", 70, "auto"), (8, "allgather", 130, "gather")])
@@ -211,3 +217,86 @@ def test_coalescing_group_of_several_shards_through_a_fake_transport(tmp_path, s
     r = subprocess.run(["python3", os.path.join(ROOT, "tests", "hoststub", "multi_shard_run.py"), str(shards), mode, str(nch),
                         "150000", gather], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "multi-shard ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("want_iq", [False, True])
+@pytest.mark.parametrize("plan,nch", [("cfg2_64ch", 64), ("cfg2_64ch_grid", 64), ("cfg3_1024ch", 200), ("multifm_1ch", 20)])
+def test_overlapped_launches_against_the_oracle(pkg, ora, plan, nch, want_iq):
+    """MFM_F_OVERLAP: consecutive launches on two streams.  A launch takes nothing from the one before it but input samples
+    (the output in front of it is recomputed from the row kept in front of the first unconsumed sample, the rotator position
+    folded from the stream's output count), so whatever order the device runs their workgroups in, the stream is the
+    oracle's: general, quarter-turn, sign-flip and identity rotators (filter/direct_fir.c:151-172), filtered IQ on and off
+    (different kernel instances), blocks of 20 tiles and of less than one, 16 slices of channels."""
+    b = pkg.binding
+    fs, decim, taps, offs, gains = pkg.synth.plan(plan, nr_channels=nch)
+    n = decim * 40000 + 777
+    iq = pkg.synth.synth_iq(n, fs, offs[:3], seed=43)
+    eng = pkg.Engine(fs, decim, 1 << 17, device=0, flags=b.MFM_F_OVERLAP)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
+    eng.commit()
+    assert eng.stats()["kernel_variant"] == 2
+    cre = np.stack([eng.get_channel(c)[0] for c in range(nch)])
+    cim = np.stack([eng.get_channel(c)[1] for c in range(nch)])
+    incr = np.stack([eng.get_channel(c)[2] for c in range(nch)])
+    ref, refq = ora.run_channels(iq, cre, cim, incr, decim, threads=8, want_iq=want_iq)
+    sizes = [131072, 131072, 5000, 131072, 64 * decim, 63 * decim, 1, 131072, 100, 131072, 131072, 90000]
+    parts, qparts, pos, k = [], [], 0, 0
+    while pos < n:
+        m = min(sizes[k % len(sizes)], n - pos)
+        rc = eng.push(iq[pos:pos + m])
+        if rc == b.MFM_E_BUSY:
+            _drain(eng, parts, qparts)
+            continue
+        assert rc == 0, eng.lib.mfm_last_error()
+        pos += m
+        k += 1
+    _finish(eng, parts, qparts)
+    eng.close()
+    pcm = np.concatenate([p[1] for p in parts], axis=1)
+    assert pcm.shape == ref.shape
+    if not np.array_equal(pcm, ref):
+        bad = np.argwhere(pcm != ref)
+        raise AssertionError(f"{len(bad)} PCM samples differ; first at (chan, n) = {bad[0]}")
+    if want_iq:
+        assert np.array_equal(np.concatenate(qparts, axis=1), refq)
+
+
+@pytest.mark.parametrize("kernel", ["auto", "mfma1", "dot2", "auto+overlap"])
+@pytest.mark.parametrize("before", [0, 53000, (1 << 32) - 300, (1 << 33) + 12345, (1 << 40) + 1])
+def test_seek_resumes_the_rotators_also_beyond_2_to_the_32(pkg, ora, kernel, before):
+    """mfm_engine_seek: a stream resumed at output `before` - the derotators where that many steps of the recurrence leave
+    them (filter/direct_fir.c:166-167), history and discriminator empty.  Counts inside the pre-period of the 101 kHz
+    rotator (53 105 steps), across 2^32 (the kernels fold a 64-bit output count; a stream at the bench's rate gets there
+    within a second) and far beyond.  Oracle: the same channel stepped to `before` (mfmo_chan_skip_outputs)."""
+    b = pkg.binding
+    fs, decim = 2400000, 96
+    taps = pkg.synth.design_lpf(128, 12500.0, fs)
+    offs = [101000, 777, 3125, 37500, 25000, 12500, -6250, 1000000]
+    n = decim * 900 + 500
+    iq = pkg.synth.synth_iq(n, fs, offs[:2], seed=52, noise=2000)
+    flags = {"auto": 0, "mfma1": b.MFM_F_FORCE_MFMA_V1, "dot2": b.MFM_F_FORCE_DOT2, "auto+overlap": b.MFM_F_OVERLAP}[kernel]
+    eng = pkg.Engine(fs, decim, 1 << 15, device=0, flags=flags)
+    for o in offs:
+        eng.add_channel(int(o), taps, 1.0, want_iq=True)
+    eng.commit()
+    # a stream first, so that seek has something to forget
+    eng.run(iq[:20000], 7000)
+    eng.seek(before)
+    parts, qparts = [], []
+    for lo in range(0, n, 30000):
+        assert eng.push(iq[lo:lo + 30000]) == 0
+        _drain(eng, parts, qparts)
+    _finish(eng, parts, qparts)
+    assert parts[0][0] == before
+    pcm = np.concatenate([p[1] for p in parts], axis=1)
+    q = np.concatenate(qparts, axis=1)
+    for c in range(len(offs)):
+        cre, cim, incr = eng.get_channel(c)
+        ch = ora.Channel(cre, cim, decim, incr)
+        ch.skip_outputs(before)
+        want, wantq = ch.feed(iq)
+        ch.close()
+        assert np.array_equal(pcm[c], want), (c, before)
+        assert np.array_equal(q[c], wantq.reshape(-1, 2)), (c, before)
+    eng.close()

@@ -23,12 +23,13 @@ MFM_F_TIMING_SPARSE = 0x20
 MFM_F_GROUP_SHARED_DEVICE = 0x40
 MFM_F_STREAM_TAPS = 0x80
 MFM_F_GATHER = 0x100
+MFM_F_OVERLAP = 0x200
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
 ABI_SYMBOLS = [
     "mfm_engine_input_bytes", "mfm_engine_input_bytes_cfg", "mfm_engine_flush", "mfm_engine_replay", "mfm_group_flush",
-    "mfm_engine_last_launch_input",
+    "mfm_engine_last_launch_input", "mfm_engine_seek",
     "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
     "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
     "mfm_engine_acquire_input_bytes",
@@ -172,6 +173,7 @@ def load_library():
     lib.mfm_engine_input_bytes_cfg.argtypes = [C.POINTER(EngineConfig), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mfm_engine_flush.argtypes = [vp]
     lib.mfm_engine_replay.argtypes = [vp, C.c_size_t, C.c_size_t]
+    lib.mfm_engine_seek.argtypes = [vp, C.c_uint64]
     lib.mfm_engine_last_launch_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     lib.mfm_group_flush.argtypes = [vp]
     lib.mfm_engine_create.argtypes = [C.POINTER(vp), C.POINTER(EngineConfig)]
@@ -458,6 +460,10 @@ class Engine:
 
     def reset(self):
         self._chk(self.lib.mfm_engine_reset(self.h), "mfm_engine_reset")
+
+    def seek(self, outputs_before):
+        """fresh history, rotators where outputs_before steps leave them, output numbering continues from there"""
+        self._chk(self.lib.mfm_engine_seek(self.h, int(outputs_before)), "mfm_engine_seek")
 
     def stats(self):
         st = Stats()

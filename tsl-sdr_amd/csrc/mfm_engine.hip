@@ -200,12 +200,16 @@ struct mfm_engine {
     hipEvent_t in_ready = nullptr;
     int nbuf = 2;      /* 3 with coalesce_samples: one being read, one queued behind it, one being filled */
     int cur_in = 0;
-    uint32_t tail = 0; /* samples of history at the front of d_in[cur_in] */
+    uint32_t tail = 0; /* unconsumed samples at the front of d_in[cur_in] (behind `hist`): the history the next outputs need */
+    uint32_t hist = 0; /* second-generation kernel: already consumed samples kept in front of them - the decimation once the
+                          stream has produced an output, 0 before -, from which a launch recomputes the output in front of
+                          it instead of reading carried state (mfm_launch_v3::hist) */
     uint32_t pend = 0; /* samples accepted into d_in[cur_in] behind the history and not yet launched (coalesce_samples) */
     uint32_t last_launch_samples = 0; /* what the most recent launch read: a second launch is queued behind one in flight
                                          once a quarter of that has gathered */
     uint64_t submits = 0;
     int last_launch_buf = -1, last_launch_fmt = MFM_IN_CS16;
+    uint32_t last_launch_hist = 0;
     /* 8-bit blocks may sit in the input buffers as they came off the wire (2 bytes per sample, push_bytes): the format of
      * what was staged into each buffer, and of the history at the front of d_in[cur_in] */
     int in_fmt[kMaxInBufs] = { MFM_IN_CS16, MFM_IN_CS16, MFM_IN_CS16 };
@@ -221,6 +225,14 @@ struct mfm_engine {
     int last_slot = -1;
 
     hipStream_t s_in = nullptr, s_compute = nullptr, s_out = nullptr;
+    /* MFM_F_OVERLAP: launches alternate between two compute streams (cs[0] = s_compute).  A launch of the second-generation
+     * kernel depends on the one before it through input samples only (mfm_launch_v3::hist, ::k_base), so launch k + 1 fills
+     * the workgroup slots launch k's shorter chunks free up instead of waiting for its last tile - and for a dispatch. */
+    hipStream_t cs[2] = { nullptr, nullptr };
+    uint32_t ncs = 1;
+    hipStream_t s_last = nullptr; /* the stream the most recent launch went to (mfm_engine_stream) */
+    hipEvent_t tail_done[kMaxInBufs] = { nullptr, nullptr, nullptr }; /* overlap: the carry out of buffer i has been copied */
+    bool tail_pending[kMaxInBufs] = { false, false, false };
     hipEvent_t kernel_done = nullptr;
 
     /* stream bookkeeping */
@@ -323,6 +335,23 @@ void fill_mfma(const mfm_engine *e, int fmt, mfm_launch_mfma &M)
     }
 }
 
+/* The dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) belongs to a kernel instance on a device, not to an
+ * engine: two engines of one process can share an instance with different image sizes (first-generation kernels with
+ * different decimations; the generic second-generation instances).  The limit is therefore only ever RAISED: the largest
+ * value any engine of the process has asked for, per (device, instance). */
+int raise_lds_limit(int device, const void *fn, uint32_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, uint32_t> limit;
+    std::lock_guard<std::mutex> guard(mu);
+    uint32_t &have = limit[std::make_pair(device, fn)];
+    if (lds > have) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        have = lds;
+    }
+    return MFM_OK;
+}
+
 /* which instance runs blocks of each input format; its LDS limit is raised here, once (commit, on the engine's device) */
 int select_kernels(mfm_engine *e)
 {
@@ -353,7 +382,12 @@ int select_kernels(mfm_engine *e)
             HIP_TRY(mfm_select_channel_kernel(e->opl, e->any_iq ? 1 : 0, &fn));
             lds = e->lds_bytes;
         }
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            const int rc = raise_lds_limit(e->cfg.device, fn, lds);
+            if (rc != MFM_OK) {
+                return rc;
+            }
+        }
         e->kfn[fmt] = fn;
     }
     return MFM_OK;
@@ -447,6 +481,17 @@ void free_device(mfm_engine *e)
     if (e->s_in) {
         (void)hipStreamDestroy(e->s_in);
     }
+    if (e->cs[1] && e->cs[1] != e->s_compute) {
+        (void)hipStreamDestroy(e->cs[1]);
+    }
+    e->cs[0] = e->cs[1] = e->s_last = nullptr;
+    for (int i = 0; i < kMaxInBufs; i++) {
+        if (e->tail_done[i]) {
+            (void)hipEventDestroy(e->tail_done[i]);
+            e->tail_done[i] = nullptr;
+        }
+        e->tail_pending[i] = false;
+    }
     if (e->s_compute) {
         (void)hipStreamDestroy(e->s_compute);
     }
@@ -482,7 +527,7 @@ uint64_t input_capacity(uint32_t max_block, uint32_t coalesce, uint32_t nr_taps)
      * real sample must still be readable in place: decimations that are not multiples of 4 start their chunks at any
      * sample), rounded to 64 samples.  A coalescing engine launches once coalesce_samples have gathered: fewer than that
      * plus one more block of any size always fit. */
-    return ((uint64_t)max_block + coalesce + nr_taps + 4u + 63u) & ~63ull;
+    return ((uint64_t)max_block + coalesce + 2ull * nr_taps + 4u + 63u) & ~63ull; /* 2 x: history tail + mfm_engine::hist (<= taps) */
 }
 
 int write_state_fresh(mfm_engine *e)
@@ -1138,6 +1183,15 @@ static int commit_locked(struct mfm_engine *e)
     e->committed = true; /* from here free_device() releases whatever was allocated */
     HIP_TRY(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->s_compute, hipStreamNonBlocking));
+    e->cs[0] = e->cs[1] = e->s_last = e->s_compute;
+    e->ncs = 1;
+    if ((e->cfg.flags & MFM_F_OVERLAP) && e->use_v3) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->cs[1], hipStreamNonBlocking));
+        e->ncs = 2;
+        for (int i = 0; i < kMaxInBufs; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&e->tail_done[i], hipEventDisableTiming));
+        }
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->s_out, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&e->in_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->kernel_done, hipEventDisableTiming));
@@ -1245,7 +1299,7 @@ int buffer_format(const mfm_engine *e)
     if (e->pend) {
         return e->in_fmt[e->cur_in];
     }
-    return e->tail ? e->tail_fmt : -1;
+    return (e->hist + e->tail) ? e->tail_fmt : -1;
 }
 
 bool event_done(hipEvent_t ev)
@@ -1318,6 +1372,10 @@ int launch_locked(mfm_engine *e)
     const uint32_t n_new = n_avail >= T ? (n_avail - T) / D + 1 : 0;
     const int fmt = e->in_fmt[cur];
     const bool raw8 = fmt != MFM_IN_CS16;
+    /* the stream of this launch, and of the one after it (the same one unless MFM_F_OVERLAP alternates them): what the
+     * next launch needs from this buffer - the carry - is queued there */
+    hipStream_t S = e->cs[e->launches & (e->ncs - 1u)];
+    hipStream_t S_after = n_new ? e->cs[(e->launches + 1u) & (e->ncs - 1u)] : S;
 
     OutSlot *slot = nullptr;
     int slot_idx = -1;
@@ -1360,7 +1418,7 @@ int launch_locked(mfm_engine *e)
 
         if (!dev_only) {
             /* the previous D2H out of this slot must have drained before the kernel rewrites it */
-            HIP_TRY(hipStreamWaitEvent(e->s_compute, slot->ready, 0));
+            HIP_TRY(hipStreamWaitEvent(S, slot->ready, 0));
         }
         /* MFM_F_TIMING_SPARSE: every fourth launch carries the event pair.  An event record is a packet the command
          * processor handles between two kernels (~4 us each on MI355X): bracketing every launch of a back-to-back
@@ -1374,7 +1432,7 @@ int launch_locked(mfm_engine *e)
                 return rc;
             }
             ti = (int)(e->t_head % kTimingPairs);
-            HIP_TRY(hipEventRecord(e->t0[ti], e->s_compute));
+            HIP_TRY(hipEventRecord(e->t0[ti], S));
         }
         if (e->use_v3) {
             mfm_launch_v3 V{};
@@ -1382,6 +1440,8 @@ int launch_locked(mfm_engine *e)
             V.x = e->d_in[cur];
             V.n_avail = n_avail;
             V.n_new = n_new;
+            V.hist = e->hist;
+            V.k_base = e->outputs;
             V.ntiles = (n_new + MFM_V3_OT - 1u) / MFM_V3_OT;
             /* chunks of consecutive tiles, `rounds` per workgroup slot and slice, lengths equal to within one tile
              * (a chunk pays one extra column group) */
@@ -1391,19 +1451,22 @@ int launch_locked(mfm_engine *e)
             V.nchunks = std::min(V.ntiles, per_slice);
             V.cl = (V.ntiles + V.nchunks - 1u) / V.nchunks;
             V.nitems = ((V.nchunks + 7u) / 8u) * 8u * V.nslices;
-            V.tail_src = n_new * D;
-            V.tail_n = n_avail - n_new * D;
+            /* the next launch's [hist | history tail]: the last consumed row and what was not consumed */
+            V.tail_src = e->hist + n_new * D - D;
+            V.tail_n = D + n_avail - n_new * D;
             V.tail_dst = e->d_in[nxt];
             tail_in_kernel = true;
-            V.st_in = L.st_in;
-            V.st_out = L.st_out;
+            if (e->ncs > 1u) {
+                V.tail_n = 0; /* the next launch must not wait for this kernel: the carry is copied on its own stream below */
+                tail_in_kernel = false;
+            }
             V.pcm = slot->d_pcm;
             V.iq_dbg = L.iq_dbg;
             if (raw8) {
                 e->launches_8bit++;
             }
             const uint32_t grid = std::min(V.nitems, slots);
-            HIP_TRY(mfm_launch_channel_kernel_v3(e->kfn[fmt], &V, e->v_lds_bytes, grid, e->s_compute));
+            HIP_TRY(mfm_launch_channel_kernel_v3(e->kfn[fmt], &V, e->v_lds_bytes, grid, S));
             L.ntiles = grid; /* for grid_last below */
             L.nslices = 1;
         } else if (e->use_mfma) {
@@ -1426,14 +1489,14 @@ int launch_locked(mfm_engine *e)
                 e->launches_8bit++;
             }
             const uint32_t grid = std::min(M.nitems, 256u * e->m_wg_fmt[fmt]);
-            HIP_TRY(mfm_launch_channel_kernel_mfma(e->kfn[fmt], &M, e->m_lds_bytes, grid, e->s_compute));
+            HIP_TRY(mfm_launch_channel_kernel_mfma(e->kfn[fmt], &M, e->m_lds_bytes, grid, S));
             L.ntiles = grid; /* for grid_last below */
             L.nslices = 1;
         } else {
-            HIP_TRY(mfm_launch_channel_kernel(e->kfn[MFM_IN_CS16], &L, e->lds_bytes, e->s_compute));
+            HIP_TRY(mfm_launch_channel_kernel(e->kfn[MFM_IN_CS16], &L, e->lds_bytes, S));
         }
         if (timing) {
-            HIP_TRY(hipEventRecord(e->t1[ti], e->s_compute));
+            HIP_TRY(hipEventRecord(e->t1[ti], S));
             timing_end = e->t1[ti];
             e->t_head++;
         }
@@ -1442,13 +1505,25 @@ int launch_locked(mfm_engine *e)
         e->grid_last = e->use_mfma ? L.ntiles : ((L.ntiles + 7) / 8) * 8 * L.nslices;
     }
 
-    /* carry the unconsumed tail to the front of the next staging buffer (the MFMA kernels have done it themselves) */
+    /* carry the unconsumed tail (and, for the second-generation kernel, the last consumed row in front of it) to the front
+     * of the next staging buffer (the MFMA kernels have done it themselves) */
     const uint32_t consumed = n_new * D;
     const uint32_t new_tail = n_avail - consumed;
-    if (new_tail && !tail_in_kernel) {
+    const uint32_t new_hist = (e->use_v3 && n_new) ? D : e->hist;
+    if (new_hist + new_tail && !tail_in_kernel) {
         const size_t ss = raw8 ? 2 : 4;
-        HIP_TRY(hipMemcpyAsync(e->d_in[nxt], reinterpret_cast<const uint8_t *>(e->d_in[cur]) + (size_t)consumed * ss,
-                               (size_t)new_tail * ss, hipMemcpyDeviceToDevice, e->s_compute));
+        if (e->ncs > 1u && e->in_free_wait[nxt]) {
+            /* the launch that last read the next buffer may be on the other stream */
+            HIP_TRY(hipStreamWaitEvent(S_after, e->in_free_wait[nxt], 0));
+        }
+        HIP_TRY(hipMemcpyAsync(e->d_in[nxt],
+                               reinterpret_cast<const uint8_t *>(e->d_in[cur]) + ((size_t)e->hist + consumed - new_hist) * ss,
+                               ((size_t)new_hist + new_tail) * ss, hipMemcpyDeviceToDevice, S_after));
+        if (e->ncs > 1u) {
+            /* this buffer is free once its kernel AND this copy are through (acquire_input waits for both) */
+            HIP_TRY(hipEventRecord(e->tail_done[cur], S_after));
+            e->tail_pending[cur] = true;
+        }
     }
     /* Every event record is a packet the command processor handles between two kernels (about 4 us each on
      * MI355X).  When the kernel carried the tail itself and its end is already stamped by the timing event, that
@@ -1456,7 +1531,7 @@ int launch_locked(mfm_engine *e)
     if (tail_in_kernel && timing_end) {
         e->in_free_wait[cur] = timing_end;
     } else {
-        HIP_TRY(hipEventRecord(e->in_free[cur], e->s_compute));
+        HIP_TRY(hipEventRecord(e->in_free[cur], S));
         e->in_free_wait[cur] = e->in_free[cur];
     }
 
@@ -1466,7 +1541,7 @@ int launch_locked(mfm_engine *e)
         if (dev_only) {
             /* nothing waits on slot->ready in device-only mode: consumers are ordered by the stream */
         } else {
-            HIP_TRY(hipEventRecord(e->kernel_done, e->s_compute));
+            HIP_TRY(hipEventRecord(e->kernel_done, S));
             HIP_TRY(hipStreamWaitEvent(e->s_out, e->kernel_done, 0));
             const size_t row = (size_t)e->out_stride * sizeof(int16_t);
             HIP_TRY(hipMemcpy2DAsync(slot->h_pcm, row, slot->d_pcm, row, (size_t)n_new * sizeof(int16_t), C,
@@ -1479,6 +1554,7 @@ int launch_locked(mfm_engine *e)
             slot->state = OutSlot::INFLIGHT;
         }
         e->last_slot = slot_idx;
+        e->s_last = S;
         e->submit_seq++;
         e->outputs += n_new;
     }
@@ -1486,6 +1562,8 @@ int launch_locked(mfm_engine *e)
     e->last_launch_samples = n_avail;
     e->last_launch_buf = cur;
     e->last_launch_fmt = fmt;
+    e->last_launch_hist = e->hist;
+    e->hist = new_hist;
     e->tail = new_tail;
     e->tail_fmt = fmt;
     e->in_fmt[cur] = MFM_IN_CS16;
@@ -1527,12 +1605,16 @@ int mfm_engine_acquire_input(struct mfm_engine *e, void **d_dst, size_t *capacit
         HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
         e->in_free_wait[e->cur_in] = nullptr; /* waited for: later blocks of this buffer need not ask again */
     }
+    if (e->tail_pending[e->cur_in]) {
+        HIP_TRY(hipEventSynchronize(e->tail_done[e->cur_in]));
+        e->tail_pending[e->cur_in] = false;
+    }
     if (0 == e->pend) {
         e->in_fmt[e->cur_in] = MFM_IN_CS16; /* what a device producer writes; mfm_engine_stage() says otherwise for raw bytes */
     }
-    *d_dst = e->d_in[e->cur_in] + e->tail + e->pend;
+    *d_dst = e->d_in[e->cur_in] + e->hist + e->tail + e->pend;
     if (capacity_samples) {
-        *capacity_samples = std::min<size_t>(e->cap_in - e->tail - e->pend, e->cfg.max_block_samples);
+        *capacity_samples = std::min<size_t>(e->cap_in - e->hist - e->tail - e->pend, e->cfg.max_block_samples);
     }
     return MFM_OK;
 }
@@ -1574,10 +1656,14 @@ int mfm_engine_acquire_input_bytes(struct mfm_engine *e, int format, void **d_ds
         HIP_TRY(hipEventSynchronize(e->in_free_wait[e->cur_in]));
         e->in_free_wait[e->cur_in] = nullptr;
     }
+    if (e->tail_pending[e->cur_in]) {
+        HIP_TRY(hipEventSynchronize(e->tail_done[e->cur_in]));
+        e->tail_pending[e->cur_in] = false;
+    }
     e->in_fmt[e->cur_in] = format;
-    *d_dst = reinterpret_cast<uint8_t *>(e->d_in[e->cur_in]) + ((size_t)e->tail + e->pend) * 2;
+    *d_dst = reinterpret_cast<uint8_t *>(e->d_in[e->cur_in]) + ((size_t)e->hist + e->tail + e->pend) * 2;
     if (capacity_samples) {
-        *capacity_samples = std::min<size_t>(e->cap_in - e->tail - e->pend, e->cfg.max_block_samples); /* the block limit is that of int16 blocks */
+        *capacity_samples = std::min<size_t>(e->cap_in - e->hist - e->tail - e->pend, e->cfg.max_block_samples); /* the block limit is that of int16 blocks */
     }
     return MFM_OK;
 }
@@ -1596,7 +1682,7 @@ int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *produc
         /* receiver_sample_buf_deliver() treats an empty buffer as a bug (receiver.c:84) */
         return fail(MFM_E_INVAL, "empty block");
     }
-    if (nr_samples > (size_t)e->cap_in - e->tail - e->pend || nr_samples > e->cfg.max_block_samples) {
+    if (nr_samples > (size_t)e->cap_in - e->hist - e->tail - e->pend || nr_samples > e->cfg.max_block_samples) {
         return fail(MFM_E_INVAL, "block of %zu samples exceeds max_block_samples %u", nr_samples,
                     e->cfg.max_block_samples);
     }
@@ -1623,15 +1709,19 @@ int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *produc
 
     if (wait_producer) {
         HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
-        HIP_TRY(hipStreamWaitEvent(e->s_compute, e->in_ready, 0));
+        for (uint32_t i = 0; i < e->ncs; i++) {
+            HIP_TRY(hipStreamWaitEvent(e->cs[i], e->in_ready, 0)); /* the launch on one, the carry out of it on the other */
+        }
     }
 
-    if (!raw8 && 0 == e->pend && e->tail && e->tail_fmt != MFM_IN_CS16) {
+    if (!raw8 && 0 == e->pend && (e->hist + e->tail) && e->tail_fmt != MFM_IN_CS16) {
         /* the history at the front of this buffer is bytes, the block behind it int16: widen it where it stands (the
          * kernel that wrote it is ahead of this on the compute stream; the block's own samples start 4 * tail bytes in) */
-        HIP_TRY(hipMemcpyAsync(e->d_tailtmp, e->d_in[cur], (size_t)e->tail * 2, hipMemcpyDeviceToDevice, e->s_compute));
-        hipLaunchKernelGGL(mfm_unpack_kernel, dim3((e->tail / 8u + 256u) / 256u), dim3(256), 0, e->s_compute, e->d_tailtmp,
-                           e->d_in[cur], e->tail, e->tail_fmt, 0);
+        const uint32_t nh = e->hist + e->tail;
+        hipStream_t Sn = e->cs[e->launches & (e->ncs - 1u)]; /* the stream of this buffer's launch: the carry was queued there */
+        HIP_TRY(hipMemcpyAsync(e->d_tailtmp, e->d_in[cur], (size_t)nh * 2, hipMemcpyDeviceToDevice, Sn));
+        hipLaunchKernelGGL(mfm_unpack_kernel, dim3((nh / 8u + 256u) / 256u), dim3(256), 0, Sn, e->d_tailtmp,
+                           e->d_in[cur], nh, e->tail_fmt, 0);
         HIP_TRY(hipGetLastError());
         e->tail_fmt = MFM_IN_CS16;
     }
@@ -1804,7 +1894,9 @@ int mfm_engine_last_launch_input(struct mfm_engine *e, void **d_in, size_t *nr_s
         return fail(MFM_E_STATE, "no launch yet");
     }
     if (d_in) {
-        *d_in = e->d_in[e->last_launch_buf];
+        /* the first sample the launch had not consumed before (the second-generation kernel keeps a row in front of it) */
+        *d_in = reinterpret_cast<uint8_t *>(e->d_in[e->last_launch_buf]) +
+                (size_t)e->last_launch_hist * (e->last_launch_fmt == MFM_IN_CS16 ? 4 : 2);
     }
     if (nr_samples) {
         *nr_samples = e->last_launch_samples;
@@ -1921,6 +2013,9 @@ int mfm_engine_sync(struct mfm_engine *e)
     }
     HIP_TRY(hipStreamSynchronize(e->s_in));
     HIP_TRY(hipStreamSynchronize(e->s_compute));
+    if (e->ncs > 1u) {
+        HIP_TRY(hipStreamSynchronize(e->cs[1]));
+    }
     HIP_TRY(hipStreamSynchronize(e->s_out));
     return MFM_OK;
 }
@@ -1946,6 +2041,7 @@ int mfm_engine_reset(struct mfm_engine *e)
     e->fetch_seq = e->submit_seq = 0;
     e->last_slot = -1;
     e->tail = 0;
+    e->hist = 0;
     e->tail_fmt = MFM_IN_CS16;
     e->in_fmt[0] = e->in_fmt[1] = e->in_fmt[2] = MFM_IN_CS16;
     e->cur_in = 0;
@@ -1953,6 +2049,30 @@ int mfm_engine_reset(struct mfm_engine *e)
     e->last_launch_buf = -1;
     e->outputs = 0;
     e->samples_in = 0;
+    return MFM_OK;
+}
+
+int mfm_engine_seek(struct mfm_engine *e, uint64_t outputs_before)
+{
+    int rc = mfm_engine_reset(e);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    /* the rotators stand where outputs_before steps of the recurrence leave them (filter/direct_fir.c:166-167); the
+     * second-generation kernel folds the count itself, the others read the folded table position from the carried state */
+    std::vector<mfm_chan_state> st(e->ngroups * MFM_CG);
+    for (size_t c = 0; c < st.size(); c++) {
+        st[c].carry_q = 0;
+        st[c].kb = 0;
+        if (c < e->chans.size()) {
+            const Channel &ch = e->chans[c];
+            st[c].kb = outputs_before < ch.mu ? (uint32_t)outputs_before : ch.mu + (uint32_t)((outputs_before - ch.mu) % ch.lam);
+        }
+    }
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMemcpy(e->d_state[i], st.data(), st.size() * sizeof(mfm_chan_state), hipMemcpyHostToDevice));
+    }
+    e->outputs = outputs_before;
     return MFM_OK;
 }
 
@@ -2016,7 +2136,7 @@ size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap)
 
 void *mfm_engine_stream(struct mfm_engine *e)
 {
-    return (e && e->committed) ? e->s_compute : nullptr;
+    return (e && e->committed) ? e->s_last : nullptr;
 }
 
 /* ---- host twins (see include/multifm_hip.h) ---- */

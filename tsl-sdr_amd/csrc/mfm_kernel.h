@@ -153,8 +153,16 @@ struct mfm_launch_mfma {
 #define MFM_V3_CH_MAX 8u       /* 16-byte staging chunks per thread and tile, at most */
 
 struct mfm_launch_v3 {
-    const uint32_t *x;
+    const uint32_t *x;    /* the input buffer: [hist samples already consumed | n_avail samples from the first unconsumed one] */
     uint32_t n_avail, n_new, decim;
+    uint32_t hist;        /* 0 at the start of a stream, else the decimation: the D samples in front of the first unconsumed
+                             one, i.e. the first row of the window of the output in front of this launch.  That output is
+                             RECOMPUTED (its filtered sample is the discriminator's history, multifm/fm_demod.c:16-17), so
+                             a launch depends on the launch before it through nothing but input samples */
+    uint32_t pad1;
+    uint64_t k_base;      /* outputs the stream produced before this launch: output n of the launch is rotated by the
+                             (k_base + n)-th state of the recurrence (filter/direct_fir.c:151-172), found by folding that
+                             index into the channel's table - so the rotator position needs no carried state either */
     uint32_t x_last4;
     uint32_t kq;          /* k-steps of 64 elements (1, 2 or 4) */
     uint32_t rs;          /* LDS row stride in bytes, an odd multiple of 32 */
@@ -181,9 +189,10 @@ struct mfm_launch_v3 {
     uint32_t nitems;      /* chunks rounded up to a multiple of 8, times slices */
     uint32_t nchan, out_stride, ah_mask;
     uint32_t rc;          /* the lowest MFM_RC_* of the launch's channels (selects the kernel instance) */
-    uint32_t tail_src, tail_n;
+    uint32_t tail_src, tail_n; /* samples x[tail_src .. tail_src + tail_n) - the next launch's hist + history tail - go to the
+                                  front of tail_dst (workgroup 0 copies them); tail_n = 0: the engine carries them itself */
     uint32_t in8;         /* 0: x is packed int16 IQ.  7 / 14: x is 8-bit IQ off the wire (2 bytes per sample; n_avail,
-                             x_last4, tail_* count samples all the same), the value is the first rounding's shift and
+                             x_last4, hist, tail_* count samples all the same), the value is the first rounding's shift and
                              krow the matching row constants (mfm_kernel_v3.hip) */
     uint32_t in8_xor;     /* 0x80808080 when the bytes are unsigned (RTL-SDR), else 0 */
     uint32_t stream_taps; /* filters of 129..512 taps (kq 8 / 16): 1 = re-read the taps from L2 in every iteration (128-register
@@ -194,8 +203,6 @@ struct mfm_launch_v3 {
     const int32_t *krow;
     const struct mfm_chan_info *info;
     const uint2 *rot;
-    const struct mfm_chan_state *st_in;
-    struct mfm_chan_state *st_out;
     const float2 *lut;
     int16_t *pcm;
     uint32_t *iq_dbg;

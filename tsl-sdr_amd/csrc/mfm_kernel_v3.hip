@@ -156,6 +156,31 @@ static __device__ __forceinline__ uint32_t mfm3_fold(uint32_t kb, uint32_t d, ui
     return k;
 }
 
+/* t mod lam for any 32-bit t, lam_magic = floor(2^32 / lam): the quotient estimate is at most one short */
+static __device__ __forceinline__ uint32_t mfm3_mod_step(uint32_t t, uint32_t lam, uint32_t lam_magic)
+{
+    const uint32_t m = t - __umulhi(t, lam_magic) * lam;
+    return (m >= lam) ? m - lam : m;
+}
+
+/* the same for a 64-bit output index: a stream at the bench's rate passes 2^32 outputs per channel within a second.
+ * k - mu is reduced mod lam (< 2^27: the engine's table limit) five bits at a time, so that everything stays 32-bit. */
+static __device__ __forceinline__ uint32_t mfm3_fold64(uint64_t k, uint32_t mu, uint32_t lam, uint32_t lam_magic)
+{
+    if (k < (uint64_t)mu) {
+        return (uint32_t)k;
+    }
+    const uint64_t x = k - mu;
+    const uint32_t xl = (uint32_t)x;
+    uint32_t a = mfm3_mod_step((uint32_t)(x >> 32), lam, lam_magic);
+#pragma unroll
+    for (int s = 27; s >= 2; s -= 5) {
+        a = mfm3_mod_step((a << 5) | ((xl >> s) & 31u), lam, lam_magic);
+    }
+    a = mfm3_mod_step((a << 2) | (xl & 3u), lam, lam_magic);
+    return mu + a;
+}
+
 /*
  * Four discriminators (multifm/fm_demod.c:68-72 on fast_atan2f.c:101-174), same operations in the same order as
  * mfm_discriminate() in mfm_numerics.h (the form the host twin proves against the oracle), written for the issue
@@ -599,12 +624,13 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     const uint32_t lb0 = chunk_rows ? 16u * n + 16u * t_pitch * kg : n * rs + 16u * kg;
 
     auto stage_load = [&](uint32_t tile, int j) -> uint4 {
-        /* 4 samples of the image of `tile`, which starts LEAD rows in front of the tile's first output.  Only a
-         * readable address is needed: samples before the stream start feed nothing but the recomputed output of
-         * tile 0 (replaced by the carried sample), samples past n_avail only outputs >= n_new (never stored) or
-         * zero-padded taps.  Chunks past the image all read the tile's first line (one cache line per wave). */
+        /* 4 samples of the image of `tile`, which starts LEAD rows in front of the tile's first output (the first
+         * unconsumed sample sits L.hist samples into the buffer).  Only a readable address is needed: samples before
+         * the buffer feed nothing but outputs in front of the recomputed one (and, at the start of a stream, that one:
+         * replaced by the zero history), samples past n_avail only outputs >= n_new (never stored) or zero-padded
+         * taps.  Chunks past the image all read the tile's first line (one cache line per wave). */
         const uint32_t q = tid + (uint32_t)j * MFM3_NT;
-        int gs = (int)(tile * MFM_V3_OT * D) - (int)(MFM_V3_LEAD * D) + (IN8 ? 8 : 4) * (int)(q < L.nstage4 ? q : 0u);
+        int gs = (int)(tile * MFM_V3_OT * D + L.hist) - (int)(MFM_V3_LEAD * D) + (IN8 ? 8 : 4) * (int)(q < L.nstage4 ? q : 0u);
         gs = gs < 0 ? 0 : gs;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
         return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << (IN8 ? 1 : 2)));
@@ -896,9 +922,11 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chs * 8;
                     const uint4 inf = *reinterpret_cast<const uint4 *>(ip);
                     const uint32_t lam_magic = ip[4];
-                    const uint32_t kb = L.st_in[chs].kb;
                     const uint32_t mu = inf.z, lam = inf.w;
-                    const uint32_t k0 = mfm3_fold(kb, first_out, mu, lam, lam_magic);
+                    /* where output k_base + first_out stands in the channel's rotator table (wave uniform which way) */
+                    const uint64_t kabs = L.k_base + first_out;
+                    const uint32_t k0 = (kabs >> 32) == 0 ? mfm3_fold((uint32_t)kabs, 0u, mu, lam, lam_magic)
+                                                          : mfm3_fold64(kabs, mu, lam, lam_magic);
                     kbg[c] = (inf.x + k0 + 4u * n) * 8u;
                     fog[c] = make_uint2((inf.x + mu + lam) * 8u, lam * 8u);
                     /* an exact rotator: (16384, 0) for ever, or alternating with (-16384, 0) - then table position k holds
@@ -917,13 +945,13 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     selq[c] = (mq & 1u) ? 0x01000302u : 0x03020100u;
                     sgq[c] = mq == 0u ? 0x00010001u : mq == 1u ? 0x0001ffffu : mq == 2u ? 0xffffffffu : 0xffff0001u;
                     voff[c] = (ip[6] * L.out_stride + first_out + 4u * n) * 2u; /* ip[6]: the row this channel's output goes to */
-                    if (first_out == 0) {
-                        hist[c] = L.st_in[chs].carry_q; /* multifm/fm_demod.c:16-17: last sample of the previous pass */
+                    if (first_out == 0 && L.hist == 0) {
+                        hist[c] = 0; /* nothing in front: multifm/fm_demod.c:16-17,29, the last sample starts at zero */
                         wrx[c] = wry[c] = 0;
                     } else {
-                        /* rotator entry of output first_out - 1 (folded on its own: the entry in front of a period is
-                         * not the period's last one) */
-                        const uint32_t kw = mfm3_fold(kb, first_out - 1u, mu, lam, lam_magic);
+                        /* rotator entry of the output in front (the entry in front of a period is not the period's last
+                         * one: position mu is reached from mu - 1 the first time and from mu + lam - 1 ever after) */
+                        const uint32_t kw = (k0 != mu || kabs == (uint64_t)mu) ? k0 - 1u : mu + lam - 1u;
                         const uint2 e = L.rot[inf.x + kw];
                         wrx[c] = e.x;
                         wry[c] = e.y;
@@ -957,9 +985,10 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         }
                     }
                 }
-                if (first_out != 0) {
+                if (first_out != 0 || L.hist != 0) {
                     /* column group 3 one sub-plane row down: lane n computes output first_out - 4 + 4n + 3; n = 0 is
-                     * the output in front of the chunk */
+                     * the output in front of the chunk - for the first chunk of a launch the last output of the launch
+                     * before, from the L.hist samples kept in front of the first unconsumed one */
                     uint32_t fw[2], qw[2];
                     uint32_t ow[KQ];
 #pragma unroll
@@ -1200,30 +1229,8 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (n_left <= MFM_V3_OT) {
-                /* this tile holds output n_new - 1: the sample the next pass starts from */
-                const uint32_t last = n_left - 1u;
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        if (ch_ok[c] && 4u * n + (uint32_t)g == last) {
-                            L.st_out[ch0 + c].carry_q = q[g][c];
-                        }
-                    }
-                }
-            }
-            if (first_out == 0 && n == 0) {
-                /* rotator position of the next pass's first output, one lane per channel pair */
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    if (ch_ok[c]) {
-                        const uint32_t chn = ch0 + c;
-                        const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chn * 8;
-                        L.st_out[chn].kb = mfm3_fold(L.st_in[chn].kb, L.n_new, ip[2], ip[3], ip[4]);
-                    }
-                }
-            }
+            /* nothing is carried to the next launch: it recomputes the output in front of it and folds its own
+             * rotator position (mfm_launch_v3::hist, ::k_base) */
             /* next tile of the chunk: 64 outputs on */
 #pragma unroll
             for (int c = 0; c < 2; c++) {
