@@ -51,9 +51,11 @@ def parse():
                          "MFM_F_FORCE_* flags (A/B timing)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
+    ap.add_argument("--overlap", action="store_true", help="MFM_F_OVERLAP: consecutive launches on two compute streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the float32-IQ comparison line")
     ap.add_argument("--no-chain", action="store_true", help="skip the device-resident FLEX chain line")
+    ap.add_argument("--no-series", action="store_true", help="skip the block-size series and the host-fed end-to-end line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
@@ -177,11 +179,31 @@ def cpu_baseline(pkg, fs, decim, taps, offs, gains, target_s):
         dt = time.perf_counter() - t0
         if dt >= target_s:
             break
-    return {"value": passes * n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
-            "host_cores": cores, "host_cpu": _cpu_model(),
-            "msamp_per_s_one_channel_one_core": one_core,
-            "sample": f"{passes} passes over {n} IQ samples x {nch} channels, {how}, {threads} threads "
-                      f"thread-per-channel, {dt:.1f} s"}
+    out = {"value": passes * n * nch / dt / 1e6, "unit": "MSamp/s x channels", "cores": threads, "kind": "port",
+           "host_cores": cores, "host_cpu": _cpu_model(),
+           "msamp_per_s_one_channel_one_core": one_core,
+           "sample": f"{passes} passes over {n} IQ samples x {nch} channels, {how}, {threads} threads "
+                     f"thread-per-channel, {dt:.1f} s"}
+    if cores > nch:
+        # SURVEY.md 8(d)(ii) asks for all cores; thread-per-channel cannot use more threads than channels, so the all-cores
+        # figure is taken on a plan with at least as many channels as the host has cores (same filter, same decimation)
+        nch2 = max(256, cores)
+        fs2, decim2, taps2, offs2, gains2 = pkg.synth.plan("cfg3_1024ch", nr_channels=nch2)
+        cre2 = np.ascontiguousarray(np.stack([ora.make_taps(taps2, int(o), fs2, float(g))[0] for o, g in zip(offs2, gains2)]), np.int16)
+        cim2 = np.ascontiguousarray(np.stack([ora.make_taps(taps2, int(o), fs2, float(g))[1] for o, g in zip(offs2, gains2)]), np.int16)
+        incr2 = np.ascontiguousarray(np.stack([ora.rot_incr(int(o), fs2, decim2) for o in offs2]), np.int16)
+        n2 = max(n_cal, n // 4)
+        run(big[:n2], cre2, cim2, incr2, decim2, cores)
+        p2, t0 = 0, time.perf_counter()
+        while True:
+            run(big[:n2], cre2, cim2, incr2, decim2, cores)
+            p2 += 1
+            dt2 = time.perf_counter() - t0
+            if dt2 >= target_s / 2:
+                break
+        out["all_cores"] = {"value": p2 * n2 * nch2 / dt2 / 1e6, "unit": "MSamp/s x channels", "cores": cores, "channels": nch2,
+                            "sample": f"{p2} passes over {n2} IQ samples x {nch2} channels (cfg3_1024ch plan), {cores} threads, {dt2:.1f} s"}
+    return out
 
 
 def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
@@ -284,9 +306,10 @@ def other_geometries(pkg, torch, block, steps=24, settle_s=0.25):
 def block_series(pkg, torch, fs, decim, taps, offs, gains, total_log2=33, settle_s=0.3):
     """SURVEY.md 8(d)'s protocol - blocks of 2^20 samples (4 MiB; >= 64 per timing), and 2^22 and 2^26 beside them - resident in
     HBM and handed to the engine ONE BY ONE by a C producer loop (mfm_engine_replay: acquire_input + submit per block, what
-    a C host does per delivered sample_buf).  Two engines per block size: `coalesced` gathers the backlog into launches of up
+    a C host does per delivered sample_buf).  Engines per block size: `coalesced` gathers the backlog into launches of up
     to 2^26 samples (mfm_engine_config::coalesce_samples; a channel thread of the reference drains up to 128 queued
-    buffers in one go, multifm/demod.c:134-150,297), `per_block` launches every block on its own (coalesce_samples = 0).
+    buffers in one go, multifm/demod.c:134-150,297), `per_block` launches every block on its own (coalesce_samples = 0);
+    both with consecutive launches on two streams (MFM_F_OVERLAP), and `_one_stream` without.
     Wall time around the loop + sync; frac = SURVEY 8(d)'s algorithmic bytes / that time / 8 TB/s.  Outside the timed region,
     never part of `value`."""
     b = pkg.binding
@@ -296,9 +319,10 @@ def block_series(pkg, torch, fs, decim, taps, offs, gains, total_log2=33, settle
     for blog in (20, 22, 26):
         block = 1 << blog
         row = {"block_samples": block, "blocks": (1 << total_log2) // block}
-        for mode, co in (("coalesced", 1 << 26), ("per_block", 0)):
+        for mode, co, fl in (("coalesced", 1 << 26, b.MFM_F_OVERLAP), ("per_block", 0, b.MFM_F_OVERLAP),
+                             ("coalesced_one_stream", 1 << 26, 0), ("per_block_one_stream", 0, 0)):
             try:
-                eng = pkg.Engine(fs, decim, block, device=torch.cuda.current_device(), flags=b.MFM_F_DEVICE_ONLY,
+                eng = pkg.Engine(fs, decim, block, device=torch.cuda.current_device(), flags=b.MFM_F_DEVICE_ONLY | fl,
                                  coalesce_samples=co)
                 for o, g in zip(offs, gains):
                     eng.add_channel(int(o), taps, float(g))
@@ -357,6 +381,75 @@ def _as_tensor(torch, ptr, n_int16):
     holder = _Ext()
     holder.__cuda_array_interface__ = {"shape": (n_int16,), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(holder, device="cuda")
+
+
+def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=4096):
+    """"a second end-to-end number includes H2D from pinned host memory".  What multifm_amd does per delivered
+    sample_buf, in the size the RTL-SDR front end delivers (131 072 samples, multifm/rtl_sdr_if.c:46): host buffer ->
+    mfm_group_push (staging in pinned memory, H2D, one device group of one GPU) -> kernel -> PCM mirrored to pinned host
+    memory -> mfm_group_fetch / release, with the group gathering up to a pool's worth of buffers (128, demod.c:297) per
+    launch as the C host configures it.  PCIe inclusive; never `value`."""
+    b = pkg.binding
+    out = {"buffer_samples": buf_samples, "buffers": nr_bufs,
+           "path": "host buffer -> mfm_group_push -> H2D -> kernel -> D2H -> mfm_group_fetch/release"}
+    nch = len(offs)
+    data = pkg.synth.synth_iq(buf_samples * 8, fs, offs[:: max(1, nch // 8)][:8], seed=7).reshape(8, -1, 2)
+    for mode, co in (("coalesced_128_buffers", 128 * buf_samples), ("launch_per_buffer", 0)):
+        try:
+            grp = b.Group(fs, decim, buf_samples, devices=(0,), coalesce_samples=co)
+            for o, g in zip(offs, gains):
+                grp.add_channel(int(o), taps, float(g))
+            grp.commit()
+            blks = (b.Block * 1)()
+            lib = grp.lib
+
+            def drain_one():
+                rc = lib.mfm_group_fetch(grp.h, blks)
+                if rc == b.MFM_E_DONE:
+                    return 0
+                if rc != 0:
+                    raise RuntimeError(f"mfm_group_fetch: {rc}")
+                n = blks[0].nr_outputs
+                lib.mfm_group_release(grp.h)
+                return n
+
+            def run(nbuf):
+                outs = 0
+                for i in range(nbuf):
+                    while grp.push(data[i & 7]) == b.MFM_E_BUSY:
+                        outs += drain_one()
+                while True:
+                    rc = grp.flush()
+                    while True:
+                        n = drain_one()
+                        if not n:
+                            break
+                        outs += n
+                    if rc == 0:
+                        break
+                grp.sync()
+                while True:
+                    n = drain_one()
+                    if not n:
+                        break
+                    outs += n
+                return outs
+
+            run(max(64, nr_bufs // 8))
+            st0 = grp.stats(0)
+            t0 = time.perf_counter()
+            outs = run(nr_bufs)
+            dt = time.perf_counter() - t0
+            st1 = grp.stats(0)
+            grp.close()
+            n_in = nr_bufs * buf_samples
+            out[mode] = {"launches": st1["launches"] - st0["launches"], "input_msamp_per_s": n_in / dt / 1e6,
+                         "value": n_in * nch / dt / 1e6, "unit": "MSamp/s x channels", "us_per_buffer": dt / nr_bufs * 1e6,
+                         "h2d_GBps": n_in * 4 / dt / 1e9, "d2h_GBps": outs * nch * 2 / dt / 1e9,
+                         "outputs_per_channel": int(outs)}
+        except Exception as e:  # a side line must never take the headline down
+            out[mode] = {"error": repr(e)}
+    return out
 
 
 def ingest_8bit(pkg, fs, decim, taps, offs, gains, block, int16_kernel_ms, steps=6, warmup=2):
@@ -424,8 +517,23 @@ def fp32_path(pkg, torch, fs, decim, taps, offs, gains, int16_kernel_ms, int16_b
             "tolerance": "1e-5 rel vs fp64 restatement (tests/test_f32_path.py)"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as CHILDREN of this process (which has not
+    touched a GPU; a process that has must never be replaced by another), hand their output through, exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
@@ -466,6 +574,7 @@ def main():
                      # one launch in four carries the event pair (runs too short to hold a few samples time every launch)
                      flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
                      (pkg.binding.MFM_F_TIMING_SPARSE if args.steps >= 16 else 0) |
+                     (pkg.binding.MFM_F_OVERLAP if args.overlap else 0) |
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
                      (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0) |
                      (pkg.binding.MFM_F_STREAM_TAPS if args.kernel == "mfma1s" else 0),
@@ -607,7 +716,7 @@ def main():
                          "kernel": kname, "kernel_ms": k_ms,
                          "kernel_ms_min": float(per_launch[0]) if len(per_launch) else None,
                          "kernel_ms_median": float(np.median(per_launch)) if len(per_launch) else None,
-                         "kernel_ms_p95": float(np.percentile(per_launch, 95)) if len(per_launch) else None,
+                         "kernel_ms_p95": float(np.percentile(per_launch, 95)) if len(per_launch) >= 20 else None,
                          "bytes_per_launch": bytes_per_launch,
                          # what holds the kernel below the HBM roof (SQ counters in profiles/)
                          "binding": "simd_issue" if mfma else "valu_dot2"},
@@ -640,6 +749,10 @@ def main():
         # reported next to the headline (never part of `value`)
         line["fp32_iq_path"] = fp32_path(pkg, torch, fs, decim, taps, offs, gains, line["roofline"]["kernel_ms"],
                                          block, block_log2=args.block_log2)
+    if rank == 0 and world == 1 and not args.no_series:
+        # SURVEY.md 8(d)'s own protocol (2^20-sample blocks, >= 64 per timing; host-fed end to end), outside the timed region
+        line["block_series"] = block_series(pkg, torch, fs, decim, taps, offs, gains)
+        line["end_to_end"] = end_to_end(pkg, fs, decim, taps, offs, gains)
     if rank == 0 and world == 1 and not args.no_chain and decim == 96:
         line["flex_chain"] = flex_chain(pkg, torch, fs, decim, taps, offs, gains, block)
         if line["roofline"]["kernel"].startswith("mfm_channel_kernel_v3"):

@@ -649,6 +649,11 @@ int16_t mfm_hosttwin_r14(int32_t a);
 void mfm_hosttwin_pcm_range(uint32_t first_bits, uint32_t count, int16_t *out);
 void mfm_hosttwin_atan_table(float tbl[257]);
 int mfm_hosttwin_atan_table_ok(void); /* 1 if the generated table matches the pinned hash */
+/* The discriminator (multifm/fm_demod.c:68-72 on fast_atan2f.c:101-174) exactly as the channel kernel of `variant`
+ * (mfm_stats::kernel_variant: 0, 1, 2) computes it ON THE DEVICE, for caller-supplied products s = q conj(prev): the three
+ * kernels carry three renderings of it (scalar, packed, four at a time), and tests run the hard cases of its division
+ * through each (tools/div_proof.c).  Host arrays in and out; not a compute path. */
+int mfm_devtest_discriminate(int variant, const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *pcm_out, int device);
 /* the device's table-driven BCH(31,21) decode (syndrome bytes -> 1024-entry flip table), on the host */
 int mfm_hosttwin_bch3121_decode(uint32_t *word);
 

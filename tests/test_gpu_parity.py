@@ -796,3 +796,46 @@ def test_full_size_8bit_blocks_bytes_equal_widened(pkg, fmt):
     assert sa["launches_8bit"] == sa["launches"] and sb["launches_8bit"] == 0 and sc["launches_8bit"] == sc["launches"]
     assert a.shape == b.shape == c.shape and a.shape[1] == (n - len(taps)) // decim + 1
     assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_discriminator_division_hard_cases_on_the_device(pkg, ora, tmp_path, variant):
+    """The three renderings of the discriminator (scalar / packed / four at a time: kernel variants 0 / 1 / 2) on the device,
+    through mfm_devtest_discriminate, against the oracle's fm_demod.c:68-72 + fast_atan2f (IEEE division): the quotients
+    tools/div_proof.c finds closest to a rounding boundary (a sample of 2^19 of the 46.5 M, every octant), the three that
+    depend on the exact v_rcp_f32 result, and 2^22 random int32 pairs."""
+    import ctypes as C
+    import subprocess
+    exe, dump = tmp_path / "div_proof", tmp_path / "hard.bin"
+    r = subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), os.path.join(os.path.dirname(__file__), "..", "tools",
+                        "div_proof.c"), "-lm", "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    subprocess.run([str(exe), "1", "8", str(dump), "rn"], capture_output=True, text=True, timeout=600)
+    hard = np.fromfile(dump, dtype=np.uint32).reshape(-1, 2).astype(np.int64)
+    assert hard.shape[0] == 8 << 16
+    crit = np.array([[8388608, 16777215], [13981011, 16777213], [15099490, 16777211]], np.int64)
+    rng = np.random.RandomState(variant)
+    # scale a share of the hard pairs by powers of two (the operands are int32 converted to float: up to 2^31)
+    sh = rng.randint(0, 7, size=hard.shape[0])
+    scaled = hard * (1 << sh)[:, None]
+    pairs = np.concatenate([crit, crit * 64, hard, scaled])
+    re_l, im_l = [], []
+    for o in range(8):
+        x = pairs[:, 1] if o & 1 else pairs[:, 0]
+        y = pairs[:, 0] if o & 1 else pairs[:, 1]
+        re_l.append(-x if o & 2 else x)
+        im_l.append(-y if o & 4 else y)
+    rnd = rng.randint(-2**31, 2**31, size=(2, 1 << 22), dtype=np.int64)
+    s_re = np.ascontiguousarray(np.concatenate(re_l + [rnd[0]]), dtype=np.int32)
+    s_im = np.ascontiguousarray(np.concatenate(im_l + [rnd[1]]), dtype=np.int32)
+    got = np.zeros(s_re.size, np.int16)
+    lib = pkg.load_library()
+    i32p, i16p = C.POINTER(C.c_int32), C.POINTER(C.c_int16)
+    rc = lib.mfm_devtest_discriminate(variant, s_re.ctypes.data_as(i32p), s_im.ctypes.data_as(i32p), s_re.size,
+                                      got.ctypes.data_as(i16p), 0)
+    assert rc == 0, lib.mfm_last_error()
+    want = np.zeros(s_re.size, np.int16)
+    ora.lib().mfmo_discriminate_batch(s_re.ctypes.data_as(i32p), s_im.ctypes.data_as(i32p), s_re.size, want.ctypes.data_as(i16p), 0)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, (bad.size, s_re[bad[:4]], s_im[bad[:4]], got[bad[:4]], want[bad[:4]])

@@ -122,3 +122,26 @@ def test_byte_plane_sums_of_8bit_input_equal_the_widened_sums(ora):
             assert kk * alpha == beta * sw + 8192
             t = ((int((wh * s).sum()) << 8) + int((wl * s).sum()) + kk) & 0xFFFFFFFF
             assert (t >> sh) & 0xFFFF == want, (fmt, trial)
+
+
+def test_division_with_one_residual_step_enumerated(tmp_path):
+    """mfm_div_unit (tsl-sdr_amd/csrc/mfm_numerics.h): reciprocal, one Newton step, quotient estimate, ONE residual step.
+    tools/div_proof.c enumerates every pair of significands whose quotient lies close enough to a midpoint of two floats for
+    the final rounding to go wrong (46.5 M pairs over all 2^23 divisors) and runs the float sequence on each: with the
+    correctly rounded reciprocal none goes wrong (Markstein's theorem, by enumeration); with reciprocals up to two ulp off
+    exactly three pairs do - the ones the engine's division self-test runs on the device at commit."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "div_proof"
+    r = subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), os.path.join(ROOT, "tools", "div_proof.c"), "-lm",
+                        "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), "1", "8", "-", "rn"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 wrong; 5e7 random pairs: 0 wrong" in r.stdout, r.stdout[-500:]
+    r = subprocess.run([str(exe), "1", "8"], capture_output=True, text=True, timeout=600)
+    bad = sorted(set(tuple(int(t.split("=")[1]) for t in ln.split()[1:3]) for ln in r.stdout.splitlines() if ln.startswith("FAIL")))
+    assert bad == [(8388608, 16777215), (13981011, 16777213), (15099490, 16777211)], r.stdout[-800:]
+    src = open(os.path.join(ROOT, "tsl-sdr_amd", "csrc", "mfm_engine.hip")).read()
+    for a, b in bad:
+        assert "{ %d, %d }" % (a, b) in src, "the commit-time division self-test must run this quotient"

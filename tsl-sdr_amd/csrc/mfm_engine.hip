@@ -35,6 +35,9 @@ extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, i
                                                      uint32_t *waves_per_simd_out);
 extern "C" hipError_t mfm_launch_channel_kernel_mfma(const void *kfn, const mfm_launch_mfma *L, uint32_t lds_bytes,
                                                      uint32_t grid, hipStream_t stream);
+extern "C" hipError_t mfm_disc_test_dot2(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream);
+extern "C" hipError_t mfm_disc_test_mfma(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream);
+extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream);
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out);
 extern "C" hipError_t mfm_launch_channel_kernel_v3(const void *kfn, const mfm_launch_v3 *L, uint32_t lds_bytes, uint32_t grid,
                                                    hipStream_t stream);
@@ -230,6 +233,7 @@ struct mfm_engine {
      * the workgroup slots launch k's shorter chunks free up instead of waiting for its last tile - and for a dispatch. */
     hipStream_t cs[2] = { nullptr, nullptr };
     uint32_t ncs = 1;
+    uint32_t si = 0;              /* index into cs of the next launch */
     hipStream_t s_last = nullptr; /* the stream the most recent launch went to (mfm_engine_stream) */
     hipEvent_t tail_done[kMaxInBufs] = { nullptr, nullptr, nullptr }; /* overlap: the carry out of buffer i has been copied */
     bool tail_pending[kMaxInBufs] = { false, false, false };
@@ -350,6 +354,51 @@ int raise_lds_limit(int device, const void *fn, uint32_t lds)
         have = lds;
     }
     return MFM_OK;
+}
+
+/*
+ * The discriminator's division (mfm_numerics.h, mfm_div_unit) is correctly rounded with the reciprocals gfx950's
+ * v_rcp_f32 returns - shown for all operands by tools/div_proof.c on the table tools/rcp_check.hip reads off the device.  It
+ * would NOT be for every reciprocal within one ulp: 8388608 / 16777215 needs the correctly rounded reciprocal of
+ * 2^24 - 1, 13981011 / 16777213 and 15099490 / 16777211 a reciprocal that is not too high.  Once per process and device
+ * the engine therefore runs exactly those quotients (all octants, the kernel variant in use) through the device's
+ * discriminator and compares with the host twin's IEEE division: a device that answers differently is refused at
+ * commit instead of producing PCM that is one LSB off once in 10^7 samples.
+ */
+int division_selftest(int device, int variant)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> done;
+    std::lock_guard<std::mutex> guard(mu);
+    auto it = done.find(std::make_pair(device, variant));
+    if (it != done.end()) {
+        return it->second == MFM_OK ? MFM_OK : fail(it->second, "the division self-test failed on device %d before", device);
+    }
+    static const int32_t pairs[][2] = { { 8388608, 16777215 }, { 13981011, 16777213 }, { 15099490, 16777211 },
+                                        { 8388607, 16777215 }, { 12582912, 16777215 }, { 1, 3 }, { 16777215, 16777215 },
+                                        { 5, 2147483647 }, { 1073741823, 2147483646 } };
+    std::vector<int32_t> re, im;
+    for (const auto &p : pairs) {
+        for (int o = 0; o < 8; o++) {
+            const int32_t x = (o & 1) ? p[0] : p[1], y = (o & 1) ? p[1] : p[0];
+            re.push_back((o & 2) ? -x : x);
+            im.push_back((o & 4) ? -y : y);
+        }
+    }
+    std::vector<int16_t> got(re.size());
+    int rc = mfm_devtest_discriminate(variant, re.data(), im.data(), re.size(), got.data(), device);
+    if (rc == MFM_OK) {
+        for (size_t i = 0; i < re.size(); i++) {
+            const int16_t want = (int16_t)mfm_hosttwin_discriminate(re[i], im[i]);
+            if (got[i] != want) {
+                rc = fail(MFM_E_DEVICE, "division self-test: discriminator(%d, %d) = %d on device %d, %d by IEEE division - this "
+                                        "device's v_rcp_f32 differs from gfx950's (tools/div_proof.c)", re[i], im[i], got[i], device, want);
+                break;
+            }
+        }
+    }
+    done[std::make_pair(device, variant)] = rc;
+    return rc;
 }
 
 /* which instance runs blocks of each input format; its LDS limit is raised here, once (commit, on the engine's device) */
@@ -1278,7 +1327,10 @@ static int commit_locked(struct mfm_engine *e)
         }
     }
     {
-        const int rc = select_kernels(e);
+        int rc = select_kernels(e);
+        if (rc == MFM_OK) {
+            rc = division_selftest(e->cfg.device, e->use_v3 ? 2 : e->use_mfma ? 1 : 0);
+        }
         if (rc != MFM_OK) {
             return rc;
         }
@@ -1374,8 +1426,21 @@ int launch_locked(mfm_engine *e)
     const bool raw8 = fmt != MFM_IN_CS16;
     /* the stream of this launch, and of the one after it (the same one unless MFM_F_OVERLAP alternates them): what the
      * next launch needs from this buffer - the carry - is queued there */
-    hipStream_t S = e->cs[e->launches & (e->ncs - 1u)];
-    hipStream_t S_after = n_new ? e->cs[(e->launches + 1u) & (e->ncs - 1u)] : S;
+    hipStream_t S = e->cs[e->si];
+    /* Two streams pay off when a launch fills the workgroup slots more than once (its ragged end is what the next launch
+     * moves into); a launch of one tile per slot or less costs more in the extra packets of the carry (a copy, two events)
+     * than it gains: it keeps the carry in the kernel and the next launch stays behind it on the same stream. */
+    bool two = false;
+    if (e->ncs > 1u && e->use_v3 && n_new) {
+        const uint32_t ntiles = (n_new + MFM_V3_OT - 1u) / MFM_V3_OT, slots = 256u * e->v_wg_per_cu;
+        two = (uint64_t)ntiles * e->m_nslices > slots;
+    }
+    hipStream_t S_after = two ? e->cs[e->si ^ 1u] : S;
+    if (e->ncs > 1u && !two && e->in_free_wait[nxt]) {
+        /* this launch (or its stream's copy) writes the carry into the next buffer: whoever read that one last - possibly on
+         * the other stream - must be through */
+        HIP_TRY(hipStreamWaitEvent(S, e->in_free_wait[nxt], 0));
+    }
 
     OutSlot *slot = nullptr;
     int slot_idx = -1;
@@ -1456,7 +1521,7 @@ int launch_locked(mfm_engine *e)
             V.tail_n = D + n_avail - n_new * D;
             V.tail_dst = e->d_in[nxt];
             tail_in_kernel = true;
-            if (e->ncs > 1u) {
+            if (two) {
                 V.tail_n = 0; /* the next launch must not wait for this kernel: the carry is copied on its own stream below */
                 tail_in_kernel = false;
             }
@@ -1512,14 +1577,14 @@ int launch_locked(mfm_engine *e)
     const uint32_t new_hist = (e->use_v3 && n_new) ? D : e->hist;
     if (new_hist + new_tail && !tail_in_kernel) {
         const size_t ss = raw8 ? 2 : 4;
-        if (e->ncs > 1u && e->in_free_wait[nxt]) {
+        if (two && e->in_free_wait[nxt]) {
             /* the launch that last read the next buffer may be on the other stream */
             HIP_TRY(hipStreamWaitEvent(S_after, e->in_free_wait[nxt], 0));
         }
         HIP_TRY(hipMemcpyAsync(e->d_in[nxt],
                                reinterpret_cast<const uint8_t *>(e->d_in[cur]) + ((size_t)e->hist + consumed - new_hist) * ss,
                                ((size_t)new_hist + new_tail) * ss, hipMemcpyDeviceToDevice, S_after));
-        if (e->ncs > 1u) {
+        if (two) {
             /* this buffer is free once its kernel AND this copy are through (acquire_input waits for both) */
             HIP_TRY(hipEventRecord(e->tail_done[cur], S_after));
             e->tail_pending[cur] = true;
@@ -1559,6 +1624,9 @@ int launch_locked(mfm_engine *e)
         e->outputs += n_new;
     }
 
+    if (two) {
+        e->si ^= 1u;
+    }
     e->last_launch_samples = n_avail;
     e->last_launch_buf = cur;
     e->last_launch_fmt = fmt;
@@ -1718,7 +1786,7 @@ int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *produc
         /* the history at the front of this buffer is bytes, the block behind it int16: widen it where it stands (the
          * kernel that wrote it is ahead of this on the compute stream; the block's own samples start 4 * tail bytes in) */
         const uint32_t nh = e->hist + e->tail;
-        hipStream_t Sn = e->cs[e->launches & (e->ncs - 1u)]; /* the stream of this buffer's launch: the carry was queued there */
+        hipStream_t Sn = e->cs[e->si]; /* the stream of this buffer's launch: the carry was queued there */
         HIP_TRY(hipMemcpyAsync(e->d_tailtmp, e->d_in[cur], (size_t)nh * 2, hipMemcpyDeviceToDevice, Sn));
         hipLaunchKernelGGL(mfm_unpack_kernel, dim3((nh / 8u + 256u) / 256u), dim3(256), 0, Sn, e->d_tailtmp,
                            e->d_in[cur], nh, e->tail_fmt, 0);
@@ -2144,6 +2212,55 @@ void *mfm_engine_stream(struct mfm_engine *e)
 static float g_atan_tbl[257];
 static float2 g_atan_lut[256];
 static bool g_atan_ok = false;
+static void atan_tbl_once(void);
+
+/* the discriminator as the kernels of variant 0 / 1 / 2 compute it, on the device, for caller-supplied products */
+int mfm_devtest_discriminate(int variant, const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *pcm_out, int device)
+{
+    if (!s_re || !s_im || !pcm_out || variant < 0 || variant > 2 || n > (1u << 28)) {
+        return fail(MFM_E_INVAL, "bad argument");
+    }
+    if (0 == n) {
+        return MFM_OK;
+    }
+    atan_tbl_once();
+    HIP_TRY(hipSetDevice(device));
+    const size_t np = (n + 3u) & ~(size_t)3u;
+    int *d_re = nullptr, *d_im = nullptr, *d_out = nullptr;
+    float2 *d_lut = nullptr;
+    int rc = MFM_OK;
+    std::vector<int32_t> out(np);
+    do {
+        if (hipMalloc(&d_re, np * 4) != hipSuccess || hipMalloc(&d_im, np * 4) != hipSuccess || hipMalloc(&d_out, np * 4) != hipSuccess ||
+            hipMalloc(&d_lut, sizeof(g_atan_lut)) != hipSuccess) {
+            rc = fail(MFM_E_NOMEM, "device allocation failed");
+            break;
+        }
+        if (hipMemset(d_re, 0, np * 4) != hipSuccess || hipMemset(d_im, 0, np * 4) != hipSuccess ||
+            hipMemcpy(d_re, s_re, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_im, s_im, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_lut, g_atan_lut, sizeof(g_atan_lut), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(MFM_E_DEVICE, "copy to the device failed");
+            break;
+        }
+        const hipError_t err = variant == 2   ? mfm_disc_test_v3(d_re, d_im, d_out, (uint32_t)np, d_lut, nullptr)
+                               : variant == 1 ? mfm_disc_test_mfma(d_re, d_im, d_out, (uint32_t)np, d_lut, nullptr)
+                                              : mfm_disc_test_dot2(d_re, d_im, d_out, (uint32_t)np, d_lut, nullptr);
+        if (err != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(out.data(), d_out, np * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(MFM_E_DEVICE, "discriminator test kernel failed: %s", hipGetErrorString(err));
+            break;
+        }
+        for (size_t i = 0; i < n; i++) {
+            pcm_out[i] = (int16_t)out[i];
+        }
+    } while (0);
+    (void)hipFree(d_re);
+    (void)hipFree(d_im);
+    (void)hipFree(d_out);
+    (void)hipFree(d_lut);
+    return rc;
+}
 
 static void atan_tbl_build(void)
 {

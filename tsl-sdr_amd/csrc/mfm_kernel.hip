@@ -243,6 +243,24 @@ __global__ __launch_bounds__(MFM_NT) void mfm_channel_kernel(const mfm_launch L)
 /* ------------------------------------------------------------------------------------- */
 
 /* which instance runs (outputs per lane, filtered-IQ output): asked once at commit, where its LDS limit is raised */
+/* The scalar discriminator (mfm_numerics.h) on caller-supplied products (tests, the engine's division self-test) */
+__global__ __launch_bounds__(256) void mfm_disc_test_kernel(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut)
+{
+    __shared__ float2 tbl[256];
+    tbl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n) {
+        pcm[t] = mfm_discriminate(s_re[t], s_im[t], tbl);
+    }
+}
+
+extern "C" hipError_t mfm_disc_test_dot2(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mfm_disc_test_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, s_re, s_im, pcm, n, lut);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mfm_select_channel_kernel(int opl, int dbg_iq, const void **kfn_out)
 {
     *kfn_out = nullptr;

@@ -896,6 +896,31 @@ static const void *mfm_resident_instance(const mfm_launch_mfma *L, int dbg_iq, u
 }
 
 /* waves_per_simd_out: what the chosen instance is built for (4: two workgroups of 8 waves per CU where LDS allows, 2: one) */
+/* The packed discriminator of this file on caller-supplied products (tests, the engine's division self-test): thread t
+ * takes s[2t], s[2t + 1]. */
+__global__ __launch_bounds__(512) void mfm_disc_test_kernel_mfma(const int *s_re, const int *s_im, int *pcm, uint32_t n2, const float2 *lut)
+{
+    __shared__ __attribute__((aligned(16))) float tbl[512]; /* T[256] followed by dT[256] */
+    reinterpret_cast<uint32_t *>(tbl)[(threadIdx.x >> 1) + ((threadIdx.x & 1u) << 8)] = reinterpret_cast<const uint32_t *>(lut)[threadIdx.x];
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 512u + threadIdx.x;
+    if (t >= n2) {
+        return;
+    }
+    const int32_t re[2] = { s_re[2 * t], s_re[2 * t + 1] }, im[2] = { s_im[2 * t], s_im[2 * t + 1] };
+    int32_t out[2];
+    mfm_discriminate2(re, im, tbl, tbl + 256, out);
+    pcm[2 * t] = out[0];
+    pcm[2 * t + 1] = out[1];
+}
+
+extern "C" hipError_t mfm_disc_test_mfma(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream)
+{
+    const uint32_t n2 = n / 2u;
+    hipLaunchKernelGGL(mfm_disc_test_kernel_mfma, dim3((n2 + 511u) / 512u), dim3(512), 0, stream, s_re, s_im, pcm, n2, lut);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mfm_select_channel_kernel_mfma(const mfm_launch_mfma *L, int dbg_iq, const void **kfn_out,
                                                      uint32_t *waves_per_simd_out)
 {

@@ -205,15 +205,14 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        /* mfm_div_unit: correctly rounded mn / mx */
+        /* mfm_div_unit: correctly rounded mn / mx (one residual step behind the quotient estimate: mfm_numerics.h has the
+         * argument and tools/div_proof.c the enumeration behind it) */
         const float r0 = __builtin_amdgcn_rcpf(mx[i]);
         const float e0 = __builtin_fmaf(-mx[i], r0, 1.0f);
         const float r1 = __builtin_fmaf(e0, r0, r0);
         const float q0 = mn[i] * r1;
         const float e1 = __builtin_fmaf(-mx[i], q0, mn[i]);
-        const float q1 = __builtin_fmaf(e1, r1, q0);
-        const float e2 = __builtin_fmaf(-mx[i], q1, mn[i]);
-        z[i] = __builtin_fmaf(e2, r1, q1);
+        z[i] = __builtin_fmaf(e1, r1, q0);
     }
     typedef const __attribute__((address_space(3))) float *lds_fp;
 #pragma unroll
@@ -1146,7 +1145,6 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
         }
         if (rb_valid) {
-            const uint32_t ch0 = rb * 8u + 2u * kg;
             /* ---- one channel after the other (register pressure): derotation, discriminator, stores ---- */
             const uint32_t n_left = L.n_new - first_out; /* >= 1 */
             uint32_t q[4][2];
@@ -1257,6 +1255,37 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
         tend = n_tend;
         first_of_chunk = n_first;
     }
+}
+
+/* The discriminator of this file on caller-supplied products (tests, and the engine's division self-test at commit):
+ * thread t takes s[4t .. 4t + 3], exactly as a lane of the channel kernel takes its four outputs. */
+__global__ __launch_bounds__(MFM3_NT) void mfm3_disc_test_kernel(const int *s_re, const int *s_im, int *pcm, uint32_t n4, const float2 *lut)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tbl[512];
+    tbl[(threadIdx.x >> 1) + ((threadIdx.x & 1u) << 8)] = reinterpret_cast<const uint32_t *>(lut)[threadIdx.x];
+    __syncthreads();
+    const uint32_t t = blockIdx.x * MFM3_NT + threadIdx.x;
+    if (t >= n4) {
+        return;
+    }
+    int re[4], im[4], out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        re[i] = s_re[4 * t + i];
+        im[i] = s_im[4 * t + i];
+    }
+    mfm3_discriminate4(re, im, (uint32_t)(uintptr_t)tbl, out);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        pcm[4 * t + i] = out[i];
+    }
+}
+
+extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream)
+{
+    const uint32_t n4 = n / 4u; /* n is a multiple of 4 (the caller pads) */
+    hipLaunchKernelGGL(mfm3_disc_test_kernel, dim3((n4 + MFM3_NT - 1u) / MFM3_NT), dim3(MFM3_NT), 0, stream, s_re, s_im, pcm, n4, lut);
+    return hipGetLastError();
 }
 
 /*

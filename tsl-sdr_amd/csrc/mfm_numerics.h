@@ -88,11 +88,19 @@ struct mfm_lut_ent {
 #define MFM_LUT_Y(e) (e).y
 #endif
 
-/* Correctly rounded mn / mx.  On the device this is the core of the compiler's own IEEE fdiv
- * expansion (v_rcp_f32 + three Newton/residual steps) without the v_div_scale / v_div_fixup
- * wrapping that only matters for subnormal, infinite or zero operands: here both operands are
- * int32 values converted to float, mn <= mx, so the quotient is in [2^-31, 1] (or 0/0 -> NaN, which
- * the caller discards). */
+/* Correctly rounded mn / mx.  On the device: v_rcp_f32, one Newton step on the reciprocal, the quotient estimate and ONE
+ * residual step (Markstein's form) - without the v_div_scale / v_div_fixup wrapping that only matters for subnormal,
+ * infinite or zero operands: here both operands are int32 values converted to float, mn <= mx, so the quotient is in
+ * [2^-31, 1] (or 0/0 -> NaN, which the caller discards).
+ * Why one residual step is enough (rounds 1-3 ran two, because Markstein's theorem wants a correctly rounded reciprocal
+ * and v_rcp_f32 is specified to 1 ulp): q1 = RN(v), v = q0 + r1 (mn - mx q0) exactly, and |v - mn/mx| < 2^-23 ulp; RN(v)
+ * can differ from RN(mn/mx) only when mn/mx lies that close to the midpoint of two floats, which for 24-bit significands
+ * A, B means |A 2^k - t B| <= 4 with t odd - at most a handful of A per B.  tools/div_proof.c enumerates all 46 517 418
+ * such pairs over all 2^23 divisors and runs this sequence on each, with the reciprocal gfx950 really returns for B
+ * (tools/rcp_check.hip tabulates v_rcp_f32 for every significand: 89 % correctly rounded, 9 % one ulp low, 2 % one ulp
+ * high): 0 wrong (profiles/r04_division_proof.txt).  The form is NOT right for every 1-ulp reciprocal: B = 2^24 - 1 needs
+ * the correctly rounded one, B = 2^24 - 3 must not come out one ulp high - so the engine checks those quotients on the
+ * device at commit (mfm_engine.hip, division self-test) and refuses a device whose v_rcp_f32 answers differently. */
 MFM_HD float mfm_div_unit(float mn, float mx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -101,9 +109,7 @@ MFM_HD float mfm_div_unit(float mn, float mx)
     const float r1 = __builtin_fmaf(e0, r0, r0);
     const float q0 = mn * r1;
     const float e1 = __builtin_fmaf(-mx, q0, mn);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(-mx, q1, mn);
-    return __builtin_fmaf(e2, r1, q1);
+    return __builtin_fmaf(e1, r1, q0);
 #else
     return mn / mx;
 #endif
@@ -204,9 +210,7 @@ static __device__ __forceinline__ void mfm_discriminate2(const int32_t s_re[2], 
     const mfm_v2f r1 = __builtin_elementwise_fma(e0, r0, r0);
     const mfm_v2f q0 = mn * r1;
     const mfm_v2f e1 = __builtin_elementwise_fma(-mx, q0, mn);
-    const mfm_v2f q1 = __builtin_elementwise_fma(e1, r1, q0);
-    const mfm_v2f e2 = __builtin_elementwise_fma(-mx, q1, mn);
-    const mfm_v2f z = __builtin_elementwise_fma(e2, r1, q1);
+    const mfm_v2f z = __builtin_elementwise_fma(e1, r1, q0);
 
     const mfm_v2f alpha = z * 255.0f;
     mfm_v2f frac, t0, dt;
