@@ -388,13 +388,24 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
     sample_buf, in the size the RTL-SDR front end delivers (131 072 samples, multifm/rtl_sdr_if.c:46): host buffer ->
     mfm_group_push (staging in pinned memory, H2D, one device group of one GPU) -> kernel -> PCM mirrored to pinned host
     memory -> mfm_group_fetch / release, with the group gathering up to a pool's worth of buffers (128, demod.c:297) per
-    launch as the C host configures it.  PCIe inclusive; never `value`."""
+    launch as the C host configures it.  `pinned_pool`: the buffers are page-locked like the C host's pool and the H2D reads
+    them in place (mfm_group_push_pinned); `staged_copy`: pageable buffers through the engine's staging copy.  The producer
+    is this Python loop (one ctypes call per buffer).  PCIe inclusive; never `value`."""
     b = pkg.binding
     out = {"buffer_samples": buf_samples, "buffers": nr_bufs,
            "path": "host buffer -> mfm_group_push -> H2D -> kernel -> D2H -> mfm_group_fetch/release"}
     nch = len(offs)
     data = pkg.synth.synth_iq(buf_samples * 8, fs, offs[:: max(1, nch // 8)][:8], seed=7).reshape(8, -1, 2)
-    for mode, co in (("coalesced_128_buffers", 128 * buf_samples), ("launch_per_buffer", 0)):
+    import ctypes
+    lib0 = pkg.load_library()
+    # the C host's sample_buf pool is page-locked memory (mfm_host_alloc): eight such buffers stand in for it
+    pinned = [lib0.mfm_host_alloc(buf_samples * 4) for _ in range(8)]
+    for k, ptr in enumerate(pinned):
+        if not ptr:
+            return {"error": "mfm_host_alloc failed"}
+        ctypes.memmove(ptr, data[k].ctypes.data, buf_samples * 4)
+    for mode, co, pin in (("pinned_pool_coalesced_128_buffers", 128 * buf_samples, True),
+                          ("pinned_pool_launch_per_buffer", 0, True), ("staged_copy_coalesced_128_buffers", 128 * buf_samples, False)):
         try:
             grp = b.Group(fs, decim, buf_samples, devices=(0,), coalesce_samples=co)
             for o, g in zip(offs, gains):
@@ -413,10 +424,20 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
                 lib.mfm_group_release(grp.h)
                 return n
 
+            def push(i):
+                if pin:
+                    return lib.mfm_group_push_pinned(grp.h, pinned[i & 7], buf_samples, b.MFM_IN_CS16, None)
+                return grp.push(data[i & 7])
+
             def run(nbuf):
                 outs = 0
                 for i in range(nbuf):
-                    while grp.push(data[i & 7]) == b.MFM_E_BUSY:
+                    while True:
+                        rc = push(i)
+                        if rc == 0:
+                            break
+                        if rc != b.MFM_E_BUSY:
+                            raise RuntimeError(f"push: {rc} {lib.mfm_last_error()}")
                         outs += drain_one()
                 while True:
                     rc = grp.flush()
@@ -449,6 +470,8 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
                          "outputs_per_channel": int(outs)}
         except Exception as e:  # a side line must never take the headline down
             out[mode] = {"error": repr(e)}
+    for ptr in pinned:
+        lib0.mfm_host_free(ptr)
     return out
 
 

@@ -58,7 +58,8 @@ extern "C" {
                                 mfm_group_config.exchange
                              4: mfm_engine_config / mfm_group_config grew coalesce_samples (+ a third ext_input); mfm_stats grew submits,
                                 pending_samples; mfm_engine_flush, mfm_group_flush, mfm_engine_input_bytes_cfg, mfm_engine_replay,
-                                mfm_engine_last_launch_input, mfm_engine_seek; MFM_F_GATHER, MFM_F_OVERLAP */
+                                mfm_engine_last_launch_input, mfm_engine_seek, mfm_host_alloc/free, mfm_*_push_pinned,
+                                mfm_*_copy_done/_wait, mfm_devtest_discriminate; MFM_F_GATHER, MFM_F_OVERLAP */
 
 /* flags for mfm_engine_config::flags */
 #define MFM_F_DEVICE_ONLY 0x1u /* keep outputs in HBM; no host mirror, fetch() unavailable */
@@ -217,6 +218,18 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples);
                                last one is stored without the subtraction (multifm/file_if.c:113-157) */
 #define MFM_IN_RTLSDR_U8 3  /* unsigned bytes, (b - 127) << 7 (multifm/rtl_sdr_if.c:146-158) */
 int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format);
+/*
+ * Host ingest without the staging copy.  The reference's sample_bufs come from a fixed pool (frame_alloc_new,
+ * multifm/receiver.c:154-157); when that pool is page-locked memory (mfm_host_alloc) the H2D copy reads data_buf where
+ * the front end wrote it.  mfm_engine_push_pinned() is mfm_engine_push_bytes() (any MFM_IN_* format) on such memory: it
+ * returns at once with a ticket, and the buffer must stay untouched until mfm_engine_copy_done(ticket) says 1 (or
+ * mfm_engine_copy_wait returns) - that is when the reference would sample_buf_decref() it (filter/direct_fir.c:395).
+ */
+void *mfm_host_alloc(size_t bytes); /* page-locked host memory (hipHostMalloc); NULL on failure */
+void mfm_host_free(void *p);
+int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_samples, int format, uint64_t *ticket);
+int mfm_engine_copy_done(struct mfm_engine *e, uint64_t ticket); /* 1: read, 0: not yet, < 0: error */
+int mfm_engine_copy_wait(struct mfm_engine *e, uint64_t ticket);
 /* The same for a producer on the device (a collective, a capture card's DMA): where the next block's BYTES go, two per
  * sample, when the engine's kernel can read them as they are - the second-generation matrix kernel, and no history of
  * another format in front (MFM_E_STATE otherwise: widen the block as the reference does and use
@@ -326,6 +339,10 @@ int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_ch
 /* host ingest of one block in any MFM_IN_* format.  MFM_E_BUSY when a shard's output ring is full (nothing was
  * staged on any shard: fetch/release and retry). */
 int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format);
+/* the same out of page-locked memory (mfm_host_alloc), without the staging copy: as mfm_engine_push_pinned() */
+int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_samples, int format, uint64_t *ticket);
+int mfm_group_copy_done(struct mfm_group *g, uint64_t ticket);
+int mfm_group_copy_wait(struct mfm_group *g, uint64_t ticket);
 /* oldest finished block of every shard into blks[0 .. nr_shards); MFM_E_DONE when nothing is pending */
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks);
 int mfm_group_release(struct mfm_group *g);

@@ -211,6 +211,10 @@ struct mfm_engine {
     uint32_t last_launch_samples = 0; /* what the most recent launch read: a second launch is queued behind one in flight
                                          once a quarter of that has gathered */
     uint64_t submits = 0;
+    /* pushes straight out of the caller's pinned memory (mfm_engine_push_pinned): a ticket per push, an event per ticket */
+    static constexpr uint64_t kCopyRing = 256;
+    hipEvent_t copy_ev[kCopyRing] = {};
+    uint64_t copy_seq = 0, copy_done_seq = 0;
     int last_launch_buf = -1, last_launch_fmt = MFM_IN_CS16;
     uint32_t last_launch_hist = 0;
     /* 8-bit blocks may sit in the input buffers as they came off the wire (2 bytes per sample, push_bytes): the format of
@@ -524,6 +528,13 @@ void free_device(mfm_engine *e)
     if (e->in_ready) {
         (void)hipEventDestroy(e->in_ready);
     }
+    for (uint64_t i = 0; i < mfm_engine::kCopyRing; i++) {
+        if (e->copy_ev[i]) {
+            (void)hipEventDestroy(e->copy_ev[i]);
+            e->copy_ev[i] = nullptr;
+        }
+    }
+    e->copy_seq = e->copy_done_seq = 0;
     if (e->kernel_done) {
         (void)hipEventDestroy(e->kernel_done);
     }
@@ -1857,8 +1868,10 @@ static int check_output_room(struct mfm_engine *e, size_t nr_samples)
  * the next submit() expects them, by work queued on the engine's copy stream.  *d_dst is that device address - what a
  * device group broadcasts to its other members before every member submits.
  */
-int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, int format, int allow_raw, void **d_dst)
+int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, int format, int flags, void **d_dst)
 {
+    const int allow_raw = flags & MFM_STAGE_ALLOW_RAW;
+    const bool pinned = (flags & MFM_STAGE_PINNED) != 0; /* the caller's memory is page-locked: the copy engine reads it directly */
     if (!e || !data) {
         return fail(MFM_E_INVAL, "NULL argument");
     }
@@ -1893,17 +1906,22 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
         return fail(MFM_E_INVAL, "the input buffer has room for %zu samples, the block has %zu", cap, nr_samples);
     }
     const int cur = e->cur_in;
-    if (!e->h_in[cur]) {
+    if (!pinned && !e->h_in[cur]) {
         HIP_TRY(hipHostMalloc(&e->h_in[cur], (size_t)e->cap_in * 4, hipHostMallocDefault));
     }
     /* acquire_input() waited for the kernel that consumed the previous contents of this buffer, so the copies out of
      * h_in[cur] that fed it are done; blocks accepted since then sit in front of this one, as they do on the device */
-    uint8_t *h = reinterpret_cast<uint8_t *>(e->h_in[cur]) + (size_t)e->pend * 4;
+    uint8_t *h = pinned ? const_cast<uint8_t *>(static_cast<const uint8_t *>(data))
+                        : reinterpret_cast<uint8_t *>(e->h_in[cur]) + (size_t)e->pend * 4;
     if (raw) {
-        memcpy(h, data, nr_samples * 2);
+        if (!pinned) {
+            memcpy(h, data, nr_samples * 2);
+        }
         HIP_TRY(hipMemcpyAsync(dst, h, nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
     } else if (format == MFM_IN_CS16) {
-        memcpy(h, data, nr_samples * 4);
+        if (!pinned) {
+            memcpy(h, data, nr_samples * 4);
+        }
         HIP_TRY(hipMemcpyAsync(dst, h, nr_samples * 4, hipMemcpyHostToDevice, e->s_in));
     } else {
         if (!e->d_raw[cur]) {
@@ -1911,7 +1929,9 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
         }
         /* the unpack kernels of the previous use of d_raw[cur] ran before the kernel acquire_input() waited for */
         uint16_t *draw = e->d_raw[cur] + ((e->pend + 7u) & ~7u); /* the unpack kernel reads 16-byte groups */
-        memcpy(h, data, nr_samples * 2);
+        if (!pinned) {
+            memcpy(h, data, nr_samples * 2);
+        }
         HIP_TRY(hipMemcpyAsync(draw, h, nr_samples * 2, hipMemcpyHostToDevice, e->s_in));
         uint32_t blocks = (uint32_t)((nr_samples / 8 + 255) / 256);
         blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
@@ -1919,10 +1939,91 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
                            static_cast<uint32_t *>(dst), (uint32_t)nr_samples, format, 1);
         HIP_TRY(hipGetLastError());
     }
+    if (pinned) {
+        /* a ticket for this push: its event says when the caller's memory has been read */
+        const uint64_t t = e->copy_seq + 1;
+        const size_t slot = (size_t)(t % mfm_engine::kCopyRing);
+        if (t - e->copy_done_seq > mfm_engine::kCopyRing) {
+            /* the slot's previous ticket is still open: copies complete in order, so waiting for it closes everything older */
+            HIP_TRY(hipEventSynchronize(e->copy_ev[slot]));
+            e->copy_done_seq = t - mfm_engine::kCopyRing;
+        }
+        if (!e->copy_ev[slot]) {
+            HIP_TRY(hipEventCreateWithFlags(&e->copy_ev[slot], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(e->copy_ev[slot], e->s_in));
+        e->copy_seq = t;
+    }
     if (d_dst) {
         *d_dst = dst;
     }
     return MFM_OK;
+}
+
+uint64_t mfm_engine_copy_ticket(struct mfm_engine *e)
+{
+    return e ? e->copy_seq : 0;
+}
+
+int mfm_engine_copy_done(struct mfm_engine *e, uint64_t ticket)
+{
+    if (!e || !e->committed || ticket > e->copy_seq) {
+        return fail(MFM_E_INVAL, "no such ticket");
+    }
+    if (ticket <= e->copy_done_seq || 0 == ticket) {
+        return 1;
+    }
+    if (e->copy_seq - ticket >= mfm_engine::kCopyRing) {
+        return 1; /* its event has been reused: staging waited for it */
+    }
+    if (!event_done(e->copy_ev[ticket % mfm_engine::kCopyRing])) {
+        return 0;
+    }
+    e->copy_done_seq = ticket; /* one copy stream, in order */
+    return 1;
+}
+
+int mfm_engine_copy_wait(struct mfm_engine *e, uint64_t ticket)
+{
+    if (!e || !e->committed || ticket > e->copy_seq) {
+        return fail(MFM_E_INVAL, "no such ticket");
+    }
+    if (ticket <= e->copy_done_seq || 0 == ticket || e->copy_seq - ticket >= mfm_engine::kCopyRing) {
+        return MFM_OK;
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipEventSynchronize(e->copy_ev[ticket % mfm_engine::kCopyRing]));
+    e->copy_done_seq = ticket;
+    return MFM_OK;
+}
+
+int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_samples, int format, uint64_t *ticket)
+{
+    int rc = mfm_engine_stage(e, data, nr_samples, format, MFM_STAGE_ALLOW_RAW | MFM_STAGE_PINNED, nullptr);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    if (ticket) {
+        *ticket = e->copy_seq;
+    }
+    return mfm_engine_submit(e, nr_samples, e->s_in, 1);
+}
+
+void *mfm_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (0 == bytes || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void mfm_host_free(void *p)
+{
+    if (p) {
+        (void)hipHostFree(p);
+    }
 }
 
 void *mfm_engine_copy_stream(struct mfm_engine *e)
@@ -1952,7 +2053,7 @@ int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
 
 int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_samples, int format)
 {
-    const int rc = mfm_engine_stage(e, bytes, nr_samples, format, 1, nullptr);
+    const int rc = mfm_engine_stage(e, bytes, nr_samples, format, MFM_STAGE_ALLOW_RAW, nullptr);
     return rc != MFM_OK ? rc : mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 

@@ -14,8 +14,12 @@ extern "C" {
  * MFM_E_BUSY when the output ring has no free slot for it.  *d_dst = device address of the staged samples: int16 pairs,
  * unless allow_raw is set and the engine chose to keep an 8-bit block as bytes for its matrix kernel (then the next
  * submit of THIS engine knows; nobody else can use the address). */
+#define MFM_STAGE_ALLOW_RAW 1 /* an 8-bit block may stay bytes when the engine's kernel reads them so */
+#define MFM_STAGE_PINNED 2    /* `data` is page-locked (mfm_host_alloc): no staging copy, the H2D reads it where it lies; the
+                                 push gets a ticket (mfm_engine_copy_ticket) that says when it has been read */
 __attribute__((visibility("hidden"))) int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples,
-                                                           int format, int allow_raw, void **d_dst);
+                                                           int format, int flags, void **d_dst);
+__attribute__((visibility("hidden"))) uint64_t mfm_engine_copy_ticket(struct mfm_engine *e);
 /* 1 when the engine would keep a block of nr_samples 8-bit samples of this format as bytes now */
 __attribute__((visibility("hidden"))) int mfm_engine_can_take_bytes(struct mfm_engine *e, int format, size_t nr_samples);
 /* the stream mfm_engine_stage() queues its work on (hipStream_t) */

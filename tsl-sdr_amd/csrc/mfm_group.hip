@@ -361,6 +361,7 @@ namespace {
 /* the group's shards behind the operations mfm_group_seq.h sequences */
 struct GroupOps {
     mfm_group *g;
+    bool pinned = false; /* the block lies in page-locked memory: the root's H2D reads it where it is */
     size_t shards() { return g->eng.size(); }
     int plan(size_t i, size_t n, bool *must, bool *may, bool *want)
     {
@@ -381,7 +382,7 @@ struct GroupOps {
     }
     int stage_root(const void *data, size_t n, int fmt, bool raw, void **d_root)
     {
-        return mfm_engine_stage(g->eng[0], data, n, fmt, raw ? 1 : 0, d_root);
+        return mfm_engine_stage(g->eng[0], data, n, fmt, (raw ? MFM_STAGE_ALLOW_RAW : 0) | (pinned ? MFM_STAGE_PINNED : 0), d_root);
     }
     int nccl_fail(int nrc, const char *what, size_t bytes)
     {
@@ -472,6 +473,41 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
         g->bytes_exchanged += bytes * (g->eng.size() - 1);
     }
     return rc;
+}
+
+int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_samples, int format, uint64_t *ticket)
+{
+    if (!g || !data) {
+        return gfail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    if (!g->exchange) {
+        return mfm_engine_push_pinned(g->eng[0], data, nr_samples, format, ticket);
+    }
+    GroupOps ops{ g };
+    ops.pinned = true;
+    size_t bytes = 0;
+    const int rc = mfm_group_push_seq(ops, &g->broken, data, nr_samples, format, format != MFM_IN_CS16, &bytes);
+    if (rc == MFM_OK) {
+        g->blocks++;
+        g->bytes_exchanged += bytes * (g->eng.size() - 1);
+        if (ticket) {
+            *ticket = mfm_engine_copy_ticket(g->eng[0]);
+        }
+    }
+    return rc;
+}
+
+int mfm_group_copy_done(struct mfm_group *g, uint64_t ticket)
+{
+    return (g && g->committed) ? mfm_engine_copy_done(g->eng[0], ticket) : gfail(MFM_E_STATE, "commit first");
+}
+
+int mfm_group_copy_wait(struct mfm_group *g, uint64_t ticket)
+{
+    return (g && g->committed) ? mfm_engine_copy_wait(g->eng[0], ticket) : gfail(MFM_E_STATE, "commit first");
 }
 
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks)

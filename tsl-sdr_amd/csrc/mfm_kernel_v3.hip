@@ -45,6 +45,9 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM3_BARRIER_LATE
 #define MFM3_BARRIER_LATE 0 /* 1: A/B builds - the tile's barrier behind the epilogue instead of in front of it */
 #endif
+#ifndef MFM3_DIV_STEPS
+#define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
+#endif
 #define MFM3_SCHED_ALL_BUT_VMEM 0x38F
 
 /* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 (left to itself the compiler makes it two shifts and a three-operand
@@ -213,6 +216,9 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         const float q0 = mn[i] * r1;
         const float e1 = __builtin_fmaf(-mx[i], q0, mn[i]);
         z[i] = __builtin_fmaf(e1, r1, q0);
+#if MFM3_DIV_STEPS > 1
+        z[i] = __builtin_fmaf(__builtin_fmaf(-mx[i], z[i], mn[i]), r1, z[i]);
+#endif
     }
     typedef const __attribute__((address_space(3))) float *lds_fp;
 #pragma unroll

@@ -309,13 +309,37 @@ static int _format_of(const struct sample_buf *buf)
     }
 }
 
+/* buffers whose H2D copy is through go back to the pool (filter/direct_fir.c:395 is where a channel thread of the reference
+ * lets go of a buffer: when its last sample has been consumed); wait = block until every one of them is back */
+static void _receiver_reap_copies(struct receiver *rx, bool wait)
+{
+    while (rx->copy_tail != rx->copy_head) {
+        const size_t i = rx->copy_tail % rx->ring_slots;
+        int done = rx->failed ? 1 : mfm_group_copy_done(rx->group, rx->copy_ticket[i]);
+        if (0 == done && wait) {
+            done = MFM_OK == mfm_group_copy_wait(rx->group, rx->copy_ticket[i]) ? 1 : -1;
+        }
+        if (0 == done) {
+            return;
+        }
+        if (done < 0 && !rx->failed) {
+            MFM_MSG(SEV_FATAL, "ENGINE-COPY", "waiting for a buffer's copy failed: %s", mfm_last_error());
+            rx->failed = 1;
+        }
+        TSL_BUG_IF_FAILED(sample_buf_decref(rx->copying[i])); /* back to the pool */
+        rx->copy_tail++;
+    }
+}
+
 /* the submit thread: ring -> device group; the only place that waits for the GPU on the input side */
 static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
 {
     struct receiver *rx = BL_CONTAINER_OF(wthr, struct receiver, submit_thr);
     while (worker_thread_is_running(wthr) || rx->ring_tail != rx->ring_head) {
         const size_t tail = rx->ring_tail;
+        _receiver_reap_copies(rx, false);
         if (tail == rx->ring_head) {
+            _receiver_reap_copies(rx, true); /* nothing else to do: the front end gets its buffers back as soon as possible */
             /* the backlog is through: what the device group accepted without launching goes out now, as the reference's
              * channel thread runs what its queue held before it sleeps again (multifm/demod.c:134-150) */
             while (!rx->failed) {
@@ -346,7 +370,14 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
             for (;;) {
                 /* armed before the attempt: a slot released between a refused push and the sleep still rings */
                 _bell_arm(&rx->room_bell);
-                const int rc = mfm_group_push(rx->group, buf->data_buf, buf->nr_samples, _format_of(buf));
+                uint64_t ticket = 0;
+                const int rc = mfm_group_push_pinned(rx->group, buf->data_buf, buf->nr_samples, _format_of(buf), &ticket);
+                if (MFM_OK == rc) {
+                    rx->copying[rx->copy_head % rx->ring_slots] = buf;
+                    rx->copy_ticket[rx->copy_head % rx->ring_slots] = ticket;
+                    rx->copy_head++;
+                    buf = NULL; /* the copy engine is reading it: _receiver_reap_copies() returns it to the pool */
+                }
                 if (MFM_E_BUSY == rc && !rx->failed) {
                     /* every output slot holds a block the drain thread has not written out yet */
                     _bell_sleep(&rx->room_bell, MFM_IDLE_MS);
@@ -365,8 +396,11 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
         rx->nr_bufs_submitted++;
         _bell_ring(&rx->block_bell);
         _bell_ring(&rx->idle_bell);
-        TSL_BUG_IF_FAILED(sample_buf_decref(buf)); /* back to the pool */
+        if (NULL != buf) {
+            TSL_BUG_IF_FAILED(sample_buf_decref(buf)); /* not handed over (a failed receiver): back to the pool */
+        }
     }
+    _receiver_reap_copies(rx, true);
     return rx->failed ? A_E_DEVICE : A_OK;
 }
 
@@ -642,6 +676,9 @@ static void _receiver_zero(struct receiver *rx, receiver_rx_thread_func_t rx_fun
     rx->nr_shards = 0;
     rx->ring = NULL;
     rx->ring_slots = 0;
+    rx->copying = NULL;
+    rx->copy_ticket = NULL;
+    rx->copy_head = rx->copy_tail = 0;
     rx->nr_demod_threads = 0;
     atomic_store(&rx->nr_samp_buf_alloc_fails, 0);
     atomic_store(&rx->input_done, false);
@@ -677,8 +714,15 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
     if (FAILED(ret = _settings_read(cfg, samples_per_buf, &st))) {
         goto done;
     }
-    TSL_BUG_IF_FAILED(frame_alloc_new(&rx->samp_alloc, sizeof(struct sample_buf) + samples_per_buf * sizeof(int16_t) * 2,
-                                      (size_t)st.nr_samp_bufs));
+    /* the pool of multifm/receiver.c:154-157, in page-locked memory: the H2D copy reads a delivered buffer's data_buf where
+     * the front end wrote it, no staging copy in between */
+    if (FAILED(frame_alloc_new_on(&rx->samp_alloc, sizeof(struct sample_buf) + samples_per_buf * sizeof(int16_t) * 2,
+                                  (size_t)st.nr_samp_bufs, mfm_host_alloc, mfm_host_free))) {
+        MFM_MSG(SEV_FATAL, "NO-PINNED-POOL", "Unable to allocate %d page-locked sample buffers of %zu samples (no usable GPU?).",
+                st.nr_samp_bufs, samples_per_buf);
+        ret = A_E_NOMEM;
+        goto done;
+    }
 
     /* one device group for the whole channel set, and a pointer ring with a slot per pool frame in front of it */
     if (MFM_OK != mfm_group_create(&rx->group, &st.group)) {
@@ -690,7 +734,9 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
             st.group.devices[0], st.group.exchange == MFM_X_RCCL ? " (RCCL exchange forced)" :
             st.group.exchange == MFM_X_RCCL_ALLGATHER ? " (RCCL scatter + all-gather exchange)" : "");
     rx->ring_slots = (size_t)st.nr_samp_bufs;
-    if (FAILED(ret = TACALLOC(&rx->ring, rx->ring_slots, sizeof(*rx->ring), SYS_CACHE_LINE_LENGTH))) {
+    if (FAILED(ret = TACALLOC(&rx->ring, rx->ring_slots, sizeof(*rx->ring), SYS_CACHE_LINE_LENGTH)) ||
+        FAILED(ret = TACALLOC(&rx->copying, rx->ring_slots, sizeof(*rx->copying), SYS_CACHE_LINE_LENGTH)) ||
+        FAILED(ret = TACALLOC(&rx->copy_ticket, rx->ring_slots, sizeof(*rx->copy_ticket), SYS_CACHE_LINE_LENGTH))) {
         goto done;
     }
 
@@ -799,6 +845,12 @@ aresult_t receiver_cleanup(struct receiver **prx)
     mfm_group_destroy(&rx->group);
     if (NULL != rx->ring) {
         TFREE(rx->ring);
+    }
+    if (NULL != rx->copying) {
+        TFREE(rx->copying);
+    }
+    if (NULL != rx->copy_ticket) {
+        TFREE(rx->copy_ticket);
     }
     TSL_BUG_IF_FAILED(frame_alloc_delete(&rx->samp_alloc));
     sem_destroy(&rx->ring_bell.sem);

@@ -118,6 +118,11 @@ struct receiver {
     struct sample_buf **ring;     /* delivered, not yet submitted buffers: single producer (front end), single
                                      consumer (submit thread); as many slots as the pool has frames, so it never fills */
     size_t ring_slots;
+    /* buffers handed to the device group and not yet read by its H2D copy (the pool is page-locked memory: the copy
+     * engine reads data_buf where the front end wrote it).  Only the submit thread touches these. */
+    struct sample_buf **copying;
+    uint64_t *copy_ticket;
+    size_t copy_head, copy_tail;
     /* shared between the front end's thread, the submit thread and the drain thread: C11 atomics (sequentially
      * consistent by default; a slot of `ring` is published by the store to ring_head that follows it) */
     _Atomic size_t ring_head, ring_tail;

@@ -49,13 +49,29 @@ aresult_t worker_thread_delete(struct worker_thread *thr)
 
 struct frame_alloc {
     uint8_t *slab;
+    void (*slab_free)(void *);
     void **free_stack;
     size_t frame_bytes, nr_frames, nr_free;
     pthread_mutex_t lock;
 };
 
+static void *_slab_malloc(size_t bytes)
+{
+    void *p = NULL;
+    return 0 == posix_memalign(&p, 64, bytes) ? p : NULL;
+}
+
 aresult_t frame_alloc_new(struct frame_alloc **pfa, size_t frame_bytes, size_t nr_frames)
 {
+    return frame_alloc_new_on(pfa, frame_bytes, nr_frames, _slab_malloc, free);
+}
+
+/* the same pool on memory from the caller's allocator: the receiver puts its sample_bufs into page-locked memory
+ * (mfm_host_alloc) so that the H2D copy reads data_buf where the front end wrote it */
+aresult_t frame_alloc_new_on(struct frame_alloc **pfa, size_t frame_bytes, size_t nr_frames, void *(*slab_alloc)(size_t),
+                             void (*slab_free)(void *))
+{
+    TSL_ASSERT_ARG(NULL != slab_alloc && NULL != slab_free);
     TSL_ASSERT_ARG(NULL != pfa);
     TSL_ASSERT_ARG(0 != frame_bytes);
     TSL_ASSERT_ARG(0 != nr_frames);
@@ -65,13 +81,15 @@ aresult_t frame_alloc_new(struct frame_alloc **pfa, size_t frame_bytes, size_t n
     }
     fa->frame_bytes = (frame_bytes + 63u) & ~(size_t)63u;
     fa->nr_frames = nr_frames;
-    if (0 != posix_memalign((void **)&fa->slab, 64, fa->frame_bytes * nr_frames)) {
+    fa->slab_free = slab_free;
+    fa->slab = slab_alloc(fa->frame_bytes * nr_frames);
+    if (NULL == fa->slab) {
         free(fa);
         return A_E_NOMEM;
     }
     fa->free_stack = malloc(nr_frames * sizeof(void *));
     if (!fa->free_stack) {
-        free(fa->slab);
+        slab_free(fa->slab);
         free(fa);
         return A_E_NOMEM;
     }
@@ -125,7 +143,7 @@ aresult_t frame_alloc_delete(struct frame_alloc **pfa)
     if (*pfa) {
         pthread_mutex_destroy(&(*pfa)->lock);
         free((*pfa)->free_stack);
-        free((*pfa)->slab);
+        (*pfa)->slab_free((*pfa)->slab);
         free(*pfa);
         *pfa = NULL;
     }

@@ -131,6 +131,8 @@ static inline bool worker_thread_is_running(struct worker_thread *thr)
 /* ---- fixed pool of equally sized frames (sample buffers) ---- */
 struct frame_alloc;
 aresult_t frame_alloc_new(struct frame_alloc **pfa, size_t frame_bytes, size_t nr_frames);
+aresult_t frame_alloc_new_on(struct frame_alloc **pfa, size_t frame_bytes, size_t nr_frames, void *(*slab_alloc)(size_t),
+                             void (*slab_free)(void *));
 aresult_t frame_alloc(struct frame_alloc *fa, void **pframe); /* A_E_NOMEM when the pool is empty */
 aresult_t frame_free(struct frame_alloc *fa, void **pframe);
 aresult_t frame_alloc_delete(struct frame_alloc **pfa);
