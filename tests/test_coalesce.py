@@ -300,3 +300,54 @@ def test_seek_resumes_the_rotators_also_beyond_2_to_the_32(pkg, ora, kernel, bef
         assert np.array_equal(pcm[c], want), (c, before)
         assert np.array_equal(q[c], wantq.reshape(-1, 2)), (c, before)
     eng.close()
+
+
+@pytest.mark.parametrize("coalesce", [0, 200000])
+def test_pushes_out_of_page_locked_memory_with_copy_tickets(pkg, ora, coalesce):
+    """mfm_engine_push_pinned: the H2D copy reads the caller's page-locked buffer in place (what the C host's sample_buf pool
+    is) and a ticket says when the buffer may be reused - the front end's next fill, here an overwrite with garbage the
+    moment the ticket is through.  int16 and RTL-SDR byte blocks; PCM against the oracle."""
+    import ctypes
+    b = pkg.binding
+    lib = pkg.load_library()
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=12)
+    nbuf, spb = 4, 16384
+    pool = [lib.mfm_host_alloc(spb * 4) for _ in range(nbuf)]
+    assert all(pool)
+    eng = pkg.Engine(fs, decim, spb, device=0, coalesce_samples=coalesce)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    rng = np.random.RandomState(5)
+    sizes = [spb, spb, 4096, spb, 100, spb, 7777, spb] * 6
+    iq, parts, qparts, tickets = [], [], [], [0] * nbuf
+    for k, m in enumerate(sizes):
+        fmt = b.MFM_IN_RTLSDR_U8 if (k // 8) % 2 else b.MFM_IN_CS16
+        slot = k % nbuf
+        assert lib.mfm_engine_copy_wait(eng.h, tickets[slot]) == 0 and lib.mfm_engine_copy_done(eng.h, tickets[slot]) == 1
+        if fmt == b.MFM_IN_CS16:
+            blk = rng.randint(-20000, 20000, size=(m, 2)).astype(np.int16)
+            iq.append(blk)
+        else:
+            blk = rng.randint(0, 256, size=(m, 2)).astype(np.uint8)
+            iq.append(ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+        ctypes.memset(pool[slot], 0x5a, spb * 4)   # whatever was there is gone: its copy had better be through
+        ctypes.memmove(pool[slot], blk.ctypes.data, blk.nbytes)
+        t = ctypes.c_uint64()
+        while True:
+            rc = lib.mfm_engine_push_pinned(eng.h, pool[slot], m, fmt, ctypes.byref(t))
+            if rc == 0:
+                break
+            assert rc == b.MFM_E_BUSY, lib.mfm_last_error()
+            _drain(eng, parts, qparts)
+        tickets[slot] = t.value
+        assert t.value == k + 1
+    _finish(eng, parts, qparts)
+    eng.close()
+    for p in pool:
+        lib.mfm_host_free(p)
+    iq = np.concatenate(iq)
+    cre, cim, incr = _tables(ora, taps, offs, fs, decim, gains)
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
+    got = np.concatenate([p[1] for p in parts], axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)

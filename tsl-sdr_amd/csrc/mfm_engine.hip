@@ -212,9 +212,16 @@ struct mfm_engine {
                                          once a quarter of that has gathered */
     uint64_t submits = 0;
     /* pushes straight out of the caller's pinned memory (mfm_engine_push_pinned): a ticket per push, an event per ticket */
-    static constexpr uint64_t kCopyRing = 256;
+    /* Copies complete in order (one copy stream), so a ticket is through as soon as ANY event recorded behind it is: events
+     * are recorded only when somebody asks about a ticket no recorded event covers yet (an event per push cost more host
+     * time than the staging copy it replaced), a few of them in rotation. */
+    static constexpr uint64_t kCopyRing = 4;
     hipEvent_t copy_ev[kCopyRing] = {};
+    uint64_t copy_ev_seq[kCopyRing] = {}; /* the ticket each of them covers (0: not recorded) */
+    uint64_t copy_ev_next = 0;
     uint64_t copy_seq = 0, copy_done_seq = 0;
+    bool wait_copy_stream = false; /* blocks staged on the engine's copy stream since the last launch: the launch waits for
+                                      that stream once, instead of every push recording and waiting for an event */
     int last_launch_buf = -1, last_launch_fmt = MFM_IN_CS16;
     uint32_t last_launch_hist = 0;
     /* 8-bit blocks may sit in the input buffers as they came off the wire (2 bytes per sample, push_bytes): the format of
@@ -533,8 +540,10 @@ void free_device(mfm_engine *e)
             (void)hipEventDestroy(e->copy_ev[i]);
             e->copy_ev[i] = nullptr;
         }
+        e->copy_ev_seq[i] = 0;
     }
-    e->copy_seq = e->copy_done_seq = 0;
+    e->copy_seq = e->copy_done_seq = e->copy_ev_next = 0;
+    e->wait_copy_stream = false;
     if (e->kernel_done) {
         (void)hipEventDestroy(e->kernel_done);
     }
@@ -1462,6 +1471,13 @@ int launch_locked(mfm_engine *e)
             return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
         }
     }
+    if (e->wait_copy_stream) {
+        HIP_TRY(hipEventRecord(e->in_ready, e->s_in));
+        for (uint32_t i = 0; i < e->ncs; i++) {
+            HIP_TRY(hipStreamWaitEvent(e->cs[i], e->in_ready, 0));
+        }
+        e->wait_copy_stream = false;
+    }
 
     bool tail_in_kernel = false;
     hipEvent_t timing_end = nullptr;
@@ -1786,10 +1802,15 @@ int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *produc
         return fail(MFM_E_BUSY, "all %d output slots hold unfetched blocks", e->nslots);
     }
 
-    if (wait_producer) {
+    if (wait_producer && static_cast<hipStream_t>(producer_stream) == e->s_in && !launch) {
+        e->wait_copy_stream = true; /* the launch that takes this block waits for the copy stream, once for all it gathered */
+    } else if (wait_producer) {
         HIP_TRY(hipEventRecord(e->in_ready, static_cast<hipStream_t>(producer_stream)));
         for (uint32_t i = 0; i < e->ncs; i++) {
             HIP_TRY(hipStreamWaitEvent(e->cs[i], e->in_ready, 0)); /* the launch on one, the carry out of it on the other */
+        }
+        if (static_cast<hipStream_t>(producer_stream) == e->s_in) {
+            e->wait_copy_stream = false; /* everything staged before is covered too */
         }
     }
 
@@ -1940,19 +1961,7 @@ int mfm_engine_stage(struct mfm_engine *e, const void *data, size_t nr_samples, 
         HIP_TRY(hipGetLastError());
     }
     if (pinned) {
-        /* a ticket for this push: its event says when the caller's memory has been read */
-        const uint64_t t = e->copy_seq + 1;
-        const size_t slot = (size_t)(t % mfm_engine::kCopyRing);
-        if (t - e->copy_done_seq > mfm_engine::kCopyRing) {
-            /* the slot's previous ticket is still open: copies complete in order, so waiting for it closes everything older */
-            HIP_TRY(hipEventSynchronize(e->copy_ev[slot]));
-            e->copy_done_seq = t - mfm_engine::kCopyRing;
-        }
-        if (!e->copy_ev[slot]) {
-            HIP_TRY(hipEventCreateWithFlags(&e->copy_ev[slot], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(e->copy_ev[slot], e->s_in));
-        e->copy_seq = t;
+        e->copy_seq++; /* this push's ticket (mfm_engine_copy_done / _wait) */
     }
     if (d_dst) {
         *d_dst = dst;
@@ -1965,36 +1974,51 @@ uint64_t mfm_engine_copy_ticket(struct mfm_engine *e)
     return e ? e->copy_seq : 0;
 }
 
-int mfm_engine_copy_done(struct mfm_engine *e, uint64_t ticket)
+/* is ticket through?  wait: block until it is.  Looks at the events that cover it; records one if none does. */
+static int copy_ticket_state(struct mfm_engine *e, uint64_t ticket, bool wait)
 {
     if (!e || !e->committed || ticket > e->copy_seq) {
         return fail(MFM_E_INVAL, "no such ticket");
     }
-    if (ticket <= e->copy_done_seq || 0 == ticket) {
+    if (ticket <= e->copy_done_seq) {
         return 1;
     }
-    if (e->copy_seq - ticket >= mfm_engine::kCopyRing) {
-        return 1; /* its event has been reused: staging waited for it */
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    /* the oldest recorded event that covers the ticket answers soonest */
+    int best = -1;
+    for (int i = 0; i < (int)mfm_engine::kCopyRing; i++) {
+        if (e->copy_ev_seq[i] >= ticket && (best < 0 || e->copy_ev_seq[i] < e->copy_ev_seq[best])) {
+            best = i;
+        }
     }
-    if (!event_done(e->copy_ev[ticket % mfm_engine::kCopyRing])) {
+    if (best < 0) {
+        /* none yet: one behind everything staged so far.  Its slot's previous event is the oldest one; if that is still
+         * pending it covers only older tickets, and re-recording it loses nothing we are asked about. */
+        best = (int)(e->copy_ev_next++ % mfm_engine::kCopyRing);
+        if (!e->copy_ev[best]) {
+            HIP_TRY(hipEventCreateWithFlags(&e->copy_ev[best], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(e->copy_ev[best], e->s_in));
+        e->copy_ev_seq[best] = e->copy_seq;
+    }
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(e->copy_ev[best]));
+    } else if (!event_done(e->copy_ev[best])) {
         return 0;
     }
-    e->copy_done_seq = ticket; /* one copy stream, in order */
+    e->copy_done_seq = std::max(e->copy_done_seq, e->copy_ev_seq[best]);
     return 1;
+}
+
+int mfm_engine_copy_done(struct mfm_engine *e, uint64_t ticket)
+{
+    return copy_ticket_state(e, ticket, false);
 }
 
 int mfm_engine_copy_wait(struct mfm_engine *e, uint64_t ticket)
 {
-    if (!e || !e->committed || ticket > e->copy_seq) {
-        return fail(MFM_E_INVAL, "no such ticket");
-    }
-    if (ticket <= e->copy_done_seq || 0 == ticket || e->copy_seq - ticket >= mfm_engine::kCopyRing) {
-        return MFM_OK;
-    }
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipEventSynchronize(e->copy_ev[ticket % mfm_engine::kCopyRing]));
-    e->copy_done_seq = ticket;
-    return MFM_OK;
+    const int rc = copy_ticket_state(e, ticket, true);
+    return rc < 0 ? rc : MFM_OK;
 }
 
 int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_samples, int format, uint64_t *ticket)
@@ -2214,6 +2238,7 @@ int mfm_engine_reset(struct mfm_engine *e)
     e->tail_fmt = MFM_IN_CS16;
     e->in_fmt[0] = e->in_fmt[1] = e->in_fmt[2] = MFM_IN_CS16;
     e->cur_in = 0;
+    e->wait_copy_stream = false;
     e->last_launch_samples = 0;
     e->last_launch_buf = -1;
     e->outputs = 0;

@@ -45,6 +45,9 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM3_BARRIER_LATE
 #define MFM3_BARRIER_LATE 0 /* 1: A/B builds - the tile's barrier behind the epilogue instead of in front of it */
 #endif
+#ifndef MFM3_NONTEMPORAL
+#define MFM3_NONTEMPORAL 0 /* A/B builds - bit 0: the image loads carry the non-temporal hint, bit 1: the PCM stores do */
+#endif
 #ifndef MFM3_DIV_STEPS
 #define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
 #endif
@@ -638,7 +641,13 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
         int gs = (int)(tile * MFM_V3_OT * D + L.hist) - (int)(MFM_V3_LEAD * D) + (IN8 ? 8 : 4) * (int)(q < L.nstage4 ? q : 0u);
         gs = gs < 0 ? 0 : gs;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
+#if MFM3_NONTEMPORAL & 1
+        const mfm_v4i ld = __builtin_nontemporal_load(
+            reinterpret_cast<const mfm_v4i *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << (IN8 ? 1 : 2))));
+        return make_uint4((uint32_t)ld[0], (uint32_t)ld[1], (uint32_t)ld[2], (uint32_t)ld[3]);
+#else
         return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << (IN8 ? 1 : 2)));
+#endif
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
         if (IN8) {
@@ -1211,7 +1220,13 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         uint2 w;
                         w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
                         w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
+#if MFM3_NONTEMPORAL & 2
+                        typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
+                        mfm_v2u wv = { w.x, w.y };
+                        __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]));
+#else
                         *reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]) = w;
+#endif
                         if (DBG_IQ) {
                             *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + 2u * (size_t)voff[c]) =
                                 make_uint4(q[0][c], q[1][c], q[2][c], q[3][c]);

@@ -337,7 +337,11 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
     struct receiver *rx = BL_CONTAINER_OF(wthr, struct receiver, submit_thr);
     while (worker_thread_is_running(wthr) || rx->ring_tail != rx->ring_head) {
         const size_t tail = rx->ring_tail;
-        _receiver_reap_copies(rx, false);
+        if (rx->copy_head - rx->copy_tail >= (rx->ring_slots + 3) / 4) {
+            /* a quarter of the pool is with the copy engine: ask for it back (asking costs an event on the copy stream, so
+             * not after every buffer) */
+            _receiver_reap_copies(rx, false);
+        }
         if (tail == rx->ring_head) {
             _receiver_reap_copies(rx, true); /* nothing else to do: the front end gets its buffers back as soon as possible */
             /* the backlog is through: what the device group accepted without launching goes out now, as the reference's
