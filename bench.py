@@ -615,10 +615,10 @@ def main():
             b.copy_(torch.from_numpy(host))
     torch.cuda.synchronize()
 
-    # the exchange step: "auto" times the RCCL broadcast and the scatter + all-gather form once on the real buffer and keeps
-    # the faster (tsl-sdr_amd/dist.py; DESIGN.md section 7: a broadcast delivers at one xGMI link's rate per GPU, the
-    # all-gather uses all of them); MFM_EXCHANGE=broadcast | scatter_allgather pins one
-    exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "auto")) if use_dist else None
+    # the exchange step: scatter + all-gather by default (tsl-sdr_amd/dist.py; DESIGN.md section 7: a broadcast delivers at
+    # one xGMI link's rate per GPU, the all-gather uses all of them); MFM_EXCHANGE=broadcast pins the other form, =auto times
+    # both once on the real buffer and keeps the faster
+    exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "scatter_allgather")) if use_dist else None
 
     def step():
         ptr, cap = eng.acquire_input()
@@ -757,6 +757,8 @@ def main():
                 # max(exchange, kernel)): one block per kernel time
                 "needed_GBps_per_peer": block * 4 / (k_ms * 1e-3) / 1e9,
                 "delivered_GBps_per_peer": block * 4 / (dt / args.steps) / 1e9,
+                # does the exchange hide behind the kernel (a step costs max(exchange, kernel))?
+                "hidden": bool(dt / args.steps <= 1.1 * k_ms * 1e-3),
                 "delivered_GBps_total": block * 4 * (world - 1) / (dt / args.steps) / 1e9,
                 "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7},
             "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],

@@ -202,6 +202,41 @@ int main()
         consumer.join();
         CHECK(bad == 0 && fetched == 300 && !broken);
     }
+    { /* `broken` is written by the push thread (a collective that fails, a submit that fails half-way) while
+       * the fetch thread reads it - an atomic flag, exercised here under ThreadSanitizer: a consumer polling fetch while the
+       * producer's exchange starts to fail must see blocks, "nothing yet", and from some point on only MFM_E_DEVICE */
+        Fake f; std::atomic<bool> broken{ false }; f.S = 2;
+        std::atomic<bool> stop{ false };
+        std::atomic<int> ok{ 0 }, dev{ 0 }, bad{ 0 };
+        std::thread consumer([&] {
+            Blk b[2];
+            bool seen_broken = false;
+            while (!stop) {
+                const int rc = mfm_group_fetch_seq(f, &broken, b);
+                if (rc == MFM_OK) {
+                    if (seen_broken) bad++;
+                    f.released[0]++;
+                    f.released[1]++;
+                    ok++;
+                } else if (rc == MFM_E_DEVICE) {
+                    seen_broken = true;
+                    dev++;
+                } else if (rc != MFM_E_DONE) {
+                    bad++;
+                }
+            }
+        });
+        for (int k = 0; k < 200; k++) {
+            if (k == 120) f.exchange_fail = MFM_E_DEVICE;
+            const int rc = mfm_group_push_seq(f, &broken, data, 64, 0, false, &bytes);
+            if ((k < 120) != (rc == MFM_OK)) bad++;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        stop = true;
+        consumer.join();
+        CHECK(bad == 0 && broken && dev > 0 && f.total_submits() == 240);
+    }
     printf("group sequence: all checks held\n");
     return 0;
 }

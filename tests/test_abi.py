@@ -133,3 +133,34 @@ def test_asm_scheduled_instances_do_not_spill():
     for ln in resident:
         m = re.search(r"vgpr\s+(\d+) agpr\s+\d+ spill\s+(\d+)", ln)
         assert m and int(m.group(1)) <= 256 and int(m.group(2)) == 0, ln
+
+
+def test_hand_counted_lds_waits_cover_their_reads():
+    """the resident long-filter instances (mfm_kernel_mfma.hip) and the hand-scheduled column groups
+    (mfm_kernel_v3.hip) issue ds_read_b128 from inline asm and wait with hand-counted s_waitcnt lgkmcnt(N), which the
+    compiler's own waitcnt insertion does not model.  tools/lgkm_check.py models the LGKM counter over the disassembly of
+    every instance and reports any instruction that touches a fragment register before the wait that covers its read - a
+    copy slipped in by the register allocator, a product scheduled in front of its wait.  None may exist, in any instance."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import lgkm_check
+    finally:
+        sys.path.pop(0)
+    # the checker itself: a copy of a fragment register between the read and its wait is a violation, one behind it is not
+    reads, viol, unv, _ = lgkm_check.check_kernel(["ds_read_b128 v[0:3], v10 offset:16", "ds_read_b128 v[4:7], v10 offset:32",
+                                                   "v_mov_b32_e32 v20, v5", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v21, v1",
+                                                   "v_mov_b32_e32 v22, v6", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v23, v7"])
+    assert (reads, viol, unv) == (2, 2, 0)
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm tools here")
+    for obj, flt, least in (("mfm_kernel_mfma.o", "mfm_channel_kernel_mfma<", 100), ("mfm_kernel_v3.o", "mfm_channel_kernel_v3<", 60)):
+        path = os.path.join(root, "tsl-sdr_amd", "build", obj)
+        if not os.path.exists(path):
+            pytest.skip("no built object")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "lgkm_check.py"), path, flt], capture_output=True, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("mfm_channel_kernel")]
+        assert r.returncode == 0 and len(lines) >= least, (r.returncode, len(lines), r.stdout[-2000:])
+        assert all(" violations 0 " in ln for ln in lines)

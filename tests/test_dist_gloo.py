@@ -92,8 +92,9 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_broadcast_and_sharded_demod(pkg, ora, tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_exchange_the_block_and_demodulate_their_shards(pkg, ora, tmp_path, world):
+    """world 2, and 8 - the node the north star names (10 channels over 8 ranks: shards of two and of one channel)"""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"pcm_{r}.npy") for r in range(world)]

@@ -39,6 +39,7 @@ extern "C" hipError_t mfm_disc_test_dot2(const int *s_re, const int *s_im, int *
 extern "C" hipError_t mfm_disc_test_mfma(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream);
 extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream);
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out);
+extern "C" uint32_t mfm_rot_entry_bytes_v3(void);
 extern "C" hipError_t mfm_launch_channel_kernel_v3(const void *kfn, const mfm_launch_v3 *L, uint32_t lds_bytes, uint32_t grid,
                                                    hipStream_t stream);
 
@@ -1296,8 +1297,18 @@ static int commit_locked(struct mfm_engine *e)
     }
     HIP_TRY(hipMalloc(&e->d_info, info.size() * sizeof(mfm_chan_info)));
     HIP_TRY(hipMemcpy(e->d_info, info.data(), info.size() * sizeof(mfm_chan_info), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&e->d_rot, rot.size() * sizeof(uint2)));
-    HIP_TRY(hipMemcpy(e->d_rot, rot.data(), rot.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    if (e->use_v3 && mfm_rot_entry_bytes_v3() == 4u) {
+        /* the second-generation kernel's build takes 4-byte entries (rr | ri << 16): half the table bytes per output */
+        std::vector<uint32_t> rot4(rot.size());
+        for (size_t i = 0; i < rot.size(); i++) {
+            rot4[i] = mfm_pack16(mfm_lo16(rot[i].x), mfm_lo16(rot[i].y)); /* {(rr, -ri), (ri, rr)} -> (rr, ri) */
+        }
+        HIP_TRY(hipMalloc(&e->d_rot, rot4.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(e->d_rot, rot4.data(), rot4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMalloc(&e->d_rot, rot.size() * sizeof(uint2)));
+        HIP_TRY(hipMemcpy(e->d_rot, rot.data(), rot.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc(&e->d_lut, lut.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(e->d_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
     for (int i = 0; i < 2; i++) {

@@ -202,7 +202,8 @@ struct mfm_launch_v3 {
     const uint32_t *afrag;
     const int32_t *krow;
     const struct mfm_chan_info *info;
-    const uint2 *rot;
+    const void *rot;      /* rotator tables: 8-byte entries {(rr, -ri), (ri, rr)}, or 4-byte ones (rr | ri << 16) - whichever
+                             mfm_rot_entry_bytes_v3() says this kernel file was built for */
     const float2 *lut;
     int16_t *pcm;
     uint32_t *iq_dbg;

@@ -45,6 +45,12 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM3_BARRIER_LATE
 #define MFM3_BARRIER_LATE 0 /* 1: A/B builds - the tile's barrier behind the epilogue instead of in front of it */
 #endif
+#ifndef MFM3_ROT4
+#define MFM3_ROT4 0 /* 1: rotator-table entries of 4 bytes (rr | ri << 16) instead of 8 ({(rr, -ri), (ri, rr)}): half the table
+                       bytes per output for two cheap and one expensive instruction per entry (the two dot-product operands are
+                       rebuilt in registers); must match mfm_engine.hip's table (mfm_rot_entry_bytes_v3) */
+#endif
+#define MFM3_ES (MFM3_ROT4 ? 4u : 8u) /* bytes per rotator-table entry */
 #ifndef MFM3_NONTEMPORAL
 #define MFM3_NONTEMPORAL 0 /* A/B builds - bit 0: the image loads carry the non-temporal hint, bit 1: the PCM stores do */
 #endif
@@ -147,6 +153,18 @@ static __device__ __forceinline__ uint32_t mfm3_opaque(uint32_t v)
 {
     asm volatile("" : "+v"(v));
     return v;
+}
+
+/* a 4-byte rotator entry r = (rr | ri << 16) as the two dot-product operands of the derotation: (rr, -ri) and (ri, rr).  The
+ * engine refuses rotators that reach ri = -32768, so the negated half never wraps. */
+static __device__ __forceinline__ uint32_t mfm3_rot_x(uint32_t r)
+{
+    return (r ^ 0xffff0000u) + 0x00010000u;
+}
+
+static __device__ __forceinline__ uint32_t mfm3_rot_y(uint32_t r)
+{
+    return __builtin_amdgcn_alignbit(r, r, 16);
 }
 
 /* rotator-table position of output index (kb + d) of a channel: pre-period as is, then folded into the period */
@@ -825,7 +843,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
         const uint32_t first_out = tile * MFM_V3_OT;
 
         uint32_t f[4][2];
-        uint4 rva[2][2];
+        uint4 rva[2][MFM3_ROT4 ? 1 : 2];
         if (rb_valid) {
             const uint32_t ch0 = rb * 8u + 2u * kg;
             if (slice != slice_loaded) {
@@ -941,8 +959,8 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     const uint64_t kabs = L.k_base + first_out;
                     const uint32_t k0 = (kabs >> 32) == 0 ? mfm3_fold((uint32_t)kabs, 0u, mu, lam, lam_magic)
                                                           : mfm3_fold64(kabs, mu, lam, lam_magic);
-                    kbg[c] = (inf.x + k0 + 4u * n) * 8u;
-                    fog[c] = make_uint2((inf.x + mu + lam) * 8u, lam * 8u);
+                    kbg[c] = (inf.x + k0 + 4u * n) * MFM3_ES;
+                    fog[c] = make_uint2((inf.x + mu + lam) * MFM3_ES, lam * MFM3_ES);
                     /* an exact rotator: (16384, 0) for ever, or alternating with (-16384, 0) - then table position k holds
                      * (-1)^k * 16384 (pre-period 0, even period) and a tile's first output (64 * tile + 4n) has the parity
                      * of k0 throughout the chunk.  Low half: the factor of the lane's even outputs (column groups 0, 2),
@@ -966,9 +984,15 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         /* rotator entry of the output in front (the entry in front of a period is not the period's last
                          * one: position mu is reached from mu - 1 the first time and from mu + lam - 1 ever after) */
                         const uint32_t kw = (k0 != mu || kabs == (uint64_t)mu) ? k0 - 1u : mu + lam - 1u;
-                        const uint2 e = L.rot[inf.x + kw];
+#if MFM3_ROT4
+                        const uint32_t r = reinterpret_cast<const uint32_t *>(L.rot)[inf.x + kw];
+                        wrx[c] = mfm3_rot_x(r);
+                        wry[c] = mfm3_rot_y(r);
+#else
+                        const uint2 e = reinterpret_cast<const uint2 *>(L.rot)[inf.x + kw];
                         wrx[c] = e.x;
                         wry[c] = e.y;
+#endif
                     }
                 }
                 if constexpr (RC == MFM_RC_GENERAL) {
@@ -1058,7 +1082,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     for (int c = 0; c < 2; c++) {
                         const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
                         rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
+#if !MFM3_ROT4
                         rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1098,7 +1124,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     for (int c = 0; c < 2; c++) {
                         const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
                         rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
+#if !MFM3_ROT4
                         rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1129,7 +1157,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         for (int c = 0; c < 2; c++) {
                             const uint8_t *rp = reinterpret_cast<const uint8_t *>(L.rot) + kb8[c];
                             rva[c][0] = *reinterpret_cast<const uint4 *>(rp);
+#if !MFM3_ROT4
                             rva[c][1] = *reinterpret_cast<const uint4 *>(rp + 16);
+#endif
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1180,9 +1210,15 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     /* derotation + second rounding, two column groups per call */
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
+#if MFM3_ROT4
+                        const uint32_t r0 = h ? rva[c][0].z : rva[c][0].x, r1 = h ? rva[c][0].w : rva[c][0].y;
+                        const uint32_t fin[2] = { f[2 * h][c], f[2 * h + 1][c] };
+                        const uint32_t rx[2] = { mfm3_rot_x(r0), mfm3_rot_x(r1) }, ry[2] = { mfm3_rot_y(r0), mfm3_rot_y(r1) };
+#else
                         const uint4 e = rva[c][h];
                         const uint32_t fin[2] = { f[2 * h][c], f[2 * h + 1][c] };
                         const uint32_t rx[2] = { e.x, e.z }, ry[2] = { e.y, e.w };
+#endif
                         uint32_t qo[2];
                         derotate2(fin, rx, ry, qo);
                         q[2 * h][c] = qo[0];
@@ -1255,8 +1291,8 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             for (int c = 0; c < 2; c++) {
                 if (RC == MFM_RC_GENERAL && !w_exact) {
                     const uint2 fo = fold_s[c]; /* at or past table position mu + lam the position folds back by lam */
-                    kb8[c] += MFM_V3_OT * 8u;
-                    kb8[c] = kb8[c] >= fo.x + 32u * n ? kb8[c] - fo.y : kb8[c];
+                    kb8[c] += MFM_V3_OT * MFM3_ES;
+                    kb8[c] = kb8[c] >= fo.x + 4u * MFM3_ES * n ? kb8[c] - fo.y : kb8[c];
                 }
                 voff[c] += MFM_V3_OT * 2u;
             }
@@ -1437,6 +1473,12 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
 #undef MFM3_LAUNCH_F
 #undef MFM3_LAUNCH
     return hipSuccess;
+}
+
+/* what the engine's rotator table for this kernel file has to look like */
+extern "C" uint32_t mfm_rot_entry_bytes_v3(void)
+{
+    return MFM3_ES;
 }
 
 extern "C" hipError_t mfm_launch_channel_kernel_v3(const void *kfn, const mfm_launch_v3 *L, uint32_t lds_bytes, uint32_t grid,

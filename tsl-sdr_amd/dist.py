@@ -34,8 +34,11 @@ class BlockExchange:
                              then an all-gather fills in the rest (every link of the node busy): the classic
                              large-message broadcast, worth it where links are point to point.
     "auto" times both on the real buffer once (choose()) and keeps the faster; the decision is taken on max-reduced
-    times, so every rank takes the same one.  bench.py's default at N > 1 since round 3: a broadcast delivers the block at
-    one link's rate per GPU whatever N, the scatter + all-gather uses every link."""
+    times, so every rank takes the same one.  bench.py's default at N > 1 is "scatter_allgather" (round 4): a broadcast
+    delivers the block at one link's rate per GPU whatever N, the scatter + all-gather uses every link (DESIGN.md section
+    7) - and a fixed choice keeps every rank on the same sequence of collectives whatever happens.  A collective that fails
+    is NOT caught anywhere here: after a failed RCCL operation the communicator is not usable for a fallback, and ranks that
+    disagree about which collective comes next hang; the error ends the process (and with it the job)."""
 
     ALGOS = ("broadcast", "scatter_allgather")
 
@@ -89,19 +92,16 @@ class BlockExchange:
         dev = view.device
         res = {}
         for algo in self.ALGOS:
-            try:
+            # both forms use operations every backend in use here has (broadcast, batched send / receive, all-gather: RCCL
+            # and gloo); an error is a real one and propagates - every rank runs the same collectives in the same order
+            self.run(view, algo)
+            sync()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(iters):
                 self.run(view, algo)
-                sync()
-                dist.barrier(group=self.group)
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    self.run(view, algo)
-                sync()
-                mine = (time.perf_counter() - t0) / iters
-            except RuntimeError as e:  # a backend that lacks an operation: every rank sees the same error and keeps the other
-                print(f"[dist] exchange '{algo}' not usable here: {e}", flush=True)
-                mine = float("inf")
-            res[algo] = max_over_ranks(mine, device=dev)
+            sync()
+            res[algo] = max_over_ranks((time.perf_counter() - t0) / iters, device=dev)
         self.timings = res
         self.algo = min(res, key=res.get)
         return self.algo

@@ -1,7 +1,11 @@
 /*
- * multifm_main.c - `multifm_amd cfg1.json [cfg2.json ...]`: the multifm channelizer driver on the MI355X
- * engine.  Same command line and config merging as the reference (multifm/multifm.c:89-173); device
- * types other than "file" need vendor libraries that are not part of this build.
+ * multifm_main.c - `multifm_amd cfg1.json [cfg2.json ...]`: the multifm channelizer driver on the MI355X engine.
+ *
+ * Command line, configuration merging and the messages a user sees follow the reference's driver
+ * (multifm/multifm.c:89-173): every argument is a JSON file merged into one configuration, whose "device" stanza
+ * names the front end by "type".  The front ends this build knows sit in a table: a name (matched as a prefix, like the
+ * reference's strncmp chain) and the constructor that turns the configuration into a running receiver, or NULL for the
+ * types whose vendor libraries (librtlsdr, libdespairspy, UHD) are not part of this build.
  */
 #include "mfm_file_if.h"
 
@@ -10,70 +14,103 @@
 
 #define MFM_MSG(sev, sys, msg, ...) MESSAGE("MULTIFM", sev, sys, msg, ##__VA_ARGS__)
 
-static volatile sig_atomic_t g_running = 1;
+typedef aresult_t (*front_end_new_func_t)(struct receiver **prx, struct config *cfg);
 
-static void _on_sigint(int sig)
+static const struct front_end {
+    const char *type;            /* "device": { "type": ... } starts with this */
+    front_end_new_func_t create; /* NULL: known to multifm, not built here */
+} front_ends[] = {
+    { "file", file_worker_thread_new },
+    { "rtlsdr", NULL },
+    { "airspy", NULL },
+    { "usrp", NULL },
+};
+
+static volatile sig_atomic_t stop_requested;
+
+static void on_sigint(int sig)
 {
     (void)sig;
-    g_running = 0;
+    stop_requested = 1;
+}
+
+/* every command-line argument is one more file of the same configuration */
+static struct config *load_configuration(int nr_files, const char *files[])
+{
+    struct config *cfg = NULL;
+    TSL_BUG_IF_FAILED(config_new(&cfg));
+    for (int i = 0; i < nr_files; i++) {
+        if (FAILED(config_add(cfg, files[i]))) {
+            MFM_MSG(SEV_FATAL, "MALFORMED-CONFIG", "Configuration file [%s] is malformed.", files[i]);
+            config_delete(&cfg);
+            return NULL;
+        }
+    }
+    return cfg;
+}
+
+static const struct front_end *find_front_end(struct config *cfg)
+{
+    struct config device = CONFIG_INIT_EMPTY;
+    const char *type = NULL;
+
+    if (FAILED(config_get(cfg, &device, "device"))) {
+        MFM_MSG(SEV_FATAL, "MALFORMED-CONFIG", "Configuration is missing 'device' stanza. Aborting.");
+        return NULL;
+    }
+    if (FAILED(config_get_string(&device, &type, "type"))) {
+        MFM_MSG(SEV_FATAL, "MALFORMED-CONFIG", "The 'device' stanza is missing a 'type' specification. Aborting.");
+        return NULL;
+    }
+    for (size_t i = 0; i < sizeof(front_ends) / sizeof(front_ends[0]); i++) {
+        if (0 == strncmp(type, front_ends[i].type, strlen(front_ends[i].type))) {
+            if (NULL == front_ends[i].create) {
+                MFM_MSG(SEV_FATAL, "DEVICE-NOT-SUPPORTED", "'%s' devices are not supported by this build.", type);
+                return NULL;
+            }
+            return &front_ends[i];
+        }
+    }
+    MFM_MSG(SEV_FATAL, "UNKNOWN-DEV-TYPE", "Unknown device type: '%s'", type);
+    return NULL;
+}
+
+/* unmute, start, and stay until the operator interrupts or the input runs out (a file does; the reference's loop only ends
+ * on SIGINT, multifm.c:163-165) */
+static int run_receiver(struct receiver *rx)
+{
+    TSL_BUG_IF_FAILED(receiver_set_mute(rx, false));
+    MFM_MSG(SEV_INFO, "CAPTURING", "Starting capture and demodulation process.");
+    if (FAILED(receiver_start(rx))) {
+        return EXIT_FAILURE;
+    }
+    while (!stop_requested && !rx->input_done) {
+        usleep(10000);
+    }
+    return EXIT_SUCCESS;
 }
 
 int main(int argc, const char *argv[])
 {
-    int ret = EXIT_FAILURE;
-    struct config *cfg = NULL;
-    struct config device = CONFIG_INIT_EMPTY;
-    struct receiver *rx_thr = NULL;
-    const char *dev_type = NULL;
-
     if (argc < 2) {
         fprintf(stderr, "usage: %s [Config File 1]{, Config File 2, ...} | %s -h\n", argv[0], argv[0]);
         return EXIT_FAILURE;
     }
-    TSL_BUG_IF_FAILED(config_new(&cfg));
-    for (int i = 1; i < argc; i++) {
-        if (FAILED(config_add(cfg, argv[i]))) {
-            MFM_MSG(SEV_FATAL, "MALFORMED-CONFIG", "Configuration file [%s] is malformed.", argv[i]);
-            goto done;
-        }
+    struct config *cfg = load_configuration(argc - 1, argv + 1);
+    if (NULL == cfg) {
+        return EXIT_FAILURE;
     }
-    signal(SIGINT, _on_sigint);
+    signal(SIGINT, on_sigint);
     signal(SIGPIPE, SIG_IGN); /* EPIPE is handled per channel (demod.c:95-105) */
 
-    if (FAILED(config_get(cfg, &device, "device"))) {
-        MFM_MSG(SEV_FATAL, "MALFORMED-CONFIG", "Configuration is missing 'device' stanza. Aborting.");
-        goto done;
+    int ret = EXIT_FAILURE;
+    struct receiver *rx = NULL;
+    const struct front_end *fe = find_front_end(cfg);
+    if (NULL != fe && !FAILED(fe->create(&rx, cfg))) {
+        ret = run_receiver(rx);
     }
-    if (FAILED(config_get_string(&device, &dev_type, "type"))) {
-        MFM_MSG(SEV_FATAL, "MALFORMED-CONFIG", "The 'device' stanza is missing a 'type' specification. Aborting.");
-        goto done;
-    }
-    if (!strncmp(dev_type, "file", 4)) {
-        if (FAILED(file_worker_thread_new(&rx_thr, cfg))) {
-            goto done;
-        }
-    } else if (!strncmp(dev_type, "rtlsdr", 6) || !strncmp(dev_type, "airspy", 6) || !strncmp(dev_type, "usrp", 4)) {
-        MFM_MSG(SEV_FATAL, "DEVICE-NOT-SUPPORTED", "'%s' devices are not supported by this build.", dev_type);
-        goto done;
-    } else {
-        MFM_MSG(SEV_FATAL, "UNKNOWN-DEV-TYPE", "Unknown device type: '%s'", dev_type);
-        goto done;
-    }
-
-    TSL_BUG_IF_FAILED(receiver_set_mute(rx_thr, false));
-    MFM_MSG(SEV_INFO, "CAPTURING", "Starting capture and demodulation process.");
-    if (FAILED(receiver_start(rx_thr))) {
-        goto done;
-    }
-    /* a file runs out; the reference's loop only ends on SIGINT (multifm.c:163-165) */
-    while (g_running && !rx_thr->input_done) {
-        usleep(10000);
-    }
-    ret = EXIT_SUCCESS;
-
-done:
-    if (NULL != rx_thr) {
-        receiver_cleanup(&rx_thr);
+    if (NULL != rx) {
+        receiver_cleanup(&rx);
     }
     config_delete(&cfg);
     return ret;
