@@ -46,13 +46,19 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #define MFM3_BARRIER_LATE 0 /* 1: A/B builds - the tile's barrier behind the epilogue instead of in front of it */
 #endif
 #ifndef MFM3_ROT4
-#define MFM3_ROT4 0 /* 1: rotator-table entries of 4 bytes (rr | ri << 16) instead of 8 ({(rr, -ri), (ri, rr)}): half the table
-                       bytes per output for two cheap and one expensive instruction per entry (the two dot-product operands are
-                       rebuilt in registers); must match mfm_engine.hip's table (mfm_rot_entry_bytes_v3) */
+#define MFM3_ROT4 1 /* rotator-table entries of 4 bytes (rr | ri << 16) instead of 8 ({(rr, -ri), (ri, rr)}; 0: A/B builds): half
+                       the table bytes per output for two cheap and one expensive instruction per entry (the two dot-product
+                       operands are rebuilt in registers).  At 1024 channels the tables are what misses L2 (each workgroup
+                       re-reads its 64 channels' periodic table parts every other tile while input and output stream
+                       through): 5.25 -> 2.21 GB per launch together with the stores' hint below, and 3 % faster
+                       (profiles/r04_traffic_1024ch.txt).  The engine builds what mfm_rot_entry_bytes_v3() says. */
 #endif
 #define MFM3_ES (MFM3_ROT4 ? 4u : 8u) /* bytes per rotator-table entry */
 #ifndef MFM3_NONTEMPORAL
-#define MFM3_NONTEMPORAL 0 /* A/B builds - bit 0: the image loads carry the non-temporal hint, bit 1: the PCM stores do */
+#define MFM3_NONTEMPORAL 2 /* bit 1: the PCM stores carry the non-temporal hint - the 8-byte stores of a tile leave L2 as whole
+                              lines instead of being written back piecemeal (WRITE_SIZE 1.23 x the PCM bytes without it,
+                              0.98 x with it) and stop pushing the rotator tables out; bit 0 (A/B builds): the image loads
+                              too - wrong, the slices of a chunk share the image through L2 (fetch + 40 %, 4 % slower) */
 #endif
 #ifndef MFM3_DIV_STEPS
 #define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
