@@ -1,5 +1,5 @@
 #!/bin/bash
-# library variant of the first-generation kernel file: tools/exp/snap1.sh <name> [extra hipcc flags]
+# snapshot the current first-generation kernel source as library variant <name>: tools/exp/snap1.sh <name> [extra hipcc flags]
 cd "$(dirname "$0")/../.."
 name=$1; shift
 B=tsl-sdr_amd/build

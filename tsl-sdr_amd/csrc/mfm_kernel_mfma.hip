@@ -35,6 +35,12 @@
  */
 #include <hip/hip_runtime.h>
 
+#ifndef MFM_M_NONTEMPORAL
+#define MFM_M_NONTEMPORAL 0 /* 1: A/B builds - the 2-byte PCM stores carry the non-temporal hint.  What helps the second generation's
+                               8-byte stores (mfm_kernel_v3.hip) is wrong here: 0.543 -> 0.861 ms at decimation 25, 0.282 -> 0.515 ms
+                               at the configs[4] share (profiles/r04_traffic_1024ch.txt) - a hinted 2-byte store is a fabric write
+                               of its own */
+#endif
 #include "mfm_kernel.h"
 #include "mfm_numerics.h"
 
@@ -775,7 +781,11 @@ __global__ __launch_bounds__(MFM_M_NT, mfm_m_waves_per_simd(KQ, KC, IN8)) void m
                     const uint32_t chn = ch0 + c;
                     const bool ok = col_ok && chn < L.nchan;
                     const uint32_t at = ok ? chn * L.out_stride + (uint32_t)rel : dump; /* fits 32 bits (engine checks) */
+#if MFM_M_NONTEMPORAL
+                    __builtin_nontemporal_store((int16_t)pcm[gq][c], reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + (at << 1)));
+#else
                     *reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + (at << 1)) = (int16_t)pcm[gq][c];
+#endif
                     if (DBG_IQ) {
                         *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + (at << 2)) = q[gq][c];
                     }
