@@ -267,7 +267,8 @@ gen_text = "\n".join(gen)
 open(os.path.join(P, "r04_summary.md"), "w").write(gen_text + "\n")
 
 # single values quoted in running text: <!--r04:KEY-->value<!--/r04-->
-d40v3, d40v1 = lines["multifm_d40"]["roofline"]["kernel_ms"], lines["multifm_d40_mfma1"]["roofline"]["kernel_ms"]
+d40v3 = lines.get("multifm_d40", {}).get("roofline", {}).get("kernel_ms", float("nan"))
+d40v1 = lines.get("multifm_d40_mfma1", {}).get("roofline", {}).get("kernel_ms", float("nan"))
 vals = {"ms_step": f"{head['ms_per_step']:.4f}", "kernel_ms": f"{head['roofline']['kernel_ms']:.4f}", "frac": f"{head['roofline']['frac']:.3f}",
         "gap_us": f"{(head['ms_per_step'] - head['roofline']['kernel_ms']) * 1e3:.1f}", "d40_v3": f"{d40v3:.4f}", "d40_v1": f"{d40v1:.4f}",
         "d40_gain": f"−{100 * (1 - d40v3 / d40v1):.0f} %"}
@@ -276,6 +277,52 @@ for key, a, b_ in (("cfg5", "cfg5_256", "cfg5_256_streamed"), ("t512", "t512_aut
         ra, rb = lines[a]["roofline"]["kernel_ms"], lines[b_]["roofline"]["kernel_ms"]
         vals[key + "_res"], vals[key + "_str"], vals[key + "_gain"] = f"{ra:.4f}", f"{rb:.4f}", f"−{100 * (1 - ra / rb):.0f} %"
         vals[key + "_mfma"] = f"{lines[a]['compute_roofline']['frac']:.2f}"
+# round 4's additions: block series, host-fed figures, overlap, issue ceiling, other geometries
+bs = head.get("block_series", {}).get("series", [])
+def _ser(blog, mode, key="frac"):
+    for row in bs:
+        if row.get("block_samples") == 1 << blog and isinstance(row.get(mode), dict) and key in row[mode]:
+            return row[mode][key]
+    return float("nan")
+vals.update({"s20_one": f"{_ser(20, 'per_block_one_stream'):.3f}", "s20_co": f"{_ser(20, 'coalesced'):.3f}",
+             "s22_one": f"{_ser(22, 'per_block_one_stream'):.3f}", "s22_co": f"{_ser(22, 'coalesced'):.3f}",
+             "traffic_ratio": f"{tr['ratio']:.3f}", "mfma_pct": f"{100 * mfma_frac:.0f}", "valu_pct": f"{100 * valu_frac3:.0f}",
+             "ceiling": f"{head['roofline']['frac'] / (mfma_frac + valu_frac3):.2f}"})
+if "overlap" in lines:
+    vals["ms_overlap"] = f"{lines['overlap']['ms_per_step']:.4f}"
+    vals["ms_step"] = f"{lines['default']['ms_per_step']:.4f}" if "default" in lines else vals["ms_step"]
+og = head.get("other_geometries", {})
+if "configs3_pocsag_d25" in og and "kernel_ms" in og["configs3_pocsag_d25"]:
+    vals["d25"] = f"{og['configs3_pocsag_d25']['kernel_ms']:.3f}"
+if "configs4_int16_share" in og and "kernel_ms" in og["configs4_int16_share"]:
+    vals["cfg5"] = f"{og['configs4_int16_share']['kernel_ms']:.3f}"
+if head.get("fp32_iq_path"):
+    vals["f32_frac"] = f"{head['fp32_iq_path']['frac']:.2f}"
+st = ["| block | mode | launches | us per block | input GSamp/s | of the HBM roof |", "|---|---|---|---|---|---|"]
+names = {"coalesced": "backlog gathered into launches of up to 2^26 samples, two streams", "per_block": "every block its own launch, two streams",
+         "coalesced_one_stream": "gathered, one stream", "per_block_one_stream": "every block its own launch, one stream (rounds 1-3)"}
+for row in bs:
+    for mode in ("coalesced", "coalesced_one_stream", "per_block", "per_block_one_stream"):
+        m = row.get(mode)
+        if isinstance(m, dict) and "frac" in m:
+            st.append(f"| 2^{row['block_samples'].bit_length() - 1} x {row['blocks']} | {names[mode]} | {m['launches']} | {m['us_per_block']:.2f} | "
+                      f"{m['input_msamp_per_s'] / 1e3:.1f} | **{m['frac']:.3f}** |")
+ee = head.get("end_to_end", {})
+st.append("")
+st.append(f"Host-fed (`end_to_end`, {ee.get('buffer_samples')}-sample buffers, {ee.get('buffers')} of them; PCIe both ways inside the figure):")
+st.append("")
+st.append("| mode | launches | us per buffer | input GSamp/s | H2D GB/s | D2H GB/s |")
+st.append("|---|---|---|---|---|---|")
+for mode, m in ee.items():
+    if isinstance(m, dict) and "input_msamp_per_s" in m:
+        st.append(f"| {mode} | {m['launches']} | {m['us_per_buffer']:.1f} | {m['input_msamp_per_s'] / 1e3:.2f} | {m['h2d_GBps']:.1f} | {m['d2h_GBps']:.1f} |")
+cba = cb.get("all_cores") if cb else None
+if cba:
+    st.append("")
+    st.append(f"CPU baseline on all cores (`cpu_baseline.all_cores`): {cba['value']:.0f} MSamp/s x channels on {cba['cores']} threads, {cba['channels']} channels.")
+series_text = "\n".join(st)
+open(os.path.join(P, "r04_block_series.md"), "w").write(series_text + "\n")
+
 # the exchange table of DESIGN.md section 7
 blk_mb = head["config"]["block_samples"] * 4 / 1e6
 xt = ["| channels per GPU | kernel per block | needed per peer (int16 / 8-bit) | broadcast (≈ 153 GB/s per GPU) | all-gather on 7 links (≈ 940 GB/s at N = 8) |",
@@ -294,8 +341,9 @@ for path in (os.path.join(P, "README.md"), os.path.join(R, "DESIGN.md")):
     if "<!-- r04:begin -->" not in s:
         print("no r04 markers in", path)
         continue
-    s = re.sub(r"<!-- r04:begin -->.*?<!-- r04:end -->", "<!-- r04:begin -->\n" + gen_text + "\n<!-- r04:end -->", s, flags=re.S)
+    s = re.sub(r"<!-- r04:begin -->.*?<!-- r04:end -->", lambda m: "<!-- r04:begin -->\n" + gen_text + "\n<!-- r04:end -->", s, flags=re.S)
     s = re.sub(r"<!-- r04x:begin -->.*?<!-- r04x:end -->", "<!-- r04x:begin -->\n" + xt_text + "\n<!-- r04x:end -->", s, flags=re.S)
+    s = re.sub(r"<!-- r04s:begin -->.*?<!-- r04s:end -->", lambda m: "<!-- r04s:begin -->\n" + series_text + "\n<!-- r04s:end -->", s, flags=re.S)
     for k, v in vals.items():
         s = re.sub(r"<!--r04:%s-->.*?<!--/r04-->" % k, "<!--r04:%s-->%s<!--/r04-->" % (k, v), s)
     open(path, "w").write(s)
