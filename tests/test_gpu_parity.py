@@ -27,6 +27,8 @@ def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_i
         eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
     eng.commit()
     variant = eng.stats()["kernel_variant"]
+    if kernel == "auto" and decim == 25 and len(taps) <= 150 and not want_iq and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
+        assert variant == 2, "decimation 25 without filtered IQ: the second-generation kernel on padded rows applies"
     if kernel == "dot2":
         assert variant == 0
     elif decim % 8 == 0 and len(taps) <= 128 and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
@@ -89,11 +91,12 @@ def test_reference_shaped_configs(pkg, ora, name, kernel):
     _check(pkg, ora, fs, decim, taps, offs, iq, 4096, gains=gains, kernel=kernel)
     if name == "pocsag_rtlsdr" and kernel != "dot2":
         # decimation 25 is not a multiple of 8: LDS rows padded from 50 to 64 bytes, zero taps over the padding
-        # (filter/direct_fir.c:328-417 has no restriction on the decimation; neither has the matrix kernel now)
+        # (filter/direct_fir.c:328-417 has no restriction on the decimation; neither have the matrix kernels): the second
+        # generation on its padded-row layout since round 4, the first generation when forced
         eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=4096, kernel=kernel)
         st = eng.stats()
         eng.close()
-        assert st["kernel_variant"] == 1
+        assert st["kernel_variant"] == (2 if kernel == "auto" else 1)
     if name == "multifm_1ch" and kernel == "auto":
         # etc/multifm.json, etc/multifm_1ch.json: decimation 40 - a multiple of 8, not of 32: the second-generation
         # kernel on its chunk-row LDS layout
@@ -306,9 +309,13 @@ def test_decimations_that_are_not_multiples_of_8_run_on_the_matrix_kernel(pkg, o
     eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 15, want_iq=False)
     st = eng.stats()
     eng.close()
-    assert st["kernel_variant"] == 1, st
+    # decimation 25 with up to 150 taps: the second generation on padded rows (round 4) - unless a channel wants its filtered
+    # IQ; every other decimation of this list: the first generation
+    assert st["kernel_variant"] == (2 if decim == 25 else 1), st
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, want_iq=(nch == 2))
     _check(pkg, ora, fs, decim, taps, offs, iq, 5000, want_iq=False)
+    if decim == 25:
+        _check(pkg, ora, fs, decim, taps, offs, iq, 7777, want_iq=False, kernel="mfma1")
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -624,7 +631,8 @@ def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom)
                     "d400_t512": (400, 512), "d7_t33": (7, 33),
                     # 7 / 5 / 5 k-steps of taps held in registers (one and two staging chunks per thread)
                     "d25_t170": (25, 170), "d30_t150": (30, 150), "d24_t140": (24, 140)}[geom]
-    variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128", "d40_t64") else 1  # d40: chunk-row layout
+    # d40: chunk-row layout; d25_t128: padded rows (round 4; 170 taps span seven rows and stay on the first generation)
+    variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128", "d40_t64", "d25_t128") else 1
     base_flags = pkg.binding.MFM_F_FORCE_MFMA_V1 if geom == "d96_t128_gen1" else 0
     taps = pkg.synth.design_lpf(ntaps, 9000.0, fs) * (3.0 if geom in ("d96_t512", "d7_t33") else 1.0)
     offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-9, 10)]

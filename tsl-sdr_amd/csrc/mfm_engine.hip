@@ -308,7 +308,7 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
         V.in8 = fmt == MFM_IN_RTLSDR_U8 ? 7u : 14u;
         V.in8_xor = fmt == MFM_IN_RTLSDR_U8 ? 0x80808080u : 0u;
         V.krow = e->d_krow8[fmt];
-        V.nstage4 = e->v_nstage4 / 2u;
+        V.nstage4 = 2u == e->v_layout ? (73u * 25u + 7u + 7u) / 8u : e->v_nstage4 / 2u;
         V.x_last4 = (2u * e->cap_in - 8u) & ~7u;
     }
 }
@@ -1083,6 +1083,25 @@ static int commit_locked(struct mfm_engine *e)
         }
     }
 
+    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && 25u == D && T <= 150u && !e->any_iq) {
+        /* decimation 25 (etc/pocsag_rtlsdr.json) on the second generation: rows of 50 plane bytes padded to 64, so that a k-step
+         * is exactly one row and a window of up to 150 taps spans six of them (layout 2, mfm_kernel.h); sub-planes at the fixed
+         * pitch, the image staged sample by sample.  The tap fragments are laid out for six k-steps. */
+        e->use_v3 = true;
+        e->v_layout = 2;
+        e->v_rs = 96u;
+        e->v_sp_pitch = 4096u;
+        e->v_nstage4 = (73u * 25u + 3u + 3u) / 4u; /* 16-byte chunks covering the image wherever it starts inside the first one */
+        e->v_lds_bytes = 16u * 4096u + 2048u + 4u * 512u * 4u + 1024u + 2048u;
+        e->v_wg_per_cu = 2u;
+        for (uint32_t k = 0; k < 4; k++) {
+            e->v_cross[k] = k;
+            e->v_within[k] = 0;
+        }
+        e->m_ks = 6u;
+        e->m_kq_used = 6u;
+    }
+
     /* ---- rotator classes and row order (filter/direct_fir.c:151-172,406-413).  An increment of exactly (16384, 0) - every
      *      channel whose offset is a multiple of the output rate, e.g. a 25 kHz grid at 2.4 MS/s / 96 - leaves the rotator at
      *      (16384, 0) for ever, and r14(f * 16384) = f: nothing to do.  An increment of (-16384, 0) - offsets at odd
@@ -1129,8 +1148,9 @@ static int commit_locked(struct mfm_engine *e)
         e->v_rc = std::min(e->v_rc, cls);
         e->rot_fast_slices += cls != MFM_RC_GENERAL ? 1u : 0u;
     }
-    if (!e->use_v3 || e->any_iq) {
-        e->v_rc = MFM_RC_GENERAL; /* the exact-rotator instances are built without the filtered-IQ output */
+    if (!e->use_v3 || e->any_iq || 2u == e->v_layout) {
+        e->v_rc = MFM_RC_GENERAL; /* the exact-rotator instances are built without the filtered-IQ output, and for the
+                                     sub-plane / chunk-row geometries only */
     }
 
     if (e->use_mfma) {

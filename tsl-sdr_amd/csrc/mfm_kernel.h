@@ -180,7 +180,11 @@ struct mfm_launch_v3 {
      * (D / 8) * g, so "lane n reads slot n (+ a constant) of row r" for every (g, k-step): 16 consecutive 16-byte cells,
      * conflict free, and the address is again lane register + wave-uniform constant.  Rows 0..2 of each slot are kept a
      * second time as rows t_per..t_per + 2 of the slot before, so that the four cells of a k-step (one per kg) never wrap. */
-    uint32_t layout;      /* 0: four sub-planes per byte plane (rs, sp_pitch, cross, within); 1: chunk rows (t_per, t_pitch) */
+    /* layout 2 - decimation 25 (etc/pocsag_rtlsdr.json): sub-planes as in layout 0, but a row is the 25 samples between two
+     * outputs (50 plane bytes) padded to 64, the taps carry zeros over the padding, a k-step is exactly one row and a window
+     * spans six of them (kq = 6).  The image is staged sample by sample (a 16-byte chunk of the input straddles rows). */
+    uint32_t layout;      /* 0: four sub-planes per byte plane (rs, sp_pitch, cross, within); 1: chunk rows (t_per, t_pitch);
+                             2: padded rows, decimation 25 */
     uint32_t t_per, t_pitch;
     uint32_t nslices, nrb;
     uint32_t ntiles;      /* ceil(n_new / 64) */

@@ -540,8 +540,13 @@ static constexpr uint32_t mfm3_row_stride(uint32_t decim)
 template <int DFIX>
 struct mfm3_geo {
     static constexpr uint32_t D = DFIX > 0 ? (uint32_t)DFIX : 32u;
-    static constexpr bool chunk_rows = (2u * D) % 64u != 0u;
-    static constexpr uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + (64u * 4u - 1u) / (2u * D); /* 128-tap class: four k-steps */
+    /* decimation 25 (etc/pocsag_rtlsdr.json): rows of 50 plane bytes padded to 64, the taps carry zeros over the padding
+     * (mfm_kernel.h, layout 2) - a k-step IS a row, a window spans six of them */
+    static constexpr bool padded = DFIX == 25;
+    static constexpr uint32_t row_bytes = padded ? 64u : 2u * D;
+    static constexpr bool chunk_rows = !padded && (2u * D) % 64u != 0u;
+    static constexpr uint32_t rows = padded ? MFM_V3_LEAD + MFM_V3_OT + 5u
+                                            : MFM_V3_LEAD + MFM_V3_OT + (64u * 4u - 1u) / (2u * D); /* 128-tap class: four k-steps */
     /* chunk rows */
     static constexpr uint32_t cpo = D / 8u, per = 4u * cpo;
     static constexpr uint32_t nchunks16 = (rows * 2u * D + 15u) / 16u;
@@ -549,7 +554,7 @@ struct mfm3_geo {
     static constexpr uint32_t pitch = pitch_a > pitch_b ? pitch_a : pitch_b;
     static constexpr uint32_t plane_t = ((per + 3u) * pitch * 16u + 63u) & ~63u;
     /* sub-planes */
-    static constexpr uint32_t rs = mfm3_row_stride(D), sp = 4096u;
+    static constexpr uint32_t rs = padded ? 96u : mfm3_row_stride(D), sp = 4096u;
     static constexpr uint32_t plane_pitch = chunk_rows ? plane_t : 4u * sp, buf_pitch = 2u * plane_pitch;
     /* byte offset (from the lane's base) of the B fragment of column group g, k-step kq */
     static constexpr uint32_t ofs(uint32_t g, uint32_t kq)
@@ -558,7 +563,7 @@ struct mfm3_geo {
             const uint32_t x = cpo * g + 4u * kq;
             return ((x % per) * pitch + 1u + x / per) * 16u;
         }
-        const uint32_t c = (64u * kq) / (2u * D), w = (64u * kq) % (2u * D);
+        const uint32_t c = (64u * kq) / row_bytes, w = (64u * kq) % row_bytes;
         return ((g + c) & 3u) * sp + (1u + ((g + c) >> 2)) * rs + w;
     }
 };
@@ -590,8 +595,10 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t kg = lane >> 4, n = lane & 15u;
-    const uint32_t D = DFIX ? (uint32_t)DFIX : L.decim, row_bytes = 2u * D;
     using G = mfm3_geo<DFIX>;
+    constexpr bool PADDED = DFIX != 0 && G::padded; /* decimation 25: 64-byte rows of 50 sample bytes, sample-wise staging */
+    constexpr uint32_t NCHS = PADDED ? 4u : (uint32_t)NCH; /* dwords of staging-offset table per thread (the engine sizes LDS) */
+    const uint32_t D = DFIX ? (uint32_t)DFIX : L.decim, row_bytes = PADDED ? 64u : 2u * D;
     const uint32_t rs = DFIX ? G::rs : L.rs;
     const uint32_t sp_pitch = DFIX ? G::sp : L.sp_pitch;
     const uint32_t plane_pitch = DFIX ? G::plane_pitch : L.plane_pitch, buf_pitch = DFIX ? G::buf_pitch : L.buf_pitch;
@@ -615,9 +622,29 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
     /* chunk-row layout: where the second copy of a chunk goes (rows 0..2 of a slot again behind the last row of the slot
      * before), or ~0 - behind the first table, only there when the layout is in use */
-    uint32_t *sta2_s = sta_s + NCH * MFM3_NT + 768u; /* behind the row constants, fold constants and exact-rotator table */
+    uint32_t *sta2_s = sta_s + NCHS * MFM3_NT + 768u; /* behind the row constants, fold constants and exact-rotator table */
+    /* decimation 25: a 16-byte chunk (4 samples; 8 as bytes) does not sit in one row, and where the tile's image starts in
+     * it depends on the launch (the first unconsumed sample is L.hist samples into the buffer): sample k of this thread's
+     * chunk is image sample C * tid + k - delta, delta = (L.hist - LEAD * D) mod C; its two plane bytes go to row i / 25,
+     * column 2 * (i % 25).  Eight 16-bit LDS offsets per thread (samples in front of or behind the image: a padding
+     * column nobody reads). */
+    uint16_t *sta16_s = reinterpret_cast<uint16_t *>(sta_s);
+    if constexpr (PADDED) {
+        constexpr int C = IN8 ? 8 : 4;
+        const int delta = ((int)L.hist - (int)(MFM_V3_LEAD * 25u)) & (C - 1);
 #pragma unroll
-    for (int j = 0; j < NCH; j++) {
+        for (int k = 0; k < C; k++) {
+            const int i = C * (int)tid + k - delta;
+            uint32_t off = 64u; /* behind the 64 bytes of row 0 that the fragments read */
+            if (i >= 0 && i < (int)(G::rows * 25u)) {
+                const uint32_t row = (uint32_t)i / 25u, col = ((uint32_t)i % 25u) * 2u;
+                off = (row & 3u) * sp_pitch + (row >> 2) * rs + col;
+            }
+            sta16_s[tid * 8u + (uint32_t)k] = (uint16_t)off;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH && !PADDED; j++) {
         const uint32_t p8 = (tid + (uint32_t)j * MFM3_NT) * (IN8 ? 16u : 8u); /* plane bytes in front of the chunk */
         if (chunk_rows) {
             const uint32_t sc = p8 >> 4, r = sc % t_per, c = sc / t_per;
@@ -635,6 +662,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
 #pragma unroll
     for (int kq = 0; kq < KQ; kq++) {
         const uint32_t c = DFIX ? (64u * kq) / row_bytes : L.cross[kq], w = DFIX ? (64u * kq) % row_bytes : L.within[kq];
+        static_assert(!PADDED || (KQ == 6 && NCH == 1), "decimation 25: six rows per window, one staging chunk per thread");
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             ofs[g][kq] = ((g + c) & 3u) * sp_pitch + (1u + ((g + c) >> 2)) * rs + w;
@@ -663,6 +691,9 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
          * taps.  Chunks past the image all read the tile's first line (one cache line per wave). */
         const uint32_t q = tid + (uint32_t)j * MFM3_NT;
         int gs = (int)(tile * MFM_V3_OT * D + L.hist) - (int)(MFM_V3_LEAD * D) + (IN8 ? 8 : 4) * (int)(q < L.nstage4 ? q : 0u);
+        if constexpr (PADDED) {
+            gs -= ((int)L.hist - (int)(MFM_V3_LEAD * 25u)) & ((IN8 ? 8 : 4) - 1); /* chunks are 16-byte aligned in the buffer */
+        }
         gs = gs < 0 ? 0 : gs;
         gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
 #if MFM3_NONTEMPORAL & 1
@@ -674,6 +705,33 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
 #endif
     };
     auto stage_store = [&](uint32_t buf, int j, const uint4 &v) {
+        if constexpr (PADDED) {
+            if (tid < L.nstage4) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(sta16_s + tid * 8u);
+                uint8_t *img = smem + buf * buf_pitch;
+                const uint32_t vv[4] = { v.x, v.y, v.z, v.w }, oo[4] = { o.x, o.y, o.z, o.w };
+                if (IN8) {
+                    const uint32_t m = L.in8_xor;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { /* two samples (two bytes each) per dword */
+                        const uint32_t w = vv[k] ^ m;
+                        *reinterpret_cast<uint16_t *>(img + (oo[k] & 0xffffu)) = (uint16_t)w;
+                        *reinterpret_cast<uint16_t *>(img + (oo[k] >> 16)) = (uint16_t)(w >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { /* one sample per dword: (I_lo, I_hi, Q_lo, Q_hi) */
+                        const uint32_t off = (k & 1) ? oo[k >> 1] >> 16 : oo[k >> 1] & 0xffffu;
+                        const uint32_t hi = __builtin_amdgcn_perm(vv[k], vv[k], 0x0c0c0301u);
+                        const uint32_t lo = __builtin_amdgcn_perm(vv[k], vv[k], 0x0c0c0200u) ^ 0x8080u;
+                        *reinterpret_cast<uint16_t *>(img + off) = (uint16_t)hi;
+                        *reinterpret_cast<uint16_t *>(img + off + plane_pitch) = (uint16_t)lo;
+                    }
+                }
+            }
+            (void)j;
+            return;
+        }
         if (IN8) {
             if (tid + (uint32_t)j * MFM3_NT < L.nstage4) {
                 const uint32_t m = L.in8_xor; /* 0x80808080: unsigned bytes -> int8 */
@@ -727,7 +785,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     mfm_v4i a_h[KQ], a_l[KQ];
     /* 128 * sum(W) + 8192 of the wave's 16 rows: 64 bytes of LDS per wave (read back as the initial value of the low
      * accumulator of every column group; four registers that need not be live through the epilogue) */
-    mfm_v4i *krow_s = reinterpret_cast<mfm_v4i *>(smem + L.sta_off + NCH * MFM3_NT * 4u) + wave * 4u + kg;
+    mfm_v4i *krow_s = reinterpret_cast<mfm_v4i *>(smem + L.sta_off + NCHS * MFM3_NT * 4u) + wave * 4u + kg;
     uint32_t slice_loaded = 0xffffffffu;
     {
         uint4 v[NCH];
@@ -779,10 +837,10 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
      * (same-box A/B against the static form, profiles/r02_bench_table.txt's run). */
     const int prio_matrix = wave >= 4 ? 1 : 0;
     /* behind them, per (wave, kg, channel of the lane): {byte offset of table position mu + lam, 8 * lam} */
-    uint2 *fold_s = reinterpret_cast<uint2 *>(smem + L.sta_off + NCH * MFM3_NT * 4u + 512u) + (wave * 4u + kg) * 2u;
+    uint2 *fold_s = reinterpret_cast<uint2 *>(smem + L.sta_off + NCHS * MFM3_NT * 4u + 512u) + (wave * 4u + kg) * 2u;
     /* behind them, per (wave, kg): exact rotators in their general form - per channel of the lane four byte selectors and
      * four sign words, one per column group (2 KB) */
-    uint32_t *xq_s = reinterpret_cast<uint32_t *>(smem + L.sta_off + NCH * MFM3_NT * 4u + 1024u) + (wave * 4u + kg) * 16u;
+    uint32_t *xq_s = reinterpret_cast<uint32_t *>(smem + L.sta_off + NCHS * MFM3_NT * 4u + 1024u) + (wave * 4u + kg) * 16u;
     uint32_t cur = 0;
     bool first_of_chunk = true;
 
@@ -1435,6 +1493,34 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
     /* decimation 40 (etc/multifm.json, etc/multifm_1ch.json at 1 MS/s) with the engine's chunk-row numbers */
     const bool geo40 = L->layout == 1u && L->t_per == mfm3_geo<40>::per && L->t_pitch == mfm3_geo<40>::pitch &&
                        L->plane_pitch == mfm3_geo<40>::plane_pitch && L->buf_pitch == mfm3_geo<40>::buf_pitch;
+    if (L->layout == 2u) {
+        /* decimation 25 (etc/pocsag_rtlsdr.json) on padded rows: fixed geometry, six k-steps; instances by which k-steps carry a
+         * high-byte tap plane (a mask that is a subset of an instance's runs on it: a zero plane multiplies zeros) */
+        if (dbg_iq || L->decim != 25u || L->kq != 6u || L->rs != mfm3_geo<25>::rs || L->sp_pitch != mfm3_geo<25>::sp) {
+            return hipErrorInvalidValue;
+        }
+#define MFM3_LAUNCH_25(IN8_)                                                                                 \
+    do {                                                                                                     \
+        if ((L->ah_mask & ~0x4u) == 0u) {                                                                    \
+            MFM3_LAUNCH_F(6, false, 1, 0x4, 25, IN8_);                                                       \
+        } else if ((L->ah_mask & ~0xeu) == 0u) {                                                             \
+            MFM3_LAUNCH_F(6, false, 1, 0xe, 25, IN8_);                                                       \
+        } else {                                                                                             \
+            MFM3_LAUNCH_F(6, false, 1, -1, 25, IN8_);                                                        \
+        }                                                                                                    \
+    } while (0)
+        if (L->in8 == 7u) {
+            MFM3_LAUNCH_25(7);
+        } else if (L->in8 == 14u) {
+            MFM3_LAUNCH_25(14);
+        } else if (L->in8 == 0u) {
+            MFM3_LAUNCH_25(0);
+        } else {
+            return hipErrorInvalidValue;
+        }
+#undef MFM3_LAUNCH_25
+        return hipSuccess;
+    }
     if (L->in8) {
         if (dbg_iq || nch > 4 || (L->in8 != 7u && L->in8 != 14u)) {
             return hipErrorInvalidValue;
