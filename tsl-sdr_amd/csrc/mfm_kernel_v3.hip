@@ -60,6 +60,9 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
                               0.98 x with it) and stop pushing the rotator tables out; bit 0 (A/B builds): the image loads
                               too - wrong, the slices of a chunk share the image through L2 (fetch + 40 %, 4 % slower) */
 #endif
+#ifndef MFM3_EPI_SERIAL
+#define MFM3_EPI_SERIAL 0
+#endif
 #ifndef MFM3_DIV_STEPS
 #define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
 #endif
@@ -1344,9 +1347,15 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         }
                     }
                 }
+#if MFM3_EPI_SERIAL
+                /* A/B builds: the second channel's epilogue strictly behind the first's (rounds 2-3: a scheduling barrier kept
+                 * the register pressure down).  Without it the compiler interleaves the two dependent chains - the division
+                 * of one under the table reads of the other - at the same 128 registers: 1.5 % faster
+                 * (profiles/r04_ab_epilogue_interleave.txt) */
                 if (c == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
             }
             /* nothing is carried to the next launch: it recomputes the output in front of it and folds its own
              * rotator position (mfm_launch_v3::hist, ::k_base) */
