@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--overlap", action="store_true", help="MFM_F_OVERLAP: consecutive launches on two compute streams")
+    ap.add_argument("--input", choices=["cs16", "rtlsdr_u8"], default="cs16",
+                    help="rtlsdr_u8: the wideband block is 8-bit IQ as an RTL-SDR delivers it (multifm/rtl_sdr_if.c:146-148); the matrix "
+                         "kernel reads the bytes and, at N > 1, the exchange moves half the bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the float32-IQ comparison line")
     ap.add_argument("--no-chain", action="store_true", help="skip the device-resident FLEX chain line")
@@ -121,10 +124,16 @@ def verify_last_block(pkg, eng, fs, decim, taps, offs, gains, outputs_before):
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     T = len(taps)
     iptr, n_avail, fmt = eng.last_launch_input()
-    assert fmt == 0 and nout == (n_avail - T) // decim + 1, (nout, n_avail, fmt)
-    host_in = np.empty((n_avail, 2), np.int16)
-    if hip.hipMemcpy(host_in.ctypes.data, C.c_void_p(iptr), 4 * n_avail, 2) != 0:
-        raise SystemExit("hipMemcpy of the last launch's input failed")
+    assert nout == (n_avail - T) // decim + 1, (nout, n_avail, fmt)
+    if fmt == 0:
+        host_in = np.empty((n_avail, 2), np.int16)
+        if hip.hipMemcpy(host_in.ctypes.data, C.c_void_p(iptr), 4 * n_avail, 2) != 0:
+            raise SystemExit("hipMemcpy of the last launch's input failed")
+    else:
+        raw = np.empty((n_avail, 2), np.uint8)
+        if hip.hipMemcpy(raw.ctypes.data, C.c_void_p(iptr), 2 * n_avail, 2) != 0:
+            raise SystemExit("hipMemcpy of the last launch's input failed")
+        host_in = ora.unpack_bytes(raw, fmt).reshape(-1, 2)  # widened as the reference's front end widens it on the host
     chans = sorted(set(int(round(k * (len(offs) - 1) / 3)) for k in range(4)))
     wins = sorted(set([1, max(1, nout // 2 - 512), max(1, nout - 1024)]))
     bad, checked = 0, 0
@@ -607,12 +616,21 @@ def main():
     eng.commit()
 
     # synthetic wideband IQ, resident in HBM before the timed region (rank 0 is the ingest GPU)
+    in8 = args.input == "rtlsdr_u8"
     if rank == 0:
         base = pkg.synth.synth_iq(1 << 22, fs, all_offs[:: max(1, total_ch // 8)][:8], seed=7)
-        reps = -(-(in_bytes // 4) // base.shape[0])
-        host = np.tile(base, (reps, 1))[: in_bytes // 4].reshape(-1)
-        for b in bufs:
-            b.copy_(torch.from_numpy(host))
+        if in8:
+            # what the dongle would have delivered for this signal: unsigned bytes, 127 = zero
+            u8 = np.clip((base.astype(np.int32) >> 7) + 127, 0, 255).astype(np.uint8)
+            reps = -(-(in_bytes // 2) // u8.shape[0])
+            host8 = np.tile(u8, (reps, 1))[: in_bytes // 2].reshape(-1)
+            for b in bufs:
+                b.view(torch.uint8)[: host8.size].copy_(torch.from_numpy(host8))
+        else:
+            reps = -(-(in_bytes // 4) // base.shape[0])
+            host = np.tile(base, (reps, 1))[: in_bytes // 4].reshape(-1)
+            for b in bufs:
+                b.copy_(torch.from_numpy(host))
     torch.cuda.synchronize()
 
     # the exchange step: scatter + all-gather by default (tsl-sdr_amd/dist.py; DESIGN.md section 7: a broadcast delivers at
@@ -621,11 +639,12 @@ def main():
     exchange = pkg.dist.BlockExchange(src=0, algo=os.environ.get("MFM_EXCHANGE", "scatter_allgather")) if use_dist else None
 
     def step():
-        ptr, cap = eng.acquire_input()
+        ptr, cap = eng.acquire_input_bytes(pkg.binding.MFM_IN_RTLSDR_U8) if in8 else eng.acquire_input()
         which = 0 if ptr < bufs[0].data_ptr() + in_bytes and ptr >= bufs[0].data_ptr() else 1
         off = (ptr - bufs[which].data_ptr()) // 2
         if use_dist:
-            view = bufs[which][off: off + 2 * block]
+            # int16 elements of the view: 2 per sample, 1 per sample when the block travels as bytes
+            view = bufs[which][off: off + (block if in8 else 2 * block)]
             if exchange.algo == "auto":
                 exchange.choose(view, sync=torch.cuda.synchronize)
             exchange.run(view)
@@ -679,7 +698,7 @@ def main():
     k_ms = (st1["kernel_ms"] - st0["kernel_ms"]) / max(1, timed)
     per_launch = np.sort(eng.launch_ms(min(int(timed), 4096)).astype(np.float64))
     outs = (st1["outputs"] - st0["outputs"]) / max(1, launches)
-    bytes_per_launch = block * 4 + len(offs) * outs * 2        # 4 + 2*C_g/D bytes per input sample
+    bytes_per_launch = block * (2 if in8 else 4) + len(offs) * outs * 2  # 4 (2 as bytes) + 2*C_g/D bytes per input sample
     dot2_per_launch = 2.0 * len(offs) * T * outs               # two v_dot2 lane-ops per complex tap per output
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
     mfma = st1["kernel_variant"] >= 1
@@ -707,7 +726,7 @@ def main():
     traffic, traffic_source = None, None
     for rnd in ("r04", "r03", "r02"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
-        if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and \
+        if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and not in8 and \
                 args.config == "cfg2_64ch" and os.path.exists(tpath):
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             traffic_source = f"profiles/{rnd}_hbm_traffic.json (rocprofv3 --pmc passes of this command, not this run)"
@@ -720,7 +739,7 @@ def main():
     ceiling = None
     ipath = os.path.join(ROOT, "profiles", "r04_issue_model.json")
     if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and args.config == "cfg2_64ch" and \
-            os.path.exists(ipath) and not args.overlap:
+            os.path.exists(ipath) and not args.overlap and not in8:
         im = json.load(open(ipath))
         ceiling = {"ceiling_frac": achieved / HBM_PEAK_GBPS / im["busy_fraction_3cycle"], "simd_busy_fraction": im["busy_fraction_3cycle"],
                    "mfma_busy_cycles_per_simd": im["mfma_busy_cycles_per_simd"], "valu_cycles_per_simd": im["valu_cycles_per_simd_at_3"],
@@ -739,7 +758,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16", "data": "synthetic",
+            "dtype": "int16" if not in8 else "int16 (8-bit input read as bytes)", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cpg} FM channels per GPU ({total_ch} total), {T}-tap 25 kHz LPF, "
                                    f"decimation {decim}, fs {fs} Hz-shaped int16 IQ, block 2^{args.block_log2} samples",
                        "channels_per_gpu": cpg, "channels_total": total_ch, "block_samples": block,
@@ -766,14 +785,15 @@ def main():
             # as the GPUs take them, so this - not the kernel - is what an N > 1 line is usually bound by (a live
             # 2.4 MS/s stream is 10 MB/s).  xGMI: 7 links x ~153 GB/s per GPU, point to point.
             "exchange": None if not use_dist else {
-                "algo": exchange.algo, "algo_timings_s": exchange.timings, "bytes_per_step_per_peer": block * 4, "peers": world - 1,
+                "algo": exchange.algo, "algo_timings_s": exchange.timings, "bytes_per_step_per_peer": block * (2 if in8 else 4),
+                "peers": world - 1,
                 # what every peer would have to receive for the exchange to hide behind the kernel (a step then costs
                 # max(exchange, kernel)): one block per kernel time
-                "needed_GBps_per_peer": block * 4 / (k_ms * 1e-3) / 1e9,
-                "delivered_GBps_per_peer": block * 4 / (dt / args.steps) / 1e9,
+                "needed_GBps_per_peer": block * (2 if in8 else 4) / (k_ms * 1e-3) / 1e9,
+                "delivered_GBps_per_peer": block * (2 if in8 else 4) / (dt / args.steps) / 1e9,
                 # does the exchange hide behind the kernel (a step costs max(exchange, kernel))?
                 "hidden": bool(dt / args.steps <= 1.1 * k_ms * 1e-3),
-                "delivered_GBps_total": block * 4 * (world - 1) / (dt / args.steps) / 1e9,
+                "delivered_GBps_total": block * (2 if in8 else 4) * (world - 1) / (dt / args.steps) / 1e9,
                 "xgmi_link_peak_GBps": 153.0, "xgmi_links_per_gpu": 7},
             "geometry": {"outputs_per_tile": st1["outputs_per_tile"], "lds_bytes": st1["lds_bytes"],
                          "grid": st1["grid_last"], "rot_table_entries": st1["rot_table_entries"],

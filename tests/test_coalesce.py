@@ -351,3 +351,37 @@ def test_pushes_out_of_page_locked_memory_with_copy_tickets(pkg, ora, coalesce):
     want, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
     got = np.concatenate([p[1] for p in parts], axis=1)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("geoms,kernel", [(((48, 64), (56, 64)), "auto"), (((25, 128), (30, 128), (12, 40)), "mfma1"),
+                                          (((96, 128), (96, 100), (32, 32)), "auto")])
+def test_two_engines_sharing_a_kernel_instance_keep_their_lds(pkg, ora, geoms, kernel):
+    """the dynamic-LDS limit belongs to a kernel instance on a device, not to an engine.  Engines whose
+    geometries select the same template instance with different LDS sizes (the generic second-generation instances for
+    decimations 48 and 56; first-generation instances at different decimations) live side by side, the one that needs less
+    committed LAST - the limit is only ever raised, so the first engine's launches still fit; all of them against the oracle,
+    interleaved."""
+    b = pkg.binding
+    fs = 1200000
+    flags = b.MFM_F_FORCE_MFMA_V1 if kernel == "mfma1" else 0
+    engs = []
+    for decim, ntaps in sorted(geoms, key=lambda g: -g[0]):      # the largest image first, the smallest last
+        taps = pkg.synth.design_lpf(ntaps, 9000.0, fs)
+        offs = [12345, -250000, 100000, 37500, 0]
+        eng = pkg.Engine(fs, decim, 1 << 15, device=0, flags=flags)
+        for o in offs:
+            eng.add_channel(int(o), taps, 1.0)
+        eng.commit()
+        iq = pkg.synth.synth_iq(decim * 700 + ntaps + 5, fs, offs[:3], seed=decim)
+        engs.append((eng, decim, taps, offs, iq))
+    for rnd in range(2):
+        for eng, decim, taps, offs, iq in engs:
+            eng.reset()
+            pcm, _ = eng.run(iq, 9000)
+            cre = np.stack([eng.get_channel(c)[0] for c in range(len(offs))])
+            cim = np.stack([eng.get_channel(c)[1] for c in range(len(offs))])
+            incr = np.stack([eng.get_channel(c)[2] for c in range(len(offs))])
+            ref, _ = ora.run_channels(iq, cre, cim, incr, decim)
+            assert pcm.shape == ref.shape and np.array_equal(pcm, ref), (decim, rnd)
+    for eng, *_ in engs:
+        eng.close()

@@ -274,3 +274,18 @@ def test_bench_runs_its_distributed_path_on_one_rank(pkg):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
     assert line["verified"] is True and line["exchange"]["needed_GBps_per_peer"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_exchanges_8bit_blocks_as_bytes(pkg):
+    """bench.py --input rtlsdr_u8 on its distributed path (one rank): the block lies in the engine's buffer as the bytes an
+    RTL-SDR delivers, the exchange moves 2 bytes per sample instead of 4, the matrix kernel reads the bytes, and the line's
+    self-check widens the launch's input as multifm/rtl_sdr_if.c:146-148 does before it asks the oracle."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--settle-seconds", "0", "--no-cpu-baseline", "--no-fp32", "--no-chain", "--no-series", "--block-log2", "22",
+                        "--input", "rtlsdr_u8"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["verified"] is True and line["exchange"]["bytes_per_step_per_peer"] == 2 << 22
+    assert line["roofline"]["bytes_per_launch"] < 4 << 22

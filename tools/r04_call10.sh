@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, tenth GPU call: the two channels of a lane's epilogue interleaved by the compiler (no scheduling barrier between them)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04j; rm -rf $O; mkdir -p $O
+O=gpurun_out/r04k; rm -rf $O; mkdir -p $O
 summ() { python3 - "$1" <<'PY'
 import json,sys
 try:
@@ -13,13 +13,13 @@ PY
 }
 B="--no-cpu-baseline --no-fp32 --no-chain --no-series"
 for rep in 1 2 3; do
-  for v in base epi; do
+  for v in base maxilp maxmem iter; do
     L=""; [ $v != base ] && L=$PWD/tools/exp/libexp_$v.so
     MFM_LIB=$L timeout 300 python bench.py $B --steps 200 --warmup 10 > $O/c64_${v}_$rep.json 2> $O/c64_${v}_$rep.err; summ $O/c64_${v}_$rep.json
   done
 done
-for rep in 1 2; do
-  for v in base epi; do
+for rep in; do
+  for v in base maxilp maxmem iter; do
     L=""; [ $v != base ] && L=$PWD/tools/exp/libexp_$v.so
     MFM_LIB=$L timeout 300 python bench.py $B --steps 60 --warmup 5 --config pocsag_rtlsdr --channels-per-gpu 64 > $O/d25_${v}_$rep.json 2> $O/d25_${v}_$rep.err; summ $O/d25_${v}_$rep.json
   done
