@@ -398,8 +398,9 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
     mfm_group_push (staging in pinned memory, H2D, one device group of one GPU) -> kernel -> PCM mirrored to pinned host
     memory -> mfm_group_fetch / release, with the group gathering up to a pool's worth of buffers (128, demod.c:297) per
     launch as the C host configures it.  `pinned_pool`: the buffers are page-locked like the C host's pool and the H2D reads
-    them in place (mfm_group_push_pinned); `staged_copy`: pageable buffers through the engine's staging copy.  The producer
-    is this Python loop (one ctypes call per buffer).  PCIe inclusive; never `value`."""
+    them in place (mfm_group_push_pinned); `staged_copy`: pageable buffers through the engine's staging copy.  `c_loop`: the
+    producer loop in C (mfm_group_replay_pinned), otherwise a Python loop (one ctypes call per buffer).  PCIe inclusive; never
+    `value`."""
     b = pkg.binding
     out = {"buffer_samples": buf_samples, "buffers": nr_bufs,
            "path": "host buffer -> mfm_group_push -> H2D -> kernel -> D2H -> mfm_group_fetch/release"}
@@ -413,7 +414,10 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
         if not ptr:
             return {"error": "mfm_host_alloc failed"}
         ctypes.memmove(ptr, data[k].ctypes.data, buf_samples * 4)
-    for mode, co, pin in (("pinned_pool_coalesced_128_buffers", 128 * buf_samples, True),
+    arr = (ctypes.c_void_p * 8)(*pinned)
+    for mode, co, pin in (("c_loop_pinned_pool_coalesced_128_buffers", 128 * buf_samples, "c"),
+                          ("c_loop_pinned_pool_launch_per_buffer", 0, "c"),
+                          ("pinned_pool_coalesced_128_buffers", 128 * buf_samples, True),
                           ("pinned_pool_launch_per_buffer", 0, True), ("staged_copy_coalesced_128_buffers", 128 * buf_samples, False)):
         try:
             grp = b.Group(fs, decim, buf_samples, devices=(0,), coalesce_samples=co)
@@ -439,6 +443,13 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
                 return grp.push(data[i & 7])
 
             def run(nbuf):
+                if pin == "c":
+                    # the producer loop in C (mfm_group_replay_pinned): push, fetch / release when the rings are full, flush + drain
+                    got = ctypes.c_uint64()
+                    rc = lib.mfm_group_replay_pinned(grp.h, arr, 8, buf_samples, b.MFM_IN_CS16, nbuf, ctypes.byref(got))
+                    if rc != 0:
+                        raise RuntimeError(f"mfm_group_replay_pinned: {rc} {lib.mfm_last_error()}")
+                    return got.value
                 outs = 0
                 for i in range(nbuf):
                     while True:

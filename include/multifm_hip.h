@@ -342,6 +342,11 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
 /* the same out of page-locked memory (mfm_host_alloc), without the staging copy: as mfm_engine_push_pinned() */
 int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_samples, int format, uint64_t *ticket);
 int mfm_group_copy_done(struct mfm_group *g, uint64_t ticket);
+/* A host loop in C, for measurements (bench.py end_to_end): nr_pushes buffers of buf_samples samples, taken in turn from the
+ * caller's nr_bufs page-locked buffers, pushed with mfm_group_push_pinned(); blocks are fetched and released whenever the
+ * output rings are full, everything is flushed and drained at the end.  *outputs_per_channel = outputs fetched. */
+int mfm_group_replay_pinned(struct mfm_group *g, const void *const *bufs, size_t nr_bufs, size_t buf_samples, int format,
+                            size_t nr_pushes, uint64_t *outputs_per_channel);
 int mfm_group_copy_wait(struct mfm_group *g, uint64_t ticket);
 /* oldest finished block of every shard into blks[0 .. nr_shards); MFM_E_DONE when nothing is pending */
 int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks);

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mfm_engine_input_bytes", "mfm_engine_input_bytes_cfg", "mfm_engine_flush", "mfm_engine_replay", "mfm_group_flush",
     "mfm_engine_last_launch_input", "mfm_engine_seek", "mfm_devtest_discriminate",
     "mfm_host_alloc", "mfm_host_free", "mfm_engine_push_pinned", "mfm_engine_copy_done", "mfm_engine_copy_wait",
-    "mfm_group_push_pinned", "mfm_group_copy_done", "mfm_group_copy_wait",
+    "mfm_group_push_pinned", "mfm_group_copy_done", "mfm_group_copy_wait", "mfm_group_replay_pinned",
     "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
     "mfm_engine_add_channel_q14", "mfm_engine_get_channel", "mfm_engine_commit", "mfm_engine_acquire_input",
     "mfm_engine_acquire_input_bytes",
@@ -185,6 +185,7 @@ def load_library():
     lib.mfm_engine_copy_wait.argtypes = [vp, C.c_uint64]
     lib.mfm_group_push_pinned.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
     lib.mfm_group_copy_done.argtypes = [vp, C.c_uint64]
+    lib.mfm_group_replay_pinned.argtypes = [vp, C.POINTER(vp), C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_uint64)]
     lib.mfm_group_copy_wait.argtypes = [vp, C.c_uint64]
     lib.mfm_engine_last_launch_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     lib.mfm_group_flush.argtypes = [vp]

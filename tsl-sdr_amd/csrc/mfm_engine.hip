@@ -40,6 +40,7 @@ extern "C" hipError_t mfm_disc_test_mfma(const int *s_re, const int *s_im, int *
 extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pcm, uint32_t n, const float2 *lut, hipStream_t stream);
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out);
 extern "C" uint32_t mfm_rot_entry_bytes_v3(void);
+extern "C" uint32_t mfm_sp_pitch_v3(void);
 extern "C" hipError_t mfm_launch_channel_kernel_v3(const void *kfn, const mfm_launch_v3 *L, uint32_t lds_bytes, uint32_t grid,
                                                    hipStream_t stream);
 
@@ -1065,7 +1066,7 @@ static int commit_locked(struct mfm_engine *e)
         const uint32_t rows = MFM_V3_LEAD + MFM_V3_OT + extra;
         const uint32_t sr = (rows + 3u) / 4u;
         uint32_t sp = sr * rs_v;
-        sp = sp <= 4096u ? 4096u : (sp + 63u) & ~63u;
+        sp = sp <= mfm_sp_pitch_v3() ? mfm_sp_pitch_v3() : (sp + 63u) & ~63u;
         const uint32_t nstage4 = rows * D / 4u; /* D % 16 == 0 here */
         const uint32_t nch = (nstage4 + 511u) / 512u;
         const uint32_t lds = 16u * sp + 2048u + nch * 512u * 4u + 1024u + 2048u; /* image, atan table, staging offsets, row constants + fold constants, exact-rotator table */
@@ -1090,9 +1091,9 @@ static int commit_locked(struct mfm_engine *e)
         e->use_v3 = true;
         e->v_layout = 2;
         e->v_rs = 96u;
-        e->v_sp_pitch = 4096u;
+        e->v_sp_pitch = mfm_sp_pitch_v3();
         e->v_nstage4 = (73u * 25u + 3u + 3u) / 4u; /* 16-byte chunks covering the image wherever it starts inside the first one */
-        e->v_lds_bytes = 16u * 4096u + 2048u + 4u * 512u * 4u + 1024u + 2048u;
+        e->v_lds_bytes = 16u * mfm_sp_pitch_v3() + 2048u + 4u * 512u * 4u + 1024u + 2048u;
         e->v_wg_per_cu = 2u;
         for (uint32_t k = 0; k < 4; k++) {
             e->v_cross[k] = k;

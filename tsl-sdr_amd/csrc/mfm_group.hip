@@ -500,6 +500,62 @@ int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_sampl
     return rc;
 }
 
+/* A host loop in C, for measurements: nr_pushes buffers of buf_samples samples each, taken in turn from the caller's nr_bufs
+ * page-locked buffers, through mfm_group_push_pinned(); whenever a push finds the output rings full a block is fetched and
+ * released (its PCM has reached host memory by then), and at the end everything is flushed and drained.  What this repo's C
+ * host does with two threads, in one - without a scripting language's call overhead between the buffers. */
+int mfm_group_replay_pinned(struct mfm_group *g, const void *const *bufs, size_t nr_bufs, size_t buf_samples, int format,
+                            size_t nr_pushes, uint64_t *outputs_per_channel)
+{
+    if (!g || !bufs || 0 == nr_bufs || !g->committed) {
+        return gfail(MFM_E_INVAL, "bad argument");
+    }
+    std::vector<mfm_block> blks(g->eng.size());
+    uint64_t outs = 0;
+    auto drain_one = [&]() -> int {
+        const int rc = mfm_group_fetch(g, blks.data());
+        if (rc != MFM_OK) {
+            return rc;
+        }
+        outs += blks[0].nr_outputs;
+        return mfm_group_release(g);
+    };
+    for (size_t i = 0; i < nr_pushes; i++) {
+        for (;;) {
+            const int rc = mfm_group_push_pinned(g, bufs[i % nr_bufs], buf_samples, format, nullptr);
+            if (rc == MFM_OK) {
+                break;
+            }
+            if (rc != MFM_E_BUSY) {
+                return rc;
+            }
+            const int dr = drain_one();
+            if (dr != MFM_OK) {
+                return dr == MFM_E_DONE ? gfail(MFM_E_STATE, "output rings full and nothing to fetch") : dr;
+            }
+        }
+    }
+    for (;;) {
+        const int frc = mfm_group_flush(g);
+        if (frc != MFM_OK && frc != MFM_E_BUSY) {
+            return frc;
+        }
+        int dr;
+        while ((dr = drain_one()) == MFM_OK) {
+        }
+        if (dr != MFM_E_DONE) {
+            return dr;
+        }
+        if (frc == MFM_OK) {
+            break;
+        }
+    }
+    if (outputs_per_channel) {
+        *outputs_per_channel = outs;
+    }
+    return MFM_OK;
+}
+
 int mfm_group_copy_done(struct mfm_group *g, uint64_t ticket)
 {
     return (g && g->committed) ? mfm_engine_copy_done(g->eng[0], ticket) : gfail(MFM_E_STATE, "commit first");

@@ -60,6 +60,10 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
                               0.98 x with it) and stop pushing the rotator tables out; bit 0 (A/B builds): the image loads
                               too - wrong, the slices of a chunk share the image through L2 (fetch + 40 %, 4 % slower) */
 #endif
+#ifndef MFM3_SP
+#define MFM3_SP 4096u /* bytes between the four sub-planes of a byte plane at the fixed geometries (A/B builds: 4160 - not a
+                         multiple of the LDS bank cycle, so that the image stores of rows r and r + 1 do not meet in one bank) */
+#endif
 #ifndef MFM3_EPI_SERIAL
 #define MFM3_EPI_SERIAL 0
 #endif
@@ -557,7 +561,7 @@ struct mfm3_geo {
     static constexpr uint32_t pitch = pitch_a > pitch_b ? pitch_a : pitch_b;
     static constexpr uint32_t plane_t = ((per + 3u) * pitch * 16u + 63u) & ~63u;
     /* sub-planes */
-    static constexpr uint32_t rs = padded ? 96u : mfm3_row_stride(D), sp = 4096u;
+    static constexpr uint32_t rs = padded ? 96u : mfm3_row_stride(D), sp = MFM3_SP;
     static constexpr uint32_t plane_pitch = chunk_rows ? plane_t : 4u * sp, buf_pitch = 2u * plane_pitch;
     /* byte offset (from the lane's base) of the B fragment of column group g, k-step kq */
     static constexpr uint32_t ofs(uint32_t g, uint32_t kq)
@@ -1486,7 +1490,7 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
 #define MFM3_LAUNCH_8K(IN8_)                                                                                 \
     do {                                                                                                     \
         if (L->decim == 96 && L->kq == 4 && nch == 2 && L->ah_mask == 0x6u && L->rs == mfm3_row_stride(96) &&      \
-            L->sp_pitch == 4096u) {                                                                          \
+            L->sp_pitch == MFM3_SP) {                                                                        \
             MFM3_LAUNCH_RC(4, 2, 0x6, 96, IN8_);                                                             \
         } else if (L->decim == 40 && L->kq == 4 && nch == 1 && L->ah_mask == 0x6u && geo40) {                \
             MFM3_LAUNCH_F(4, false, 1, 0x6, 40, IN8_);                                                       \
@@ -1545,7 +1549,7 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
      * outer k-steps fit one byte) with every address a compile-time constant */
 #ifndef MFM3_NO_FIX
     if (L->decim == 96 && L->kq == 4 && nch == 4 && !dbg_iq && L->ah_mask == 0x6u && L->rs == mfm3_row_stride(96) &&
-        L->sp_pitch == 4096u) {
+        L->sp_pitch == MFM3_SP) {
         MFM3_LAUNCH_RC(4, 4, 0x6, 96, 0);
         return hipSuccess;
     }
@@ -1574,6 +1578,12 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
 #undef MFM3_LAUNCH_F
 #undef MFM3_LAUNCH
     return hipSuccess;
+}
+
+/* the sub-plane pitch the fixed-geometry instances of this kernel file are built for */
+extern "C" uint32_t mfm_sp_pitch_v3(void)
+{
+    return MFM3_SP;
 }
 
 /* what the engine's rotator table for this kernel file has to look like */
