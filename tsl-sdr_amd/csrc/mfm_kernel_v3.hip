@@ -70,6 +70,16 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM3_DIV_STEPS
 #define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
 #endif
+#ifndef MFM3_LUT_MODE
+#define MFM3_LUT_MODE 1 /* the arctangent table in LDS: 1 {T, dT} pairs, one 8-byte read per output (banked over 64 dwords);
+                         * 0 (rounds 2-3, A/B builds) T[256] then dT[256], one ds_read2st64_b32 (banked over 32): the table's
+                         * data-dependent addresses were 88 % of the kernel's SQ_LDS_BANK_CONFLICT cycles, the pair form halves
+                         * them (25 % -> 17 % of LDS cycles) at the same instruction count; 2 counter builds only - every lane
+                         * reads its own bank (wrong PCM): the kernel without those conflicts, 1.5 % faster, which a table
+                         * replicated per bank would give and LDS (2 x 78.8 KB per CU) has no room for.
+                         * profiles/r04_lds_conflicts.txt */
+#endif
+#define MFM3_LUT_SLOT(t) (MFM3_LUT_MODE == 1 ? (t) : ((t) >> 1) + (((t)&1u) << 8))
 #define MFM3_SCHED_ALL_BUT_VMEM 0x38F
 
 /* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 (left to itself the compiler makes it two shifts and a three-operand
@@ -226,7 +236,7 @@ static __device__ __forceinline__ uint32_t mfm3_fold64(uint64_t k, uint32_t mu, 
  * four.  So the division is scalar FMAs (no packed math: nothing to gain, registers to lose), and the table index comes
  * out of the float adder: floor(alpha) + 2^21 has 4 * floor(alpha) in its low mantissa bits - the byte offset of
  * T[floor(alpha)] - which saves the conversion and the shift.
- * lut_addr: LDS byte address of T[0]; dT[0] sits 1024 bytes behind it.
+ * lut_addr: LDS byte address of the table: {T[i], dT[i]} pairs (MFM3_LUT_MODE 0: T[0], with dT[0] 1024 bytes behind it).
  */
 static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], const int s_im[4], uint32_t lut_addr, int pcm[4])
 {
@@ -260,12 +270,28 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
         fr[i] = __builtin_amdgcn_fractf(alpha);        /* :127 (alpha - floor(alpha), exact) */
         const float fl = alpha - fr[i];                /* floor(alpha), 0..255 (NaN for (0, 0)) */
+#if MFM3_LUT_MODE == 1
+        const float m = fl + 1048576.0f;               /* bits 0x49800000 + 8 * floor(alpha) */
+        /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
+        const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x49800000u);
+        typedef const __attribute__((address_space(3))) float2 *lds_f2p;
+        const float2 pr = *(lds_f2p)(uintptr_t)addr;
+        t0[i] = pr.x;
+        dt[i] = pr.y;
+#else
         const float m = fl + 2097152.0f;               /* bits 0x4A000000 + 4 * floor(alpha) */
         /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
+#if MFM3_LUT_MODE == 2
+        /* bit 0 of lut_addr set by the channel kernel only: the commit-time self-test keeps the real table reads */
+        const uint32_t addr = (lut_addr & 1u) ? (lut_addr - 1u) + 4u * (__lane_id() + 64u * (uint32_t)i)
+                                              : __float_as_uint(m) + (lut_addr - 0x4A000000u);
+#else
         const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x4A000000u);
+#endif
         lds_fp p = (lds_fp)(uintptr_t)addr;
         t0[i] = p[0];
         dt[i] = p[256];
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -612,16 +638,16 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     const bool chunk_rows = DFIX ? G::chunk_rows : L.layout == 1u; /* mfm_kernel.h: decimations that are not multiples of 32 */
     const uint32_t t_per = DFIX ? G::per : L.t_per, t_pitch = DFIX ? G::pitch : L.t_pitch;
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
-    const uint32_t lut_addr = (uint32_t)(uintptr_t)(smem + L.lut_off);
+    const uint32_t lut_addr = (uint32_t)(uintptr_t)(smem + L.lut_off) | (MFM3_LUT_MODE == 2 ? 1u : 0u);
 
-    /* atan LUT, once per workgroup: {T[i], T[i+1]-T[i]} pairs split into T[256] followed by dT[256].  Requested here,
+    /* atan LUT, once per workgroup: {T[i], T[i+1]-T[i]} pairs as the engine holds them (MFM3_LUT_MODE).  Requested here,
      * stored behind the first image (MFM3_PROLOGUE: everything a workgroup needs before its first matrix phase - table,
      * first image, tap fragments, row constants - is requested before anything is waited for; the kernel's start is a
      * chain of memory round trips during which every SIMD of the chip idles, 6 % of a 2^26-sample launch in round 2) */
     static_assert(MFM3_NT == 512, "one table dword per thread");
     const uint32_t lut_v = reinterpret_cast<const uint32_t *>(L.lut)[tid];
 #if !MFM3_PROLOGUE
-    reinterpret_cast<uint32_t *>(smem + L.lut_off)[(tid >> 1) + ((tid & 1u) << 8)] = lut_v;
+    reinterpret_cast<uint32_t *>(smem + L.lut_off)[MFM3_LUT_SLOT(tid)] = lut_v;
 #endif
 
     /* staging: this thread owns the 16-byte chunks q = tid + j * 512 of every tile (4 samples = 8 bytes per byte
@@ -813,7 +839,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
             }
             krow0 = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rb0 * 16 + 4 * mfm3_opaque(kg));
         }
-        reinterpret_cast<uint32_t *>(smem + L.lut_off)[(tid >> 1) + ((tid & 1u) << 8)] = lut_v;
+        reinterpret_cast<uint32_t *>(smem + L.lut_off)[MFM3_LUT_SLOT(tid)] = lut_v;
 #endif
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
@@ -1396,7 +1422,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
 __global__ __launch_bounds__(MFM3_NT) void mfm3_disc_test_kernel(const int *s_re, const int *s_im, int *pcm, uint32_t n4, const float2 *lut)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tbl[512];
-    tbl[(threadIdx.x >> 1) + ((threadIdx.x & 1u) << 8)] = reinterpret_cast<const uint32_t *>(lut)[threadIdx.x];
+    tbl[MFM3_LUT_SLOT(threadIdx.x)] = reinterpret_cast<const uint32_t *>(lut)[threadIdx.x];
     __syncthreads();
     const uint32_t t = blockIdx.x * MFM3_NT + threadIdx.x;
     if (t >= n4) {
