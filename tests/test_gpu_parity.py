@@ -106,6 +106,85 @@ def test_reference_shaped_configs(pkg, ora, name, kernel):
         assert st["kernel_variant"] == 2
 
 
+# every channelizer geometry the reference ships under etc/: (name, fs, centre, decimation, channel centre frequencies, gains in
+# dB, the low-pass that goes with it by sample rate: its length and cut-off, the front end's sample format and buffer size)
+ETC_CONFIGS = [
+    # etc/multifm.json (8 channels; etc/multifm_1ch.json is its first) + etc/flex_25khz_lpf.json (128 taps); RTL-SDR bytes,
+    # 131 072-sample buffers (multifm/rtl_sdr_if.c:46)
+    ("multifm", 1000000, 929500000, 40, [929838000, 929538000, 929388000, 929938000, 929362000, 929662500, 929638000, 929612000],
+     None, 128, 12500.0, "rtlsdr_u8", 131072),
+    # etc/multifm_airspy.json, etc/multifm_usrp.json + etc/flex_25khz_lpf_3mhz.json (512 taps); int16, 16 384-sample buffers
+    ("multifm_airspy", 3000000, 930500000, 120, [929612500], None, 512, 12500.0, "cs16", 16384),
+    # etc/pocsag_rtlsdr.json + etc/pocsag_1200khz_fs.json (256 taps, hamming, 9 kHz); channel 1's gain key is misspelt
+    # ("dbGain") in the file, so it runs at 0 dB (multifm/receiver.c reads "dBGain")
+    ("pocsag_rtlsdr", 1200000, 152500000, 25, [152180000, 152008000], [4.0, 0.0], 256, 9000.0, "rtlsdr_u8", 131072),
+    # etc/pocsag_airspy.json + etc/pocsag_narrow.json (256 taps, hamming, 4.8 kHz); int16, 262 144-sample buffers
+    # (multifm/airspy_if.c:244-245)
+    ("pocsag_airspy", 2500000, 152500000, 100, [152180000], [2.0], 256, 4800.0, "cs16", 262144),
+    # etc/multifm_file.json: a cs8 capture at 8 738 133 S/s channelised WITHOUT decimation, 4096-sample buffers
+    # (multifm/file_if.c:18); no filter file goes with it by name: 128 taps
+    ("multifm_file", 8738133, 1692000000, 1, [1691000000], None, 128, 400000.0, "cs8", 4096),
+]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("cfg", ETC_CONFIGS, ids=[c[0] for c in ETC_CONFIGS])
+def test_every_configuration_under_etc(pkg, ora, cfg, kernel):
+    """The reference's own configurations - sample rate, decimation, channel centres and gains as the files under etc/ have
+    them, filters of the lengths its filter files have, the sample format and buffer size of the front end each is written
+    for (8-bit sources pushed as bytes) - against the oracle on the widened input, every kernel."""
+    name, fs, centre, decim, chans, gains_db, ntaps, cutoff, fmt_name, buf = cfg
+    b = pkg.binding
+    offs = np.array([f - centre for f in chans], dtype=np.int64)
+    gains = [10.0 ** (g / 10.0) for g in gains_db] if gains_db else [1.0] * len(offs)   # multifm/receiver.c: dBGain -> linear
+    taps = pkg.synth.design_lpf(ntaps, cutoff, fs)
+    n = buf * 5 + 1234 if decim > 1 else buf * 9 + 77
+    fmt = {"cs16": b.MFM_IN_CS16, "cs8": b.MFM_IN_CS8, "rtlsdr_u8": b.MFM_IN_RTLSDR_U8}[fmt_name]
+    sig = pkg.synth.synth_iq(n, fs, offs, seed=len(name))
+    if fmt == b.MFM_IN_CS16:
+        raw, iq = sig, sig
+    elif fmt == b.MFM_IN_CS8:
+        raw = (sig >> 8).astype(np.int8).view(np.uint8)
+        iq = ora.unpack_bytes(raw, fmt).reshape(-1, 2)
+    else:
+        raw = np.clip((sig.astype(np.int32) >> 7) + 127, 0, 255).astype(np.uint8)
+        iq = ora.unpack_bytes(raw, fmt).reshape(-1, 2)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=buf, kernel=kernel)
+    cre, cim, incr = _oracle_tables(eng, len(offs))
+    parts = []
+    for lo in range(0, n, buf):
+        blk = raw[lo:lo + buf]
+        while True:
+            rc = eng.push(blk.reshape(-1)) if fmt == b.MFM_IN_CS16 else eng.push_bytes(blk, fmt)
+            if rc == 0:
+                break
+            assert rc == b.MFM_E_BUSY, eng.lib.mfm_last_error()
+            parts.append(eng.fetch()[1])
+    eng.sync()
+    while True:
+        got = eng.fetch()
+        if got is None:
+            break
+        parts.append(got[1])
+    eng.close()
+    pcm = np.concatenate(parts, axis=1)
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
+    assert pcm.shape == ref.shape, (pcm.shape, ref.shape)
+    assert np.array_equal(pcm, ref), f"{name}: {np.count_nonzero(pcm != ref)} PCM samples differ"
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("decim,ntaps", [(1, 1), (1, 128), (2, 2), (2, 129), (3, 64), (4, 128), (5, 5), (5, 200), (6, 512), (7, 100)])
+def test_decimations_below_eight(pkg, ora, decim, ntaps, kernel):
+    """filter/direct_fir.c:328-417 decimates by any factor >= 1 (etc/multifm_file.json: 1); filters from one tap per output
+    sample to 512 taps, ragged blocks, full-scale input, filtered IQ compared as well."""
+    fs = 1000000
+    taps = pkg.synth.design_lpf(ntaps, 100000.0, fs) if ntaps > 1 else np.array([0.9])
+    offs = np.array([0, 250000, -123456, 31250, fs // (4 * decim) if decim > 1 else 7, -499999], dtype=np.int64)
+    iq = pkg.synth.random_iq(20000 * decim + ntaps + 3, seed=decim * 1000 + ntaps)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 7001, kernel=kernel)
+
+
 @pytest.mark.parametrize("decim,ntaps,nch,want_iq", [(40, 128, 64, False), (40, 128, 9, True), (8, 8, 3, True), (8, 60, 20, False),
                                                      (16, 128, 5, False), (24, 100, 70, False), (48, 128, 64, True),
                                                      (56, 56, 3, False), (72, 128, 130, False), (88, 100, 7, True),

@@ -1485,7 +1485,11 @@ int launch_locked(mfm_engine *e)
     bool two = false;
     if (e->ncs > 1u && e->use_v3 && n_new) {
         const uint32_t ntiles = (n_new + MFM_V3_OT - 1u) / MFM_V3_OT, slots = 256u * e->v_wg_per_cu;
-        two = (uint64_t)ntiles * e->m_nslices > slots;
+        /* ... and only when what its carry copy reads - the last consumed row and the unconsumed samples behind it - lies
+         * behind the [hist | tail] front of this buffer, which the previous launch's carry wrote on the OTHER stream: the
+         * copy below is then ordered behind everything it reads (the H2D copies, through in_ready) without a wait of its
+         * own.  True for every launch of more than a tile per slot; spelled out so that it does not rest on that. */
+        two = (uint64_t)ntiles * e->m_nslices > slots && (uint64_t)n_new * D >= (uint64_t)e->tail + D;
     }
     hipStream_t S_after = two ? e->cs[e->si ^ 1u] : S;
     if (e->ncs > 1u && !two && e->in_free_wait[nxt]) {

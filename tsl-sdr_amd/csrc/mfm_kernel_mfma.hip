@@ -193,13 +193,13 @@ static __device__ __forceinline__ bool mfm_decode_item(const mfm_launch_mfma &L,
  * rounding's shift in L.in8 (mfm_kernel_v3.hip has the arithmetic).  A staging chunk stays 4 samples - an 8-byte load.
  *
  * Waves per SIMD.  Instances that keep up to four (int16) or eight (8-bit) k-steps of taps in registers are built for 128
- * vector registers, i.e. two workgroups per CU.  The RESIDENT long-filter instances (KC = 1 with KQ = 8 or 16: filters of
+ * vector registers, i.e. two workgroups per CU.  The RESIDENT long-filter instances (KC = 1 with KQ = 8, 12 or 16: filters of
  * 129..512 taps, all of whose taps stay in registers - up to 64 + 64 of them) are built for 256 registers and one workgroup
  * per CU: what a long filter loses in occupancy it more than gets back by not re-reading 16..32 KB of taps per wave and
  * iteration from L2. */
 constexpr int mfm_m_waves_per_simd(int KQ, int KC, bool IN8)
 {
-    return (KC == 1 && (KQ >= 16 || (KQ >= 8 && !IN8))) ? 2 : 4;
+    return (KC == 1 && (KQ >= 12 || (KQ >= 8 && !IN8))) ? 2 : 4;
 }
 
 template <int KQ, bool DBG_IQ, bool FIXP, int NCH, int KC, int AHM, int NIT, bool IN8>
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(MFM_M_NT, mfm_m_waves_per_simd(KQ, KC, IN8)) void m
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
     const uint32_t in8_sh = (uint32_t)__builtin_amdgcn_readfirstlane(L.in8);
-    /* the resident long-filter instances are built for decimations that are multiples of 4 only (a staging chunk never
-     * straddles two rows): the per-sample store path and the shuffles of the straddling load are not in their code */
+    /* the resident long-filter instances (two waves per SIMD, 256 registers): decimations that are not multiples of 4
+     * included since round 4 - etc/pocsag_rtlsdr.json's 25 with the 256-tap low-pass of etc/pocsag_1200khz_fs.json */
     constexpr bool RESIDENT = mfm_m_waves_per_simd(KQ, KC, IN8) == 2;
-    const bool split_rows = RESIDENT ? false : L.split_rows != 0u;
+    const bool split_rows = L.split_rows != 0u;
     /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
      * offset field of the LDS instructions instead of costing a v_add each (ds_read has no SGPR offset) */
     const uint32_t plane_dist = FIXP ? MFM_M_PLANE_DIST : L.plane_bytes;
@@ -892,11 +892,21 @@ static const void *mfm_resident_instance_mask(const mfm_launch_mfma *L, uint32_t
 
 static const void *mfm_resident_instance(const mfm_launch_mfma *L, int dbg_iq, uint32_t nch)
 {
-    if (dbg_iq || L->stream_taps || L->fixed_planes || L->split_rows || (L->kq != 8u && L->kq != 16u)) {
+    if (dbg_iq || L->stream_taps || L->fixed_planes || (L->kq != 8u && L->kq != 16u)) {
         return nullptr;
     }
     if (L->ot != MFM_M_NEW && nch > 4u) {
         return nullptr;
+    }
+    if (L->kq == 16u && L->kq_used >= 9u && L->kq_used <= 12u) {
+        /* nine to twelve k-steps of taps in a sixteen-step layout (256 taps at decimation 25 = 11, at decimation 100 = 9:
+         * the reference's POCSAG configurations with their own low-pass files): an instance of twelve multiplies the
+         * first twelve and leaves the all-zero rest alone.  Where the taps beyond one byte sit depends on the filter's
+         * centre and the channel gains: none of them (instance without the high-byte products) or the mask at run time. */
+        if (L->ah_mask == 0u) {
+            return L->in8 ? mfm_resident_instance_nit<12, 0, true>(L, nch) : mfm_resident_instance_nit<12, 0, false>(L, nch);
+        }
+        return L->in8 ? mfm_resident_instance_nit<12, -1, true>(L, nch) : mfm_resident_instance_nit<12, -1, false>(L, nch);
     }
     if (L->kq == 16u) {
         return L->in8 ? mfm_resident_instance_mask<16, true>(L, nch) : mfm_resident_instance_mask<16, false>(L, nch);
