@@ -98,8 +98,8 @@ def case8(pkg, ora, rng, long_only=False):
     fs = int(rng.choice([1200000, 2400000]))
     ntaps = max(decim, int(rng.choice([32, 64, 128, 128, 100, 96])))
     if long_only:
-        decim = int(rng.choice([4 * int(rng.randint(2, 116)), 8 * int(rng.randint(1, 58)), 96, 400]))
-        ntaps = max(decim, int(rng.choice([int(rng.randint(257, 513)), 300, 400, 512])))
+        decim = int(rng.choice([4 * int(rng.randint(2, 116)), 8 * int(rng.randint(1, 58)), 96, 400, 25, 100, int(rng.randint(8, 461))]))
+        ntaps = max(decim, int(rng.choice([int(rng.randint(257, 513)), 300, 400, 512, 256, 256])))
     nch = int(rng.choice([1, 3, 8, 9, 16, 64, 65, 130]))
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     offs = rng.randint(-fs // 2, fs // 2, size=nch)
