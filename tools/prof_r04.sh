@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04; rm -rf $O; mkdir -p $O
 B="--no-fp32 --no-chain --no-series"
 N="--no-cpu-baseline $B"
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driverflags.json 2> $O/bench_driverflags.err
+T0=$SECONDS; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driverflags.json 2> $O/bench_driverflags.err; echo "driver-flags run (everything the default line carries): $((SECONDS - T0)) s wall" > $O/driver_run_s.txt
 timeout 400 python bench.py $B > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python bench.py --overlap $N > $O/bench_overlap.json 2> $O/bench_overlap.err
 timeout 300 python bench.py --kernel mfma1 $N > $O/bench_mfma1.json 2> $O/bench_mfma1.err
