@@ -52,6 +52,11 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM_RES_PF
 #define MFM_RES_PF 4 /* resident long-filter instances: k-steps of B fragments in flight ahead of the matrix instructions */
 #endif
+#ifndef MFM_M_RES_SPLIT_ALL
+#define MFM_M_RES_SPLIT_ALL 0 /* 1: A/B builds - every resident instance carries the per-sample staging path of decimations that
+                               * are not multiples of 4, not only the twelve-k-step ones: 6-7 % slower at configs[4]'s geometry
+                               * (decimation 400, eight staging chunks per thread), 1.5 % at 512 taps / decimation 96 */
+#endif
 #ifndef MFM_RES_EARLY
 #define MFM_RES_EARLY 1 /* resident instances, single-iteration tiles: next tile's samples requested in front of the matrix phase */
 #endif
@@ -217,10 +222,11 @@ __global__ __launch_bounds__(MFM_M_NT, mfm_m_waves_per_simd(KQ, KC, IN8)) void m
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t nchunk = L.nstage >> 2; /* 16-byte chunks (4 samples) per tile */
     const uint32_t in8_sh = (uint32_t)__builtin_amdgcn_readfirstlane(L.in8);
-    /* the resident long-filter instances (two waves per SIMD, 256 registers): decimations that are not multiples of 4
-     * included since round 4 - etc/pocsag_rtlsdr.json's 25 with the 256-tap low-pass of etc/pocsag_1200khz_fs.json */
+    /* the resident long-filter instances (two waves per SIMD, 256 registers): the twelve-k-step ones take decimations that
+     * are not multiples of 4 too (etc/pocsag_rtlsdr.json's 25 with the 256-tap low-pass of etc/pocsag_1200khz_fs.json); the
+     * eight- and sixteen-step ones are built without the per-sample store path and the shuffles of the straddling load */
     constexpr bool RESIDENT = mfm_m_waves_per_simd(KQ, KC, IN8) == 2;
-    const bool split_rows = L.split_rows != 0u;
+    const bool split_rows = (RESIDENT && KQ != 12 && !MFM_M_RES_SPLIT_ALL) ? false : L.split_rows != 0u;
     /* one staging buffer = H plane + L plane; with FIXP the distances are compile-time constants and end up in the
      * offset field of the LDS instructions instead of costing a v_add each (ds_read has no SGPR offset) */
     const uint32_t plane_dist = FIXP ? MFM_M_PLANE_DIST : L.plane_bytes;
@@ -907,6 +913,9 @@ static const void *mfm_resident_instance(const mfm_launch_mfma *L, int dbg_iq, u
             return L->in8 ? mfm_resident_instance_nit<12, 0, true>(L, nch) : mfm_resident_instance_nit<12, 0, false>(L, nch);
         }
         return L->in8 ? mfm_resident_instance_nit<12, -1, true>(L, nch) : mfm_resident_instance_nit<12, -1, false>(L, nch);
+    }
+    if (L->split_rows && !MFM_M_RES_SPLIT_ALL) {
+        return nullptr; /* streamed instances (MFM_M_RES_SPLIT_ALL has the price of doing otherwise) */
     }
     if (L->kq == 16u) {
         return L->in8 ? mfm_resident_instance_mask<16, true>(L, nch) : mfm_resident_instance_mask<16, false>(L, nch);
