@@ -268,13 +268,17 @@ def other_geometries(pkg, torch, block, steps=24, settle_s=0.25):
     """The reference's other deployed geometries on the same engine, outside the timed region (never part of `value`): the
     int16 path of BASELINE configs[4] (per-GPU share: 256 of the 2048 Airspy channels, D = 400, 512-tap low-pass - the
     resident long-filter instances), the channelizer geometry of configs[3] (etc/pocsag_rtlsdr.json:
-    1.2 MS/s, D = 25) and of etc/multifm.json (1 MS/s, D = 40), 64 channels each.  Same protocol as the headline: blocks
+    1.2 MS/s, D = 25) and of etc/multifm.json (1 MS/s, D = 40), and the three front-end configurations with the longer low-pass
+    files the reference ships for their sample rates (profiles/r04_etc_shapes.txt), 64 channels each.  Same protocol as the headline: blocks
     resident in HBM, a settle phase of back-to-back launches, kernel duration from the engine's HIP events."""
     b = pkg.binding
     lib = pkg.load_library()
     out = {}
     for key, plan, nch in (("configs4_int16_share", "cfg5_airspy", 256), ("configs3_pocsag_d25", "pocsag_rtlsdr", 64),
-                           ("multifm_json_d40", "multifm_1ch", 64)):
+                           ("multifm_json_d40", "multifm_1ch", 64),
+                           # the same front ends with the low-pass files the reference ships for their sample rates
+                           ("pocsag_rtlsdr_d25_256taps", "pocsag_rtlsdr_256taps", 64), ("pocsag_airspy_d100_256taps", "pocsag_airspy", 64),
+                           ("multifm_airspy_d120_512taps", "multifm_airspy", 64)):
         try:
             fs, decim, taps, offs, gains = pkg.synth.plan(plan, nr_channels=nch)
             in_bytes = lib.mfm_engine_input_bytes(block, len(taps))

@@ -79,6 +79,12 @@ CONFIGS = {
     "cfg3_1024ch_grid": dict(fs=2400000, decim=96, taps=128, cutoff=12500.0, nr_channels=1024, grid=True),
     "pocsag_rtlsdr": dict(fs=1200000, decim=25, taps=128, cutoff=12500.0, offsets=[-320000, -492000],
                           gains_db=[4.0, 0.0]),
+    # the same channelizer with the low-pass the reference ships for that sample rate (etc/pocsag_1200khz_fs.json: 256 taps,
+    # hamming, 9 kHz), etc/pocsag_airspy.json + etc/pocsag_narrow.json (2.5 MS/s, D = 100, 256 taps, 4.8 kHz), and
+    # etc/multifm_airspy.json / multifm_usrp.json + etc/flex_25khz_lpf_3mhz.json (3 MS/s, D = 120, 512 taps)
+    "pocsag_rtlsdr_256taps": dict(fs=1200000, decim=25, taps=256, cutoff=9000.0, offsets=[-320000, -492000], gains_db=[4.0, 0.0]),
+    "pocsag_airspy": dict(fs=2500000, decim=100, taps=256, cutoff=4800.0, offsets=[-320000], gains_db=[2.0]),
+    "multifm_airspy": dict(fs=3000000, decim=120, taps=512, cutoff=12500.0, offsets=[-887500]),
     # the FLEX 25 kHz LPF of configs[4] (512 taps, etc/flex_25khz_lpf*.json) at the 2.4 MS/s / D = 96 geometry
     "cfg2_64ch_512taps": dict(fs=2400000, decim=96, taps=512, cutoff=12500.0, nr_channels=64),
     "cfg2_64ch_256taps": dict(fs=2400000, decim=96, taps=256, cutoff=12500.0, nr_channels=64),
