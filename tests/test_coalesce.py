@@ -385,3 +385,54 @@ def test_two_engines_sharing_a_kernel_instance_keep_their_lds(pkg, ora, geoms, k
             assert pcm.shape == ref.shape and np.array_equal(pcm, ref), (decim, rnd)
     for eng, *_ in engs:
         eng.close()
+
+
+def test_engines_driven_from_their_own_threads(pkg, ora):
+    """Several receivers in one process (one engine each, as one multifm process per dongle would be folded into one service):
+    every engine is created, committed, fed and drained from its own thread while the others do the same - creation and commit
+    included, so the process-wide pieces (kernel selection, the dynamic-LDS limits, the division self-test, the last-error
+    slot) are exercised concurrently.  Each engine's PCM against the oracle."""
+    import threading
+    b = pkg.binding
+    shapes = [(2400000, 96, 128, 33, 0), (1000000, 40, 128, 9, 0), (1200000, 25, 128, 5, b.MFM_F_OVERLAP),
+              (1200000, 25, 256, 3, 0), (2500000, 100, 256, 4, 0), (2400000, 96, 128, 8, b.MFM_F_FORCE_DOT2),
+              (2400000, 96, 128, 70, b.MFM_F_GATHER), (1000000, 40, 64, 2, b.MFM_F_FORCE_MFMA_V1)]
+    results, errors = {}, []
+
+    def work(k, fs, decim, ntaps, nch, flags):
+        try:
+            rng = np.random.RandomState(k)
+            taps = pkg.synth.design_lpf(ntaps, 9000.0, fs)
+            offs = rng.randint(-fs // 2 + 30000, fs // 2 - 30000, size=nch)
+            iq = pkg.synth.random_iq(decim * 3000 + ntaps + k, seed=100 + k)
+            eng = pkg.Engine(fs, decim, 1 << 16, device=0, flags=flags, coalesce_samples=100000 if flags & b.MFM_F_GATHER else 0)
+            for o in offs:
+                eng.add_channel(int(o), taps, 1.0)
+            eng.commit()
+            tabs = [eng.get_channel(c) for c in range(nch)]
+            parts, qparts, pos = [], [], 0
+            while pos < iq.shape[0]:
+                m = min(int(rng.randint(1, 1 << 16)), iq.shape[0] - pos)
+                rc = eng.push(iq[pos:pos + m])
+                if rc == b.MFM_E_BUSY:
+                    _drain(eng, parts, qparts)
+                    continue
+                assert rc == 0, eng.lib.mfm_last_error()
+                pos += m
+            _finish(eng, parts, qparts)
+            eng.close()
+            results[k] = (np.concatenate([p[1] for p in parts], axis=1), iq, tabs, decim)
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,) + s) for k, s in enumerate(shapes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert len(results) == len(shapes)
+    for k, (pcm, iq, tabs, decim) in results.items():
+        cre, cim, incr = (np.stack([t[i] for t in tabs]) for i in range(3))
+        ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
+        assert pcm.shape == ref.shape and np.array_equal(pcm, ref), shapes[k]
