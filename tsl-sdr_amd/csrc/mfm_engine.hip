@@ -1077,6 +1077,10 @@ static int commit_locked(struct mfm_engine *e)
             e->v_nstage4 = nstage4;
             e->v_lds_bytes = lds;
             e->v_wg_per_cu = std::max(1u, std::min(2u, (160u * 1024u) / lds));
+#ifdef MFM_EXP_ONE_WG_PER_CU /* occupancy experiment (tools/exp/snapeng.sh): LDS padded so that one workgroup fits a CU */
+            e->v_lds_bytes = 100u * 1024u;
+            e->v_wg_per_cu = 1u;
+#endif
             for (uint32_t k = 0; k < 4; k++) {
                 e->v_cross[k] = k < kq ? (64u * k) / row_bytes : 0u;
                 e->v_within[k] = k < kq ? (64u * k) % row_bytes : 0u;
