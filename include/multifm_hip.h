@@ -253,7 +253,10 @@ int mfm_engine_last_launch_input(struct mfm_engine *e, void **d_in, size_t *nr_s
  * unfetched block: fetch / release and call again).  Producer side: the thread that submits.  No-op otherwise. */
 int mfm_engine_flush(struct mfm_engine *e);
 
-/* Wait for everything submitted so far (launches pending samples first, as mfm_engine_flush). */
+/* Wait for everything submitted so far (launches pending samples first, as mfm_engine_flush, and returns its MFM_E_BUSY).
+ * Threading: push / stage / acquire_input / submit / flush / sync / seek / reset are PRODUCER-side calls and belong to one
+ * thread at a time; fetch / release (and get_stats, copy_done / copy_wait) may run on another.  A flush that finds nothing
+ * gathered is safe from any thread (it tests under the engine's lock). */
 int mfm_engine_sync(struct mfm_engine *e);
 
 /*
@@ -353,6 +356,9 @@ int mfm_group_fetch(struct mfm_group *g, struct mfm_block *blks);
 int mfm_group_release(struct mfm_group *g);
 /* coalesce_samples: launch, on every shard, what has been pushed and not yet launched (MFM_E_BUSY: fetch / release first) */
 int mfm_group_flush(struct mfm_group *g);
+/* flush, then wait for every shard (MFM_E_BUSY from the flush is returned as it is: it is not a failure).  Producer-side
+ * like the pushes: a host with a submit thread lets THAT thread flush and waits for mfm_stats::pending_samples == 0 and
+ * pending_blocks == 0 instead (host/mfm_receiver.c receiver_drain). */
 int mfm_group_sync(struct mfm_group *g);
 int mfm_group_get_stats(struct mfm_group *g, uint32_t shard, struct mfm_stats *st);
 /* whether blocks travel through RCCL, how many blocks were pushed through it and how many bytes it moved to

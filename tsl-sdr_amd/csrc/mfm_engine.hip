@@ -1648,6 +1648,11 @@ int launch_locked(mfm_engine *e)
             /* the launch that last read the next buffer may be on the other stream */
             HIP_TRY(hipStreamWaitEvent(S_after, e->in_free_wait[nxt], 0));
         }
+        if (two && e->tail_pending[nxt]) {
+            /* ... and so may the carry copy OUT of that buffer, when a launch in between did not alternate:
+             * a wait on a completed event costs nothing */
+            HIP_TRY(hipStreamWaitEvent(S_after, e->tail_done[nxt], 0));
+        }
         HIP_TRY(hipMemcpyAsync(e->d_in[nxt],
                                reinterpret_cast<const uint8_t *>(e->d_in[cur]) + ((size_t)e->hist + consumed - new_hist) * ss,
                                ((size_t)new_hist + new_tail) * ss, hipMemcpyDeviceToDevice, S_after));
@@ -1904,11 +1909,14 @@ int mfm_engine_flush(struct mfm_engine *e)
     if (!e || !e->committed) {
         return fail(MFM_E_STATE, "commit first");
     }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    /* pend is tested under the lock: two callers (a producer thread's idle flush and somebody else's sync) may get here at
+     * once, and the second one must find nothing left to launch instead of launching an empty pass that rotates the
+     * input buffers under the producer */
+    std::lock_guard<std::mutex> guard(e->mu);
     if (0 == e->pend) {
         return MFM_OK;
     }
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    std::lock_guard<std::mutex> guard(e->mu);
     return launch_locked(e);
 }
 
@@ -2106,7 +2114,11 @@ int mfm_engine_pending_blocks(struct mfm_engine *e)
 
 int mfm_engine_pending_samples(struct mfm_engine *e)
 {
-    return (e && e->committed) ? (int)e->pend : 0;
+    if (!e || !e->committed) {
+        return 0;
+    }
+    std::lock_guard<std::mutex> guard(e->mu);
+    return (int)e->pend;
 }
 
 int mfm_engine_push(struct mfm_engine *e, const int16_t *iq, size_t nr_samples)
@@ -2335,7 +2347,6 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->taps_resident = (e->use_mfma && !e->use_v3 && e->m_resident_taps) ? 1u : 0u;
     st->reserved0 = 0;
     st->submits = e->submits;
-    st->pending_samples = e->pend;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
     st->outputs_per_tile = e->use_v3 ? MFM_V3_OT : e->use_mfma ? e->m_ot : 64u * e->opl;
@@ -2344,6 +2355,7 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     {
         std::lock_guard<std::mutex> guard(e->mu);
         st->pending_blocks = (uint32_t)(e->submit_seq - e->fetch_seq);
+        st->pending_samples = e->pend; /* written under the lock by submit / launch */
         st->launches_8bit = e->launches_8bit;
     }
     st->grid_last = e->grid_last;

@@ -15,32 +15,6 @@
 
 #define MFM_MSG(sev, sys, msg, ...) MESSAGE("MULTIFM", sev, sys, msg, ##__VA_ARGS__)
 
-/* ---- intrusive list (the reference uses TSL's <tsl/list.h>) ---- */
-
-static void list_init(struct list_entry *e)
-{
-    e->prev = e->next = e;
-}
-
-static void list_append(struct list_entry *head, struct list_entry *e)
-{
-    e->prev = head->prev;
-    e->next = head;
-    head->prev->next = e;
-    head->prev = e;
-}
-
-static void list_del(struct list_entry *e)
-{
-    e->prev->next = e->next;
-    e->next->prev = e->prev;
-    e->prev = e->next = e;
-}
-
-#define list_for_each_type(pos, head, member)                                                                \
-    for (pos = BL_CONTAINER_OF((head)->next, __typeof__(*pos), member); &pos->member != (head);              \
-         pos = BL_CONTAINER_OF(pos->member.next, __typeof__(*pos), member))
-
 /* ---- doorbells (mfm_receiver.h) ---- */
 
 static void _bell_init(struct mfm_doorbell *b)
@@ -245,6 +219,28 @@ static void _demod_thread_emit(struct demod_thread *dthr, const struct mfm_block
 
 /* ---- receiver ---- */
 
+/* What the front end's thread and receiver_cleanup() share beyond the life of the receiver structure.  The reference's
+ * front ends free the structure that embeds their `struct receiver` in their cleanup function (multifm/rtl_sdr_if.c:59-82),
+ * and for a blocking reader (librtlsdr) that function is also what makes the thread function return - so the thread may
+ * come back from its front end after the memory is gone, and must not touch it then. */
+struct mfm_rx_lifeline {
+    pthread_mutex_t mu;
+    bool rx_gone; /* receiver_cleanup() has handed the structure to the front end's cleanup function */
+    int refs;     /* the receiver and, once started, its front-end thread */
+};
+
+static void _lifeline_drop(struct mfm_rx_lifeline *life)
+{
+    pthread_mutex_lock(&life->mu);
+    const int left = --life->refs;
+    pthread_mutex_unlock(&life->mu);
+    if (0 == left) {
+        pthread_mutex_destroy(&life->mu);
+        free(life);
+    }
+}
+
+
 aresult_t receiver_sample_buf_alloc(struct receiver *rx, struct sample_buf **pbuf)
 {
     aresult_t ret = A_OK;
@@ -361,6 +357,7 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
                 break;
             }
             _bell_ring(&rx->block_bell);
+            _bell_ring(&rx->idle_bell); /* receiver_drain() waits for "nothing gathered and not launched" */
             _bell_arm(&rx->ring_bell);
             if (tail == rx->ring_head && worker_thread_is_running(wthr)) {
                 _bell_sleep(&rx->ring_bell, MFM_IDLE_MS);
@@ -466,6 +463,21 @@ static aresult_t _receiver_drain_thread(struct worker_thread *wthr)
     return A_OK;
 }
 
+/* pending work of the device group: samples accepted and not launched, blocks launched and not written out */
+static aresult_t _receiver_pending(struct receiver *rx, bool *samples, bool *blocks)
+{
+    *samples = *blocks = false;
+    for (int s = 0; s < rx->nr_shards; s++) {
+        struct mfm_stats st;
+        if (MFM_OK != mfm_group_get_stats(rx->group, (uint32_t)s, &st)) {
+            return A_E_DEVICE;
+        }
+        *samples = *samples || 0 != st.pending_samples;
+        *blocks = *blocks || 0 != st.pending_blocks;
+    }
+    return A_OK;
+}
+
 aresult_t receiver_drain(struct receiver *rx)
 {
     TSL_ASSERT_ARG(NULL != rx);
@@ -481,23 +493,33 @@ aresult_t receiver_drain(struct receiver *rx)
             _bell_disarm(&rx->idle_bell);
         }
     }
-    if (rx->failed || MFM_OK != mfm_group_sync(rx->group)) {
+    if (rx->failed) {
         return A_E_DEVICE;
     }
     for (;;) {
-        bool pending = false;
-        for (int s = 0; s < rx->nr_shards; s++) {
-            struct mfm_stats st;
-            if (MFM_OK != mfm_group_get_stats(rx->group, (uint32_t)s, &st)) {
-                return A_E_DEVICE;
-            }
-            pending = pending || 0 != st.pending_blocks;
+        bool samples = false, blocks = false;
+        if (FAILED(_receiver_pending(rx, &samples, &blocks))) {
+            return A_E_DEVICE;
         }
-        if (!pending) {
+        if (!samples && !blocks) {
             return A_OK;
         }
         if (rx->failed) {
             return A_E_DEVICE;
+        }
+        if (samples && !rx->submit_thr.started) {
+            /* no submit thread (a caller that pushes by itself): launch what was gathered from here.  MFM_E_BUSY = every
+             * output slot holds an unfetched block: not an error, it goes away as blocks are written out below. */
+            const int frc = mfm_group_flush(rx->group);
+            if (MFM_OK != frc && MFM_E_BUSY != frc) {
+                return A_E_DEVICE;
+            }
+        } else if (samples) {
+            /* The submit thread is the group's one producer: it launches what it gathered when its ring runs empty
+             * (_receiver_submit_thread) and waits there for an output slot if it has to.  Flushing from this thread as well
+             * would run two producer-side calls at once, and a full output ring (MFM_E_BUSY) would look like a device
+             * failure and cut the end of the stream. */
+            _bell_ring(&rx->ring_bell);
         }
         if (rx->drain_thr.started) {
             /* the drain thread owns fetch/release and rings after every block */
@@ -684,6 +706,10 @@ static void _receiver_zero(struct receiver *rx, receiver_rx_thread_func_t rx_fun
     rx->copy_ticket = NULL;
     rx->copy_head = rx->copy_tail = 0;
     rx->nr_demod_threads = 0;
+    rx->life = calloc(1, sizeof(*rx->life));
+    TSL_BUG_ON(NULL == rx->life);
+    pthread_mutex_init(&rx->life->mu, NULL);
+    rx->life->refs = 1;
     atomic_store(&rx->nr_samp_buf_alloc_fails, 0);
     atomic_store(&rx->input_done, false);
     atomic_store(&rx->nr_blocks_drained, 0);
@@ -698,6 +724,32 @@ static void _receiver_zero(struct receiver *rx, receiver_rx_thread_func_t rx_fun
     _bell_init(&rx->room_bell);
     _bell_init(&rx->block_bell);
     _bell_init(&rx->idle_bell);
+}
+
+/* everything receiver_init() built inside `rx`, except the lifeline */
+static void _receiver_teardown(struct receiver *rx)
+{
+    struct demod_thread *cur = NULL, *tmp = NULL;
+    list_for_each_type_safe(cur, tmp, &rx->demod_threads, dt_node) {
+        list_del(&cur->dt_node);
+        TSL_BUG_IF_FAILED(demod_thread_delete(&cur));
+    }
+    rx->nr_demod_threads = 0;
+    mfm_group_destroy(&rx->group);
+    if (NULL != rx->ring) {
+        TFREE(rx->ring);
+    }
+    if (NULL != rx->copying) {
+        TFREE(rx->copying);
+    }
+    if (NULL != rx->copy_ticket) {
+        TFREE(rx->copy_ticket);
+    }
+    TSL_BUG_IF_FAILED(frame_alloc_delete(&rx->samp_alloc));
+    sem_destroy(&rx->ring_bell.sem);
+    sem_destroy(&rx->room_bell.sem);
+    sem_destroy(&rx->block_bell.sem);
+    sem_destroy(&rx->idle_bell.sem);
 }
 
 aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,
@@ -763,14 +815,31 @@ done:
     if (NULL != st.lpf_taps) {
         TFREE(st.lpf_taps);
     }
+    if (FAILED(ret)) {
+        /* the caller frees its own structure and never calls receiver_cleanup() (multifm/rtl_sdr_if.c:463-477) */
+        _receiver_teardown(rx);
+        _lifeline_drop(rx->life);
+        rx->life = NULL;
+    }
     return ret;
 }
 
 static aresult_t _receiver_worker_thread(struct worker_thread *wthr)
 {
     struct receiver *rx = BL_CONTAINER_OF(wthr, struct receiver, wthr);
+    struct mfm_rx_lifeline *life = rx->life; /* referenced for this thread by receiver_start() */
     TSL_BUG_ON(NULL == rx->thread_func);
-    return rx->thread_func(rx);
+    const aresult_t ret = rx->thread_func(rx);
+    /* a front end whose thread function has returned delivers nothing further (the reference's file front end leaves its
+     * loop when a read comes back short, multifm/file_if.c:181-184): a driver may stop waiting for input */
+    pthread_mutex_lock(&life->mu);
+    if (!life->rx_gone) {
+        receiver_mark_input_done(rx);
+        wthr->running = false;
+    }
+    pthread_mutex_unlock(&life->mu);
+    _lifeline_drop(life);
+    return ret;
 }
 
 aresult_t receiver_start(struct receiver *rx)
@@ -810,12 +879,44 @@ aresult_t receiver_start(struct receiver *rx)
     if (FAILED(ret = worker_thread_new(&rx->submit_thr, _receiver_submit_thread, WORKER_THREAD_CPU_MASK_ANY))) {
         return ret;
     }
+    pthread_mutex_lock(&rx->life->mu);
+    rx->life->refs++; /* the front end's thread */
+    pthread_mutex_unlock(&rx->life->mu);
     if (FAILED(ret = worker_thread_new(&rx->wthr, _receiver_worker_thread, WORKER_THREAD_CPU_MASK_ANY))) {
         MFM_MSG(SEV_ERROR, "THREAD-START-FAIL", "Failed to start worker thread, aborting.");
+        _lifeline_drop(rx->life);
     }
     return ret;
 }
 
+/* Wait up to `ms` for the front end's thread to end by itself.  true = joined. */
+static bool _receiver_join_front_end(struct receiver *rx, unsigned ms)
+{
+    struct timespec ts;
+    if (!rx->wthr.started) {
+        return true;
+    }
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_nsec += (long)(ms % 1000u) * 1000000L;
+    ts.tv_sec += (time_t)(ms / 1000u) + ts.tv_nsec / 1000000000L;
+    ts.tv_nsec %= 1000000000L;
+    if (0 != pthread_timedjoin_np(rx->wthr.thr, NULL, &ts)) {
+        return false;
+    }
+    rx->wthr.started = false;
+    return true;
+}
+
+/*
+ * The reference's order (multifm/receiver.c:281-315) is: the front end's cleanup function, then stop and join the front
+ * end's thread, then the channel threads, then the pool.  Two properties of the reference's front ends shape the order
+ * here: their cleanup function frees the structure that embeds `*rx` (rtl_sdr_if.c:81, so nothing of `rx` may be touched
+ * after it), and for librtlsdr it is also what ends the blocking reader (rtlsdr_cancel_async, :70), so the thread cannot be
+ * joined before it.  So: ask the thread to stop and give it a moment (a file reader or any polling front end ends by
+ * itself: what it delivered then reaches the FIFOs completely); a reader that is still blocked is muted instead (its
+ * callback delivers nothing when muted, rtl_sdr_if.c:94-98); drain and tear down everything that lives in `rx`; the front
+ * end's cleanup function comes LAST, and the thread - by then on its way out - is joined through a copy of its handle.
+ */
 aresult_t receiver_cleanup(struct receiver **prx)
 {
     struct receiver *rx = NULL;
@@ -824,9 +925,12 @@ aresult_t receiver_cleanup(struct receiver **prx)
     TSL_ASSERT_ARG(NULL != *prx);
     rx = *prx;
 
-    /* stop the producer first, then let what it delivered reach the FIFOs */
     TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->wthr));
-    TSL_BUG_IF_FAILED(worker_thread_delete(&rx->wthr));
+    const bool joined = _receiver_join_front_end(rx, 500u);
+    if (!joined) {
+        rx->muted = true;
+        usleep(20000); /* a callback that was past its muted check delivers its buffer */
+    }
     if (NULL != rx->group && rx->drain_thr.started) {
         (void)receiver_drain(rx); /* returns A_E_DEVICE instead of waiting for a thread that has given up */
         if (rx->submit_thr.started) {
@@ -839,29 +943,29 @@ aresult_t receiver_cleanup(struct receiver **prx)
         _bell_ring(&rx->block_bell);
         TSL_BUG_IF_FAILED(worker_thread_delete(&rx->drain_thr));
     }
-    TSL_BUG_IF_FAILED(rx->cleanup_func(rx));
 
-    while (rx->demod_threads.next != &rx->demod_threads) {
-        struct demod_thread *cur = BL_CONTAINER_OF(rx->demod_threads.next, struct demod_thread, dt_node);
-        list_del(&cur->dt_node);
-        TSL_BUG_IF_FAILED(demod_thread_delete(&cur));
-    }
-    mfm_group_destroy(&rx->group);
-    if (NULL != rx->ring) {
-        TFREE(rx->ring);
-    }
-    if (NULL != rx->copying) {
-        TFREE(rx->copying);
-    }
-    if (NULL != rx->copy_ticket) {
-        TFREE(rx->copy_ticket);
-    }
-    TSL_BUG_IF_FAILED(frame_alloc_delete(&rx->samp_alloc));
-    sem_destroy(&rx->ring_bell.sem);
-    sem_destroy(&rx->room_bell.sem);
-    sem_destroy(&rx->block_bell.sem);
-    sem_destroy(&rx->idle_bell.sem);
+    _receiver_teardown(rx);
+
+    /* from here on `rx` belongs to the front end */
+    struct mfm_rx_lifeline *life = rx->life;
+    const bool join_after = rx->wthr.started;
+    const pthread_t front_end = rx->wthr.thr;
+    const receiver_cleanup_func_t cleanup = rx->cleanup_func;
+    pthread_mutex_lock(&life->mu);
+    life->rx_gone = true;
+    pthread_mutex_unlock(&life->mu);
     *prx = NULL;
+    TSL_BUG_IF_FAILED(cleanup(rx));
+    if (join_after) {
+        /* a thread that is still stuck in its front end (a read on a pipe nobody writes to) is left behind, not waited for */
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        ts.tv_sec += 2;
+        if (0 != pthread_timedjoin_np(front_end, NULL, &ts)) {
+            pthread_detach(front_end);
+        }
+    }
+    _lifeline_drop(life);
     return A_OK;
 }
 

@@ -59,10 +59,6 @@ aresult_t sample_buf_decref(struct sample_buf *buf);
 
 /* ---- channels (multifm/demod.h) ---- */
 
-struct list_entry {
-    struct list_entry *prev, *next;
-};
-
 /* A doorbell between two threads: the waiter announces that it is about to sleep, looks once more, and sleeps on the
  * semaphore; whoever produces work rings only when somebody announced (one atomic exchange, no lock, never waits - which
  * is what receiver_sample_buf_deliver() needs).  The reference hands buffers to its channel threads through a work queue
@@ -98,6 +94,7 @@ void demod_thread_bind_group(struct mfm_group *group);
 /* ---- receiver (multifm/receiver.h) ---- */
 
 struct receiver;
+struct mfm_rx_lifeline;
 typedef aresult_t (*receiver_cleanup_func_t)(struct receiver *rx);
 typedef aresult_t (*receiver_rx_thread_func_t)(struct receiver *rx);
 
@@ -135,6 +132,7 @@ struct receiver {
     struct mfm_doorbell room_bell;   /* drain thread -> submit thread: an output slot was released */
     struct mfm_doorbell block_bell;  /* submit thread -> drain thread: a block was pushed to the devices */
     struct mfm_doorbell idle_bell;   /* both -> receiver_drain(): a buffer was submitted / a block written out */
+    struct mfm_rx_lifeline *life;    /* outlives this structure: see receiver_cleanup() */
 };
 
 aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thread_func_t rx_func,

@@ -1,6 +1,7 @@
 /* mfm_tsl.c - worker threads, frame pool and clock behind mfm_tsl.h. */
 #include "mfm_tsl.h"
 
+#include <signal.h>
 #include <time.h>
 
 /* ---- worker thread ---- */
@@ -43,6 +44,111 @@ aresult_t worker_thread_delete(struct worker_thread *thr)
         thr->started = false;
     }
     return A_OK;
+}
+
+/* ---- work queue ---- */
+
+aresult_t work_queue_new(struct work_queue *wq, unsigned depth)
+{
+    TSL_ASSERT_ARG(NULL != wq);
+    TSL_ASSERT_ARG(0 != depth);
+    wq->slots = calloc(depth, sizeof(void *));
+    if (NULL == wq->slots) {
+        return A_E_NOMEM;
+    }
+    wq->depth = depth;
+    wq->head = wq->count = 0;
+    return A_OK;
+}
+
+aresult_t work_queue_release(struct work_queue *wq)
+{
+    TSL_ASSERT_ARG(NULL != wq);
+    free(wq->slots);
+    wq->slots = NULL;
+    wq->depth = wq->head = wq->count = 0;
+    return A_OK;
+}
+
+aresult_t work_queue_push(struct work_queue *wq, void *value)
+{
+    TSL_ASSERT_ARG(NULL != wq && NULL != wq->slots);
+    if (wq->count == wq->depth) {
+        return A_E_BUSY;
+    }
+    wq->slots[(wq->head + wq->count) % wq->depth] = value;
+    wq->count++;
+    return A_OK;
+}
+
+aresult_t work_queue_pop(struct work_queue *wq, void **value)
+{
+    TSL_ASSERT_ARG(NULL != wq && NULL != wq->slots);
+    TSL_ASSERT_ARG(NULL != value);
+    *value = NULL;
+    if (wq->count) {
+        *value = wq->slots[wq->head];
+        wq->head = (wq->head + 1) % wq->depth;
+        wq->count--;
+    }
+    return A_OK;
+}
+
+aresult_t work_queue_size(struct work_queue *wq, unsigned *count)
+{
+    TSL_ASSERT_ARG(NULL != wq);
+    TSL_ASSERT_ARG(NULL != count);
+    *count = wq->count;
+    return A_OK;
+}
+
+/* ---- application scaffolding ---- */
+
+static volatile sig_atomic_t app_stop_requested;
+static app_sigint_handler_t app_user_handler;
+
+static void app_on_sigint(int sig)
+{
+    (void)sig;
+    app_stop_requested = 1;
+    if (NULL != app_user_handler) {
+        app_user_handler();
+    }
+}
+
+/* The reference's app_init() daemonises / logs according to an optional "app" stanza; multifm and decoder pass a name and
+ * (possibly NULL) configuration and use nothing of it afterwards.  Here: a broken pipe is an errno for the writer
+ * (EPIPE is handled per channel, multifm/demod.c:95-105), not a signal that ends the process. */
+aresult_t app_init(const char *app_name, struct config *cfg)
+{
+    TSL_ASSERT_ARG(NULL != app_name && '\0' != *app_name);
+    (void)cfg;
+    app_stop_requested = 0;
+    signal(SIGPIPE, SIG_IGN);
+    return A_OK;
+}
+
+aresult_t app_sigint_catch(app_sigint_handler_t handler)
+{
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    app_user_handler = handler;
+    sa.sa_handler = app_on_sigint;
+    sigemptyset(&sa.sa_mask);
+    if (0 != sigaction(SIGINT, &sa, NULL) || 0 != sigaction(SIGTERM, &sa, NULL)) {
+        return A_E_INVAL;
+    }
+    return A_OK;
+}
+
+int app_running(void)
+{
+    return !app_stop_requested;
+}
+
+void app_request_stop(void)
+{
+    app_stop_requested = 1;
 }
 
 /* ---- frame pool: nr_frames equally sized, 64-byte aligned frames on a lock-protected free stack ---- */

@@ -62,6 +62,13 @@ typedef int aresult_t;
         }                                                                                                    \
     } while (0)
 #define TSL_ASSERT_ARG_DEBUG(cond) TSL_ASSERT_ARG(cond)
+/* a pointer handed over by reference: neither the reference nor what it refers to may be NULL
+ * (filter/polyphase_fir.c:120) */
+#define TSL_ASSERT_PTR_BY_REF(pptr)                                                                          \
+    do {                                                                                                     \
+        TSL_ASSERT_ARG(NULL != (pptr));                                                                      \
+        TSL_ASSERT_ARG(NULL != *(pptr));                                                                     \
+    } while (0)
 
 /* invariant check: aborts */
 #define TSL_BUG_ON(cond)                                                                                     \
@@ -107,6 +114,107 @@ static inline aresult_t tsl_aligned_zalloc(void **p, size_t bytes, size_t align)
         free(ptr);                                                                                           \
         (ptr) = NULL;                                                                                        \
     } while (0)
+
+/* TCALLOC(&ptr, a, b): a * b zeroed bytes (multifm/rtl_sdr_if.c:248, decoder/decoder.c:528,560) */
+static inline aresult_t tsl_zalloc(void **p, size_t a, size_t b)
+{
+    if (NULL == p) {
+        return A_E_INVAL;
+    }
+    *p = calloc(a ? a : 1, b ? b : 1);
+    return NULL == *p ? A_E_NOMEM : A_OK;
+}
+#define TCALLOC(pptr, a, b) tsl_zalloc((void **)(pptr), (size_t)(a), (size_t)(b))
+
+/* `type *x CAL_CLEANUP(free_xxx) = NULL;` releases x when it goes out of scope (multifm/rtl_sdr_if.c:230,
+ * multifm/receiver.c:107-115, multifm/multifm.c:92) */
+#define CAL_CLEANUP(fn) __attribute__((cleanup(fn)))
+static inline void free_memory(void **p)
+{
+    if (NULL != p && NULL != *p) {
+        free(*p);
+        *p = NULL;
+    }
+}
+static inline void free_double_array(double **p)
+{
+    free_memory((void **)p);
+}
+static inline void free_i16_array(int16_t **p)
+{
+    free_memory((void **)p);
+}
+static inline void free_u32_array(uint32_t **p)
+{
+    free_memory((void **)p);
+}
+static inline void free_string(char **p)
+{
+    free_memory((void **)p);
+}
+
+/* ---- intrusive circular list (<tsl/list.h>): multifm/receiver.c:89,186,236-237,303-304, demod.c:337 ---- */
+struct list_entry {
+    struct list_entry *prev, *next;
+};
+#define LIST_INIT(name) { &(name), &(name) }
+
+static inline void list_init(struct list_entry *e)
+{
+    e->prev = e->next = e;
+}
+
+/* at the tail: a walk sees entries in the order they were appended */
+static inline void list_append(struct list_entry *head, struct list_entry *e)
+{
+    e->prev = head->prev;
+    e->next = head;
+    head->prev->next = e;
+    head->prev = e;
+}
+
+static inline void list_del(struct list_entry *e)
+{
+    e->prev->next = e->next;
+    e->next->prev = e->prev;
+    e->prev = e->next = e;
+}
+
+static inline bool list_empty(const struct list_entry *head)
+{
+    return head->next == head;
+}
+
+#define list_for_each_type(pos, head, member)                                                                \
+    for (pos = BL_CONTAINER_OF((head)->next, __typeof__(*pos), member); &pos->member != (head);              \
+         pos = BL_CONTAINER_OF(pos->member.next, __typeof__(*pos), member))
+/* `pos` may be unlinked (and freed) inside the body */
+#define list_for_each_type_safe(pos, tmp, head, member)                                                      \
+    for (pos = BL_CONTAINER_OF((head)->next, __typeof__(*pos), member),                                      \
+        tmp = BL_CONTAINER_OF(pos->member.next, __typeof__(*pos), member);                                   \
+         &pos->member != (head); pos = tmp, tmp = BL_CONTAINER_OF(tmp->member.next, __typeof__(*pos), member))
+
+/* ---- bounded FIFO of pointers (<tsl/work_queue.h>): multifm/demod.c:134,176,297, receiver.c:91.  Not locked: the
+ * reference takes its own mutex around every call (receiver.c:90-92, demod.c:133-135).  Popping an empty queue is A_OK
+ * with *value = NULL (demod.c:134-136 relies on it); pushing into a full one is A_E_BUSY. ---- */
+struct work_queue {
+    void **slots;
+    unsigned depth, head, count;
+};
+aresult_t work_queue_new(struct work_queue *wq, unsigned depth);
+aresult_t work_queue_release(struct work_queue *wq);
+aresult_t work_queue_push(struct work_queue *wq, void *value);
+aresult_t work_queue_pop(struct work_queue *wq, void **value);
+aresult_t work_queue_size(struct work_queue *wq, unsigned *count);
+
+/* ---- application scaffolding (<app/app.h>): multifm/multifm.c:114-115,163, decoder/decoder.c:668,679-680 ---- */
+struct config;
+typedef void (*app_sigint_handler_t)(void);
+aresult_t app_init(const char *app_name, struct config *cfg);
+aresult_t app_sigint_catch(app_sigint_handler_t handler); /* NULL: just stop app_running() */
+int app_running(void);
+/* not in TSL: a finite input (file front end at end of file) ends the application's main loop the way SIGINT would */
+void app_request_stop(void);
 
 /* ---- worker thread ---- */
 struct worker_thread;

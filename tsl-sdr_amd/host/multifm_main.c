@@ -5,11 +5,11 @@
  * (multifm/multifm.c:89-173): every argument is a JSON file merged into one configuration, whose "device" stanza
  * names the front end by "type".  The front ends this build knows sit in a table: a name (matched as a prefix, like the
  * reference's strncmp chain) and the constructor that turns the configuration into a running receiver, or NULL for the
- * types whose vendor libraries (librtlsdr, libdespairspy, UHD) are not part of this build.
+ * types whose vendor libraries (libdespairspy, UHD) are not part of this build.  librtlsdr is bound at run time.
  */
 #include "mfm_file_if.h"
+#include "mfm_rtl_sdr_if.h"
 
-#include <signal.h>
 #include <unistd.h>
 
 #define MFM_MSG(sev, sys, msg, ...) MESSAGE("MULTIFM", sev, sys, msg, ##__VA_ARGS__)
@@ -21,18 +21,10 @@ static const struct front_end {
     front_end_new_func_t create; /* NULL: known to multifm, not built here */
 } front_ends[] = {
     { "file", file_worker_thread_new },
-    { "rtlsdr", NULL },
+    { "rtlsdr", rtl_sdr_worker_thread_new }, /* librtlsdr bound at run time; fails politely without it */
     { "airspy", NULL },
     { "usrp", NULL },
 };
-
-static volatile sig_atomic_t stop_requested;
-
-static void on_sigint(int sig)
-{
-    (void)sig;
-    stop_requested = 1;
-}
 
 /* every command-line argument is one more file of the same configuration */
 static struct config *load_configuration(int nr_files, const char *files[])
@@ -84,7 +76,7 @@ static int run_receiver(struct receiver *rx)
     if (FAILED(receiver_start(rx))) {
         return EXIT_FAILURE;
     }
-    while (!stop_requested && !rx->input_done) {
+    while (app_running() && !rx->input_done) {
         usleep(10000);
     }
     return EXIT_SUCCESS;
@@ -94,14 +86,17 @@ int main(int argc, const char *argv[])
 {
     if (argc < 2) {
         fprintf(stderr, "usage: %s [Config File 1]{, Config File 2, ...} | %s -h\n", argv[0], argv[0]);
+        (void)rtl_sdr_dump_devices(); /* multifm/multifm.c:83-85 */
         return EXIT_FAILURE;
     }
     struct config *cfg = load_configuration(argc - 1, argv + 1);
     if (NULL == cfg) {
         return EXIT_FAILURE;
     }
-    signal(SIGINT, on_sigint);
-    signal(SIGPIPE, SIG_IGN); /* EPIPE is handled per channel (demod.c:95-105) */
+    /* the application scaffolding of the reference's driver (multifm.c:114-115): SIGINT / SIGTERM end the loop below,
+     * EPIPE is an errno handled per channel (demod.c:95-105) */
+    TSL_BUG_IF_FAILED(app_init("multifm", cfg));
+    TSL_BUG_IF_FAILED(app_sigint_catch(NULL));
 
     int ret = EXIT_FAILURE;
     struct receiver *rx = NULL;
