@@ -9,8 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-# "auto" = the matrix-core kernels where they apply (second generation when decimation % 8 == 0 and <= 128 taps, else
-# the first), "mfma1" = first-generation matrix kernel forced, "dot2" = forced v_dot2 kernel.  All three give the same bits.
+# "auto" = the matrix-core kernels where they apply (second generation when decimation % 8 == 0 and <= 128 taps, and - round 5 -
+# for filters of 129..512 taps at any decimation without a filtered-IQ consumer; else the first), "mfma1" = first-generation
+# matrix kernel forced, "dot2" = forced v_dot2 kernel.  All three give the same bits.
 KERNELS = ["auto", "mfma1", "dot2"]
 
 
@@ -255,9 +256,10 @@ def test_2048_channels_at_the_airspy_geometry(pkg, ora):
     fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=2048)
     iq = pkg.synth.synth_iq(2 * 60000 + 1234, fs, offs[::400][:5], seed=2048)
     eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=60000, want_iq=False)
-    assert eng.stats()["kernel_variant"] == 1
+    assert eng.stats()["kernel_variant"] == 2  # round 5: half-tile images of the long-filter kernel (decimation 400)
     eng.close()
     _check(pkg, ora, fs, decim, taps, offs, iq, 60000, gains=gains, want_iq=False, threads=16)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 60000, gains=gains, want_iq=False, threads=16, kernel="mfma1")
 
 
 @pytest.mark.parametrize("ntaps,want_iq", [(512, False), (512, True), (256, False), (160, False)])
@@ -268,8 +270,13 @@ def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntap
     fs, decim, _, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=24)
     taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
     iq = pkg.synth.synth_iq(96 * 2500 + ntaps, fs, offs[:3], seed=ntaps)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 16, want_iq=want_iq, kernel="mfma1s")
+    assert eng.stats()["kernel_variant"] == 1 and eng.stats()["taps_resident"] == 0
+    eng.close()
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq, kernel="mfma1s")
+    # without the flag: the second generation's long-filter kernel, unless a channel wants its filtered IQ (not built there)
     eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 16, want_iq=want_iq)
-    assert eng.stats()["kernel_variant"] == 1, "long filters should run on the (first-generation) matrix kernel too"
+    assert eng.stats()["kernel_variant"] == (1 if want_iq else 2), eng.stats()
     eng.close()
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
 
@@ -293,11 +300,18 @@ def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape
     offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-10, 11)]
     iq = pkg.synth.synth_iq(decim * 400 + ntaps + 7, fs, offs[:3], seed=decim)
     masks = {}
-    for kernel, resident in (("auto", 1), ("mfma1s", 0)):
+    for kernel, resident in (("auto", 1), ("mfma1", 1), ("mfma1s", 0)):
         eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 16, want_iq=False, kernel=kernel)
         st = eng.stats()
         eng.close()
-        assert st["kernel_variant"] == 1 and st["taps_resident"] == resident, st
+        # round 5: "auto" is the second generation's long-filter kernel (mfm_kernel_v3l.hip) where an instance is built for
+        # the geometry - all but sixteen k-steps of int16 taps with every high-byte plane held and eight staging chunks per
+        # thread on half-tile images (dense taps at decimations of 320 and more), which stay on the first generation
+        assert st["taps_resident"] == resident, st
+        if kernel != "auto":
+            assert st["kernel_variant"] == 1, st
+        elif decim <= 200 or (decim <= 400 and shape in ("lpf", "lpf_div8")):
+            assert st["kernel_variant"] == 2, (st, decim, ntaps, shape)  # (decimation 448: two half-tile images exceed LDS)
         masks[kernel] = st["tap_hi_mask"]
         _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=False, kernel=kernel)
         _check(pkg, ora, fs, decim, taps, offs, iq, 30001, want_iq=False, kernel=kernel)
@@ -321,8 +335,11 @@ def test_long_filters_on_8bit_blocks_resident_and_streamed(pkg, ora, fmt, decim,
     rng = np.random.RandomState(decim + fmt)
     blocks = [(rng.randint(0, 256, size=(m, 2)).astype(np.uint8), fmt) for m in (65536, 4096, 30000, 50000, 12346)]
     got, want, st = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536)
-    assert st["kernel_variant"] == 1 and st["launches_8bit"] == st["launches"] > 0 and st["taps_resident"] == 1
+    assert st["kernel_variant"] == 2 and st["launches_8bit"] == st["launches"] > 0 and st["taps_resident"] == 1
     assert got.shape == want.shape and np.array_equal(got, want)
+    got1, _, st1 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536, flags=pkg.binding.MFM_F_FORCE_MFMA_V1)
+    assert st1["kernel_variant"] == 1 and st1["launches_8bit"] == st1["launches"] > 0 and st1["taps_resident"] == 1
+    assert np.array_equal(got1, want)
     got2, _, st2 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 65536, flags=pkg.binding.MFM_F_STREAM_TAPS)
     assert st2["launches_8bit"] == st2["launches"] > 0 and st2["taps_resident"] == 0
     assert np.array_equal(got2, want)
@@ -345,9 +362,14 @@ def test_cfg5_airspy_rate(pkg, ora):
     eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 17, want_iq=False)
     st = eng.stats()
     eng.close()
-    assert st["kernel_variant"] == 1 and st["outputs_per_tile"] == 31
+    assert st["kernel_variant"] == 2 and st["outputs_per_tile"] == 64  # round 5: 64-output tiles from two half-tile images
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17)
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17, want_iq=False)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 17, want_iq=False, kernel="mfma1")
+    st = eng.stats()
+    eng.close()
+    assert st["kernel_variant"] == 1 and st["outputs_per_tile"] == 31
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 17, want_iq=False, kernel="mfma1")
 
 
 @pytest.mark.parametrize("decim,ntaps", [(256, 256), (200, 256), (320, 512), (136, 160), (176, 192), (400, 400)])
@@ -356,10 +378,11 @@ def test_large_decimations_use_single_iteration_tiles(pkg, ora, decim, ntaps):
     taps = pkg.synth.design_lpf(ntaps, 12500.0, fs)
     offs = [12345, -250000, 1000000, -1234567, 31250]
     iq = pkg.synth.synth_iq(decim * 300 + ntaps + 3, fs, offs[:3], seed=decim)
-    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 16, want_iq=False)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 16, want_iq=False, kernel="mfma1")
     assert eng.stats()["kernel_variant"] == 1
     eng.close()
-    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=(decim == 256))
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=(decim == 256), kernel="mfma1")
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, want_iq=False)
 
 
 @pytest.mark.parametrize("decim,ntaps", [(1, 16), (2, 9), (7, 33), (8, 8), (8, 17), (16, 64), (24, 100), (25, 128),
@@ -390,7 +413,8 @@ def test_decimations_that_are_not_multiples_of_8_run_on_the_matrix_kernel(pkg, o
     eng.close()
     # decimation 25 with up to 150 taps: the second generation on padded rows (round 4) - unless a channel wants its filtered
     # IQ; every other decimation of this list: the first generation
-    assert st["kernel_variant"] == (2 if decim == 25 else 1), st
+    # ... and, round 5, filters of 129 taps and more (mfm_kernel_v3l.hip takes any decimation the first generation takes)
+    assert st["kernel_variant"] == (2 if decim == 25 or ntaps > 128 else 1), st
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, want_iq=(nch == 2))
     _check(pkg, ora, fs, decim, taps, offs, iq, 5000, want_iq=False)
     if decim == 25:

@@ -175,6 +175,10 @@ struct mfm_engine {
     uint32_t v_rs = 0, v_sp_pitch = 0, v_nstage4 = 0, v_lds_bytes = 0, v_wg_per_cu = 1, v_cross[4] = { 0, 0, 0, 0 },
              v_within[4] = { 0, 0, 0, 0 };
     uint32_t v_layout = 0, v_t_per = 0, v_t_pitch = 0; /* mfm_launch_v3::layout: chunk rows for decimations % 32 != 0 */
+    /* layout 3, long filters (mfm_kernel_v3l.hip): plain rows; v_rs = row stride, v_plane = bytes of one byte plane */
+    uint32_t v_plane = 0, v_ng = 0, v_nstage_p = 0, v_sta_bytes = 0;
+    uint32_t v_kq = 0, v_nh = 0, v_kperm[4] = { 0, 0, 0, 0 }; /* the instance's k-step count, k-steps with a high-byte tap plane,
+                                                                 and the order the k-steps are laid out in (mfm_launch_v3::kperm) */
     uint32_t *d_afrag = nullptr;
     int32_t *d_krow = nullptr;
     int32_t *d_krow8[4] = { nullptr, nullptr, nullptr, nullptr }; /* [MFM_IN_*]: row constants of the 8-bit input forms */
@@ -293,6 +297,24 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
     V.layout = e->v_layout;
     V.t_per = e->v_t_per;
     V.t_pitch = e->v_t_pitch;
+    if (3u == e->v_layout) {
+        /* long filters: [two buffers of two byte planes | atan table | staging offsets | transposition areas + per-wave constants] */
+        V.plane_pitch = e->v_plane;
+        V.buf_pitch = 2u * e->v_plane;
+        V.lut_off = 4u * e->v_plane;
+        V.sta_off = V.lut_off + 2048u;
+        V.tp_off = V.sta_off + e->v_sta_bytes;
+        V.row_bytes = e->m_row_bytes;
+        V.split_rows = (e->cfg.decimation % 4u) != 0u ? 1u : 0u;
+        V.kq = e->v_kq;
+        V.kq_used = e->m_kq_used;
+        V.nh = e->v_nh;
+        for (int k = 0; k < 4; k++) {
+            V.kperm[k] = e->v_kperm[k];
+        }
+        V.ng = e->v_ng;
+        V.nstage_p = e->v_nstage_p;
+    }
     V.nslices = e->m_nslices;
     V.nrb = e->m_nrb;
     V.nchan = (uint32_t)e->chans.size();
@@ -311,6 +333,11 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
         V.krow = e->d_krow8[fmt];
         V.nstage4 = 2u == e->v_layout ? (73u * 25u + 7u + 7u) / 8u : e->v_nstage4 / 2u;
         V.x_last4 = (2u * e->cap_in - 8u) & ~7u;
+        if (3u == e->v_layout) {
+            /* a staging chunk stays 4 samples there - an 8-byte load */
+            V.nstage4 = e->v_nstage4;
+            V.x_last4 = (2u * e->cap_in - 4u) & ~3u;
+        }
     }
 }
 
@@ -1107,6 +1134,95 @@ static int commit_locked(struct mfm_engine *e)
         e->m_kq_used = 6u;
     }
 
+    if (e->use_mfma && !e->use_v3 && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_STREAM_TAPS)) && e->m_ks >= 8u &&
+        e->m_ks <= MFM_V3L_KQ_MAX && !e->any_iq) {
+        /* ---- filters of 129..512 taps on the second-generation structure (layout 3, mfm_kernel_v3l.hip): the first
+         *      generation's image - plain rows of m_row_bytes plane bytes at stride m_rs, any decimation - holding a whole
+         *      64-output tile, or half of one when two whole ones do not fit LDS (decimation 400 of configs[4]: 112 KB per
+         *      image of both planes); same tap fragments, same row constants. ---- */
+        const uint32_t row_bytes = e->m_row_bytes, rs_l = e->m_rs;
+        const uint32_t kq_inst = mfm_v3l_built_kq(e->m_kq_used);
+        /* k-steps whose high-byte tap plane is not all zero (what m_ah_mask will say once the fragments are built) */
+        uint32_t hi_mask = 0;
+        for (const Channel &ch : e->chans) {
+            for (uint32_t i = 0; i < T; i++) {
+                const uint32_t kst = ((i / D) * row_bytes + 2u * (i % D)) / 64u;
+                for (int32_t w : { (int32_t)ch.cre[i], (int32_t)ch.cim[i], -(int32_t)ch.cim[i] }) {
+                    const int32_t wl = (int8_t)(w & 0xff);
+                    if (((w - wl) >> 8) != 0) {
+                        hi_mask |= 1u << kst;
+                    }
+                }
+            }
+        }
+        const uint32_t reach = (k_elems - 1u) / row_bytes;                       /* rows the last window reaches past its own */
+        const uint32_t reach_read = (64u * kq_inst - 1u) / row_bytes + 1u;       /* ... and what the instance's fragment reads touch */
+        for (uint32_t ng : { 4u, 2u }) {
+            const uint32_t opi = 16u * ng;
+            const uint32_t plane = (opi + std::max(reach, reach_read)) * rs_l;
+            const uint32_t nstage4 = ((opi + reach) * D + 3u) / 4u;
+            const uint32_t nch = (nstage4 + 511u) / 512u;
+            if (nch > MFM_V3_CH_MAX || plane >= 65536u || kq_inst > e->m_ks) {
+                continue;
+            }
+            const uint32_t sta = mfm_v3l_built_nch(nch) * 2048u; /* the instance's count: a surplus chunk is loaded and not stored */
+            const uint32_t aux = 8u * 8u * MFM_V3L_TP * 4u + 512u + 512u + 2048u;
+            const uint32_t lds = 4u * plane + 2048u + sta + aux;
+            if (lds > 160u * 1024u) {
+                continue;
+            }
+            /* is the int16 instance for this geometry and tap-plane mask built?  (All are but the sixteen-step form that
+             * holds every high-byte plane with many staging chunks in flight: it would spill.)  The mask must be known HERE:
+             * the second generation orders its rows by rotator class, the first does not. */
+            mfm_launch_v3 probe{};
+            probe.layout = 3u;
+            probe.kq = kq_inst;
+            probe.kq_used = e->m_kq_used;
+            probe.nh = (uint32_t)__builtin_popcount(hi_mask);
+            probe.ng = ng;
+            probe.nstage4 = nstage4;
+            probe.ah_mask = hi_mask;
+            const void *fn = nullptr;
+            if (mfm_select_channel_kernel_v3(&probe, 0, &fn) != hipSuccess) {
+                continue;
+            }
+            e->use_v3 = true;
+            e->v_layout = 3u;
+            e->v_rs = rs_l;
+            e->v_plane = plane;
+            e->v_sp_pitch = 0;
+            e->v_ng = ng;
+            e->v_nstage4 = nstage4;
+            e->v_nstage_p = ((1u + reach) * D + 3u) / 4u;
+            e->v_sta_bytes = sta;
+            e->v_lds_bytes = lds;
+            e->v_wg_per_cu = 1u; /* two waves per SIMD hold a long filter's taps: one workgroup per CU */
+            e->v_kq = kq_inst;
+            e->v_nh = probe.nh;
+            {
+                /* the order the k-steps are multiplied in: those with a high-byte tap plane first, then the others that
+                 * hold taps, then - up to the instance's count - steps of zero taps */
+                uint8_t order[16] = { 0 };
+                uint32_t at = 0;
+                for (uint32_t k = 0; k < e->m_kq_used; k++) {
+                    if ((hi_mask >> k) & 1u) {
+                        order[at++] = (uint8_t)k;
+                    }
+                }
+                for (uint32_t k = 0; k < kq_inst; k++) {
+                    if (!((hi_mask >> k) & 1u)) {
+                        order[at++] = (uint8_t)k;
+                    }
+                }
+                for (int w = 0; w < 4; w++) {
+                    e->v_kperm[w] = (uint32_t)order[4 * w] | ((uint32_t)order[4 * w + 1] << 8) | ((uint32_t)order[4 * w + 2] << 16) |
+                                    ((uint32_t)order[4 * w + 3] << 24);
+                }
+            }
+            break;
+        }
+    }
+
     /* ---- rotator classes and row order (filter/direct_fir.c:151-172,406-413).  An increment of exactly (16384, 0) - every
      *      channel whose offset is a multiple of the output rate, e.g. a 25 kHz grid at 2.4 MS/s / 96 - leaves the rotator at
      *      (16384, 0) for ever, and r14(f * 16384) = f: nothing to do.  An increment of (-16384, 0) - offsets at odd
@@ -1153,7 +1269,7 @@ static int commit_locked(struct mfm_engine *e)
         e->v_rc = std::min(e->v_rc, cls);
         e->rot_fast_slices += cls != MFM_RC_GENERAL ? 1u : 0u;
     }
-    if (!e->use_v3 || e->any_iq || 2u == e->v_layout) {
+    if (!e->use_v3 || e->any_iq || e->v_layout >= 2u) {
         e->v_rc = MFM_RC_GENERAL; /* the exact-rotator instances are built without the filtered-IQ output, and for the
                                      sub-plane / chunk-row geometries only */
     }
@@ -1204,6 +1320,22 @@ static int commit_locked(struct mfm_engine *e)
                     krow[(size_t)rb * 16 + i] = (int32_t)(128u * sum + 8192u);
                 }
             }
+    }
+
+    if (e->use_v3 && 3u == e->v_layout) {
+        /* the long-filter kernel's fragments: v_kq k-steps per row block, in the order v_kperm */
+        if (e->m_ah_mask != ([&] { uint32_t m = 0; for (uint32_t j = 0; j < e->v_nh; j++) { m |= 1u << ((e->v_kperm[j >> 2] >> (8u * (j & 3u))) & 0xffu); } return m; })()) {
+            return fail(MFM_E_INVAL, "internal: the tap-plane mask changed between planning and building the fragments");
+        }
+        const size_t step_dw = 2u * 64u * 4u; /* dwords of one k-step: two planes x 64 lanes x 16 bytes */
+        std::vector<uint32_t> af3((size_t)e->m_nrb * e->v_kq * step_dw, 0u);
+        for (uint32_t rb = 0; rb < e->m_nrb; rb++) {
+            for (uint32_t j = 0; j < e->v_kq; j++) {
+                const uint32_t src = (e->v_kperm[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                memcpy(&af3[((size_t)rb * e->v_kq + j) * step_dw], &afrag[((size_t)rb * e->m_ks + src) * step_dw], step_dw * 4u);
+            }
+        }
+        afrag.swap(af3);
     }
 
     /* ---- rotator tables (one per distinct increment) ---- */
@@ -2344,7 +2476,7 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->rot_fast_slices = e->rot_fast_slices;
     st->k_steps = e->use_mfma ? e->m_ks : 0u;
     st->tap_hi_mask = e->use_mfma ? e->m_ah_mask : 0u;
-    st->taps_resident = (e->use_mfma && !e->use_v3 && e->m_resident_taps) ? 1u : 0u;
+    st->taps_resident = ((e->use_mfma && !e->use_v3 && e->m_resident_taps) || (e->use_v3 && 3u == e->v_layout)) ? 1u : 0u;
     st->reserved0 = 0;
     st->submits = e->submits;
     st->nr_channels = (uint32_t)e->chans.size();

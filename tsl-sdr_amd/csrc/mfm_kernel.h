@@ -151,6 +151,25 @@ struct mfm_launch_mfma {
 #define MFM_V3_OT 64u          /* outputs per tile */
 #define MFM_V3_LEAD 4u         /* rows staged in front of a tile (the first tile of a chunk recomputes output -1) */
 #define MFM_V3_CH_MAX 8u       /* 16-byte staging chunks per thread and tile, at most */
+#define MFM_V3L_TP 72u         /* layout 3: dwords per channel row of a wave's transposition area (64 outputs + 8: the four
+                                  lane groups of a wave then write different LDS banks) */
+#define MFM_V3L_KQ_MAX 16u     /* layout 3: k-steps of 64 elements, at most (512 taps) */
+/* layout 3: the k-step counts and held high-byte-plane counts instances are built for (a filter runs on the next count up:
+ * the surplus k-steps hold zero taps, the surplus planes zeros) */
+static inline uint32_t mfm_v3l_built_kq(uint32_t kq_used)
+{
+    return kq_used <= 6u ? 6u : kq_used <= 8u ? 8u : kq_used <= 12u ? kq_used : kq_used <= 14u ? 14u : 16u;
+}
+static inline uint32_t mfm_v3l_built_nh(uint32_t kq, uint32_t nh)
+{
+    const uint32_t b = nh == 0u ? 0u : nh <= 2u ? 2u : nh <= 4u ? 4u : nh <= 8u ? 8u : kq;
+    return b < kq ? b : kq;
+}
+/* ... and the staging chunks per thread */
+static inline uint32_t mfm_v3l_built_nch(uint32_t nch)
+{
+    return nch <= 4u ? 4u : 8u;
+}
 
 struct mfm_launch_v3 {
     const uint32_t *x;    /* the input buffer: [hist samples already consumed | n_avail samples from the first unconsumed one] */
@@ -184,7 +203,7 @@ struct mfm_launch_v3 {
      * outputs (50 plane bytes) padded to 64, the taps carry zeros over the padding, a k-step is exactly one row and a window
      * spans six of them (kq = 6).  The image is staged sample by sample (a 16-byte chunk of the input straddles rows). */
     uint32_t layout;      /* 0: four sub-planes per byte plane (rs, sp_pitch, cross, within); 1: chunk rows (t_per, t_pitch);
-                             2: padded rows, decimation 25 */
+                             2: padded rows, decimation 25; 3: plain rows, long filters (below) */
     uint32_t t_per, t_pitch;
     uint32_t nslices, nrb;
     uint32_t ntiles;      /* ceil(n_new / 64) */
@@ -202,6 +221,24 @@ struct mfm_launch_v3 {
     uint32_t stream_taps; /* filters of 129..512 taps (kq 8 / 16): 1 = re-read the taps from L2 in every iteration (128-register
                              instances, two workgroups per CU where LDS allows); 0 = the resident instances (all taps in
                              registers, 256 registers, one workgroup per CU) where one is built for the geometry */
+    /* layout 3 - filters of 129..512 taps (and shorter ones at decimations layouts 0-2 do not take) on the second-generation
+     * structure, mfm_kernel_v3l.hip: the image is kept as plain rows (one row = the D samples between two outputs, 2 * D
+     * plane bytes rounded up to 16 with zero taps over the padding, row stride rs an odd multiple of 32 bytes - the first
+     * generation's image, so any decimation), column n of column group g of an image is its output 16 * g + n, and the four
+     * consecutive outputs per lane that the epilogue wants come out of a wave-private transposition area in LDS.  An image
+     * holds ng column groups: a whole tile (4) where two of them fit LDS, half a tile (2) for large decimations. */
+    uint32_t row_bytes;   /* plane bytes of a row as the GEMM sees it (2 * D rounded up to 16) */
+    uint32_t split_rows;  /* 1: a 4-sample staging chunk can straddle two rows (D % 4 != 0): stored sample by sample */
+    uint32_t kq_used;     /* k-steps that hold taps at all (<= kq) */
+    uint32_t nh;          /* k-steps whose high-byte tap plane is not all zero.  The engine lays the k-steps of a row block out
+                             in the order kperm: those nh first - so an instance holds "the first NH high-byte planes" and
+                             needs no mask - then the other ones that hold taps, then (up to kq, the instance's count) steps
+                             of zero taps.  Integer sums do not care about the order. */
+    uint32_t kperm[4];    /* byte j: which 64-element step of the window is multiplied j-th */
+    uint32_t ng;          /* column groups per staged image: 4 or 2 */
+    uint32_t nstage_p;    /* 4-sample chunks of the one-group image in front of a chunk's first tile (its column 0 is the
+                             output in front of the chunk, recomputed) */
+    uint32_t tp_off;      /* LDS byte offset of the transposition areas: [8 waves][8 channels][72] dwords */
     uint32_t *tail_dst;
     const uint32_t *afrag;
     const int32_t *krow;

@@ -30,299 +30,7 @@
 #include "mfm_kernel.h"
 #include "mfm_numerics.h"
 
-typedef int mfm_v4i __attribute__((ext_vector_type(4)));
-
-#define MFM3_NT 512u
-#ifndef MFM3_EARLY16
-#define MFM3_EARLY16 1 /* 0: A/B builds - the int16 form requests the next image at the top of a tile, as before */
-#endif
-#ifndef MFM3_WAVE_EXACT
-#define MFM3_WAVE_EXACT 1 /* 0: A/B builds - waves of exact rotators inside a general launch derotate through the table too */
-#endif
-#ifndef MFM3_PROLOGUE
-#define MFM3_PROLOGUE 1 /* 0: A/B builds - table, first image, tap fragments fetched one after the other as in round 2 */
-#endif
-#ifndef MFM3_BARRIER_LATE
-#define MFM3_BARRIER_LATE 0 /* 1: A/B builds - the tile's barrier behind the epilogue instead of in front of it */
-#endif
-#ifndef MFM3_ROT4
-#define MFM3_ROT4 1 /* rotator-table entries of 4 bytes (rr | ri << 16) instead of 8 ({(rr, -ri), (ri, rr)}; 0: A/B builds): half
-                       the table bytes per output for two cheap and one expensive instruction per entry (the two dot-product
-                       operands are rebuilt in registers).  At 1024 channels the tables are what misses L2 (each workgroup
-                       re-reads its 64 channels' periodic table parts every other tile while input and output stream
-                       through): 5.25 -> 2.21 GB per launch together with the stores' hint below, and 3 % faster
-                       (profiles/r04_traffic_1024ch.txt).  The engine builds what mfm_rot_entry_bytes_v3() says. */
-#endif
-#define MFM3_ES (MFM3_ROT4 ? 4u : 8u) /* bytes per rotator-table entry */
-#ifndef MFM3_NONTEMPORAL
-#define MFM3_NONTEMPORAL 2 /* bit 1: the PCM stores carry the non-temporal hint - the 8-byte stores of a tile leave L2 as whole
-                              lines instead of being written back piecemeal (WRITE_SIZE 1.23 x the PCM bytes without it,
-                              0.98 x with it) and stop pushing the rotator tables out; bit 0 (A/B builds): the image loads
-                              too - wrong, the slices of a chunk share the image through L2 (fetch + 40 %, 4 % slower) */
-#endif
-#ifndef MFM3_SP
-#define MFM3_SP 4096u /* bytes between the four sub-planes of a byte plane at the fixed geometries (A/B builds: 4160 - not a
-                         multiple of the LDS bank cycle, so that the image stores of rows r and r + 1 do not meet in one bank) */
-#endif
-#ifndef MFM3_EPI_SERIAL
-#define MFM3_EPI_SERIAL 0
-#endif
-#ifndef MFM3_DIV_STEPS
-#define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
-#endif
-#ifndef MFM3_LUT_MODE
-#define MFM3_LUT_MODE 1 /* the arctangent table in LDS: 1 {T, dT} pairs, one 8-byte read per output (banked over 64 dwords);
-                         * 0 (rounds 2-3, A/B builds) T[256] then dT[256], one ds_read2st64_b32 (banked over 32): the table's
-                         * data-dependent addresses were 88 % of the kernel's SQ_LDS_BANK_CONFLICT cycles, the pair form halves
-                         * them (25 % -> 17 % of LDS cycles) at the same instruction count; 2 counter builds only - every lane
-                         * reads its own bank (wrong PCM): the kernel without those conflicts, 1.5 % faster, which a table
-                         * replicated per bank would give and LDS (2 x 78.8 KB per CU) has no room for.
-                         * profiles/r04_lds_conflicts.txt */
-#endif
-#define MFM3_LUT_SLOT(t) (MFM3_LUT_MODE == 1 ? (t) : ((t) >> 1) + (((t)&1u) << 8))
-#define MFM3_SCHED_ALL_BUT_VMEM 0x38F
-
-/* (hh << 16) + (md << 8) + ll, two v_lshl_add_u32 (left to itself the compiler makes it two shifts and a three-operand
- * add).  The accumulators come straight from MFMAs and the compiler does not pad the MFMA -> VALU read hazard for what it
- * cannot see inside inline asm: callers put 16 wait states between the last MFMA and this. */
-static __device__ __forceinline__ uint32_t mfm3_combine(int hh, int md, int ll)
-{
-    uint32_t t, a;
-    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(hh), "v"(md));
-    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a) : "v"(t), "v"(ll));
-    return a;
-}
-
-/* bits 29:14 of re_b and im_b (biased sums) as (re | im << 16), for two pairs: four SDWA shifts (see
- * mfm_kernel_mfma.hip for the hazard notes: one wait state between a dst_sel write and the PRESERVE read) */
-static __device__ __forceinline__ void mfm3_round_pack2(const uint32_t re_b[2], const uint32_t im_b[2], uint32_t p[2])
-{
-    uint32_t p0, p1;
-    asm("v_lshrrev_b32_sdwa %0, 14, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %1, 14, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %0, 14, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %1, 14, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_nop 0"
-        : "=&v"(p0), "=&v"(p1)
-        : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]));
-    p[0] = p0;
-    p[1] = p1;
-}
-
-/* the same with the shift as a template argument (8-bit input: the sums are 128 times smaller for the RTL-SDR scaling) */
-template <int SH>
-static __device__ __forceinline__ void mfm3_round_pack2_sh(const uint32_t re_b[2], const uint32_t im_b[2], uint32_t p[2])
-{
-    uint32_t p0, p1;
-    asm("v_lshrrev_b32_sdwa %0, %6, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %1, %6, %3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %0, %6, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "v_lshrrev_b32_sdwa %1, %6, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-        "s_nop 0"
-        : "=&v"(p0), "=&v"(p1)
-        : "v"(re_b[0]), "v"(re_b[1]), "v"(im_b[0]), "v"(im_b[1]), "n"(SH));
-    p[0] = p0;
-    p[1] = p1;
-}
-
-/* o = f * r + 8192: two VOP3P v_dot2_i32_i16 (3 wait states before the results are read) */
-static __device__ __forceinline__ void mfm3_rotate_biased(uint32_t f, uint32_t rx, uint32_t ry, uint32_t *o_re,
-                                                          uint32_t *o_im)
-{
-    asm("v_dot2_i32_i16 %0, %2, %3, %5\n\tv_dot2_i32_i16 %1, %2, %4, %5\n\ts_nop 2"
-        : "=&v"(*o_re), "=&v"(*o_im)
-        : "v"(f), "v"(rx), "v"(ry), "s"(8192));
-}
-
-/* s = q * conj(p), wrapping int32 (multifm/fm_demod.c:55-64) */
-static __device__ __forceinline__ void mfm3_conj_mul(uint32_t q, uint32_t p, int *s_re, int *s_im)
-{
-    int u, t;
-    asm("v_dot2_i32_i16 %0, %3, %4, 0\n\t"
-        "v_mad_i32_i16 %1, %3, %4, 0 op_sel:[1,0,0,0]\n\t"
-        "v_mad_i32_i16 %2, %3, %4, 0 op_sel:[0,1,0,0]\n\t"
-        "s_nop 0"
-        : "=&v"(*s_re), "=&v"(u), "=&v"(t)
-        : "v"(q), "v"(p));
-    *s_im = (int)((uint32_t)u - (uint32_t)t);
-}
-
-/* derotation + second rounding of two packed samples (filter/direct_fir.c:406-413) */
-static __device__ __forceinline__ void derotate2(const uint32_t fin[2], const uint32_t rx[2], const uint32_t ry[2], uint32_t qout[2])
-{
-    uint32_t o_re[2], o_im[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        mfm3_rotate_biased(fin[c], rx[c], ry[c], &o_re[c], &o_im[c]);
-    }
-    mfm3_round_pack2(o_re, o_im, qout);
-}
-
-/* f * (+-1) per int16 half, wrapping: r14(f * +-16384) of filter/direct_fir.c:406-413 (the int16 cast of filter/complex.h:33
- * wraps -(-32768) to -32768, and so does the low half of a 16-bit product).  sg = (factor of even outputs) | (factor of odd
- * outputs) << 16, each 1 or 0xffff. */
-static __device__ __forceinline__ uint32_t mfm3_sign_flip(uint32_t f, uint32_t sg, int odd)
-{
-    uint32_t q;
-    if (odd) {
-        asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(q) : "v"(f), "v"(sg));
-    } else {
-        asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(q) : "v"(f), "v"(sg));
-    }
-    return q;
-}
-
-static __device__ __forceinline__ uint32_t mfm3_opaque(uint32_t v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-/* a 4-byte rotator entry r = (rr | ri << 16) as the two dot-product operands of the derotation: (rr, -ri) and (ri, rr).  The
- * engine refuses rotators that reach ri = -32768, so the negated half never wraps. */
-static __device__ __forceinline__ uint32_t mfm3_rot_x(uint32_t r)
-{
-    return (r ^ 0xffff0000u) + 0x00010000u;
-}
-
-static __device__ __forceinline__ uint32_t mfm3_rot_y(uint32_t r)
-{
-    return __builtin_amdgcn_alignbit(r, r, 16);
-}
-
-/* rotator-table position of output index (kb + d) of a channel: pre-period as is, then folded into the period */
-static __device__ __forceinline__ uint32_t mfm3_fold(uint32_t kb, uint32_t d, uint32_t mu, uint32_t lam, uint32_t lam_magic)
-{
-    uint32_t k = kb + d;
-    if (k >= mu) {
-        const uint32_t x = k - mu;
-        uint32_t m = x - __umulhi(x, lam_magic) * lam;
-        m = (m >= lam) ? m - lam : m;
-        k = mu + m;
-    }
-    return k;
-}
-
-/* t mod lam for any 32-bit t, lam_magic = floor(2^32 / lam): the quotient estimate is at most one short */
-static __device__ __forceinline__ uint32_t mfm3_mod_step(uint32_t t, uint32_t lam, uint32_t lam_magic)
-{
-    const uint32_t m = t - __umulhi(t, lam_magic) * lam;
-    return (m >= lam) ? m - lam : m;
-}
-
-/* the same for a 64-bit output index: a stream at the bench's rate passes 2^32 outputs per channel within a second.
- * k - mu is reduced mod lam (< 2^27: the engine's table limit) five bits at a time, so that everything stays 32-bit. */
-static __device__ __forceinline__ uint32_t mfm3_fold64(uint64_t k, uint32_t mu, uint32_t lam, uint32_t lam_magic)
-{
-    if (k < (uint64_t)mu) {
-        return (uint32_t)k;
-    }
-    const uint64_t x = k - mu;
-    const uint32_t xl = (uint32_t)x;
-    uint32_t a = mfm3_mod_step((uint32_t)(x >> 32), lam, lam_magic);
-#pragma unroll
-    for (int s = 27; s >= 2; s -= 5) {
-        a = mfm3_mod_step((a << 5) | ((xl >> s) & 31u), lam, lam_magic);
-    }
-    a = mfm3_mod_step((a << 2) | (xl & 3u), lam, lam_magic);
-    return mu + a;
-}
-
-/*
- * Four discriminators (multifm/fm_demod.c:68-72 on fast_atan2f.c:101-174), same operations in the same order as
- * mfm_discriminate() in mfm_numerics.h (the form the host twin proves against the oracle), written for the issue
- * costs measured on gfx950 (profiles/r02_ubench_ops.txt): fp32 mul / add / fma and 32-bit add / and / xor / shift-right
- * take one issue slot, conversions, min / max, compares, selects, v_fract, SDWA / DPP and packed forms two, v_rcp_f32
- * four.  So the division is scalar FMAs (no packed math: nothing to gain, registers to lose), and the table index comes
- * out of the float adder: floor(alpha) + 2^21 has 4 * floor(alpha) in its low mantissa bits - the byte offset of
- * T[floor(alpha)] - which saves the conversion and the shift.
- * lut_addr: LDS byte address of the table: {T[i], dT[i]} pairs (MFM3_LUT_MODE 0: T[0], with dT[0] 1024 bytes behind it).
- */
-static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], const int s_im[4], uint32_t lut_addr, int pcm[4])
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma clang fp contract(off)
-    float x[4], y[4], mx[4], mn[4], z[4], fr[4], t0[4], dt[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        x[i] = (float)s_re[i];
-        y[i] = (float)s_im[i];
-        asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx[i]) : "v"(x[i]), "v"(y[i]));
-        asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn[i]) : "v"(x[i]), "v"(y[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        /* mfm_div_unit: correctly rounded mn / mx (one residual step behind the quotient estimate: mfm_numerics.h has the
-         * argument and tools/div_proof.c the enumeration behind it) */
-        const float r0 = __builtin_amdgcn_rcpf(mx[i]);
-        const float e0 = __builtin_fmaf(-mx[i], r0, 1.0f);
-        const float r1 = __builtin_fmaf(e0, r0, r0);
-        const float q0 = mn[i] * r1;
-        const float e1 = __builtin_fmaf(-mx[i], q0, mn[i]);
-        z[i] = __builtin_fmaf(e1, r1, q0);
-#if MFM3_DIV_STEPS > 1
-        z[i] = __builtin_fmaf(__builtin_fmaf(-mx[i], z[i], mn[i]), r1, z[i]);
-#endif
-    }
-    typedef const __attribute__((address_space(3))) float *lds_fp;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
-        fr[i] = __builtin_amdgcn_fractf(alpha);        /* :127 (alpha - floor(alpha), exact) */
-        const float fl = alpha - fr[i];                /* floor(alpha), 0..255 (NaN for (0, 0)) */
-#if MFM3_LUT_MODE == 1
-        const float m = fl + 1048576.0f;               /* bits 0x49800000 + 8 * floor(alpha) */
-        /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
-        const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x49800000u);
-        typedef const __attribute__((address_space(3))) float2 *lds_f2p;
-        const float2 pr = *(lds_f2p)(uintptr_t)addr;
-        t0[i] = pr.x;
-        dt[i] = pr.y;
-#else
-        const float m = fl + 2097152.0f;               /* bits 0x4A000000 + 4 * floor(alpha) */
-        /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
-#if MFM3_LUT_MODE == 2
-        /* bit 0 of lut_addr set by the channel kernel only: the commit-time self-test keeps the real table reads */
-        const uint32_t addr = (lut_addr & 1u) ? (lut_addr - 1u) + 4u * (__lane_id() + 64u * (uint32_t)i)
-                                              : __float_as_uint(m) + (lut_addr - 0x4A000000u);
-#else
-        const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x4A000000u);
-#endif
-        lds_fp p = (lds_fp)(uintptr_t)addr;
-        t0[i] = p[0];
-        dt[i] = p[256];
-#endif
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float prod = dt[i] * fr[i];
-        const float interp = t0[i] + prod;             /* :130-131, unfused */
-        const float base = (z[i] < MFM_TAN_MAP_RES_F) ? z[i] : interp;
-        /* :134-163: sign(y) * (K + u), K in {0, pi, pi/2}, u = +-base */
-        const bool x_nonneg = s_re[i] >= 0, wide = __builtin_fabsf(x[i]) > __builtin_fabsf(y[i]);
-        const float k = wide ? (x_nonneg ? 0.0f : MFM_PI_F) : MFM_HALF_PI_F;
-        const float u = (x_nonneg == wide) ? base : -base;
-        const float mag = k + u;
-        const float lo = mag * MFM_Q14_OVER_PI_LO;
-        const float sc = __builtin_fmaf(mag, MFM_Q14_OVER_PI_HI, lo);
-        int signed_sc;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(signed_sc) : "s"(0x7fffffff), "v"(sc), "v"(s_im[i]));
-        pcm[i] = (int)__int_as_float(signed_sc);       /* NaN (from (0, 0)) converts to 0 = fast_atan2f.c:111-112 */
-    }
-#else
-    (void)s_re, (void)s_im, (void)lut_addr, (void)pcm;
-#endif
-}
-
-/* one work item = (chunk of consecutive tiles, 64-channel slice); XCD-aware: the slices of a chunk run back to back
- * on one XCD, so the chunk's input is fetched from HBM once and re-read from that XCD's L2 */
-static __device__ __forceinline__ bool mfm3_decode_item(const mfm_launch_v3 &L, uint32_t item, uint32_t *chunk, uint32_t *slice)
-{
-    const uint32_t xcd = item & 7u, seq = item >> 3;
-    *chunk = (seq / L.nslices) * 8u + xcd;
-    *slice = seq % L.nslices;
-    return item < L.nitems && *chunk < L.nchunks;
-}
+#include "mfm_v3_device.h"
 
 /*
  * Hand-scheduled column group for the decimation-96 / 128-tap geometry (DFIX = 96, KQ = 4, AHM = 0x6: the high-byte tap
@@ -1453,9 +1161,34 @@ extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pc
  * ah_mask, in8), all fixed at commit.  The engine asks once per input format at commit, raises the instance's LDS limit
  * there (hipFuncSetAttribute is a driver call; round 2 paid it on every launch) and launches through the pointer.
  */
+/* layout 3 (long filters): the instances live in mfm_kernel_v3l.hip, one translation unit per k-step count */
+#define MFM3L_IMPORT(KQ_) extern "C" const void *mfm_v3l_instance_kq##KQ_(const mfm_launch_v3 *L, uint32_t nch);
+MFM3L_IMPORT(6) MFM3L_IMPORT(8) MFM3L_IMPORT(9) MFM3L_IMPORT(10) MFM3L_IMPORT(11) MFM3L_IMPORT(12) MFM3L_IMPORT(14) MFM3L_IMPORT(16)
+#undef MFM3L_IMPORT
+
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out)
 {
     *kfn_out = nullptr;
+    if (L->layout == 3u) {
+        /* L->kq is a built count of k-steps (mfm_v3l_built_kq), the tap fragments are laid out for exactly that many */
+        const uint32_t nch4 = (L->nstage4 + MFM3_NT - 1) / MFM3_NT;
+        if (dbg_iq || nch4 < 1 || nch4 > MFM_V3_CH_MAX || (L->ng != 2u && L->ng != 4u) || L->kq_used > L->kq || L->nh > L->kq ||
+            L->kq != mfm_v3l_built_kq(L->kq) || (L->in8 != 0u && L->in8 != 7u && L->in8 != 14u)) {
+            return hipErrorInvalidValue;
+        }
+        switch (L->kq) {
+        case 6: *kfn_out = mfm_v3l_instance_kq6(L, nch4); break;
+        case 8: *kfn_out = mfm_v3l_instance_kq8(L, nch4); break;
+        case 9: *kfn_out = mfm_v3l_instance_kq9(L, nch4); break;
+        case 10: *kfn_out = mfm_v3l_instance_kq10(L, nch4); break;
+        case 11: *kfn_out = mfm_v3l_instance_kq11(L, nch4); break;
+        case 12: *kfn_out = mfm_v3l_instance_kq12(L, nch4); break;
+        case 14: *kfn_out = mfm_v3l_instance_kq14(L, nch4); break;
+        case 16: *kfn_out = mfm_v3l_instance_kq16(L, nch4); break;
+        default: break;
+        }
+        return *kfn_out ? hipSuccess : hipErrorInvalidValue;
+    }
     const uint32_t nch = (L->nstage4 + MFM3_NT - 1) / MFM3_NT;
     if (nch < 1 || nch > MFM_V3_CH_MAX) {
         return hipErrorInvalidValue;
