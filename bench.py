@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--settle-seconds", type=float, default=0.75)
     ap.add_argument("--channels-per-gpu", type=int, default=None,
                     help="default 64 at N = 1 (BASELINE configs[1]), 128 at N > 1 (configs[2]: 1024 channels on 8 GPUs)")
-    ap.add_argument("--kernel", choices=["auto", "mfma1", "mfma1s", "dot2"], default="auto",
+    ap.add_argument("--kernel", choices=["auto", "mfma1", "mfma1s", "dot2", "v3l1"], default="auto",
                     help="mfma1 / dot2 = the first-generation matrix kernel / the v_dot2 kernel through the "
                          "MFM_F_FORCE_* flags (A/B timing)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
@@ -624,7 +624,8 @@ def main():
                      (pkg.binding.MFM_F_OVERLAP if args.overlap else 0) |
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
                      (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0) |
-                     (pkg.binding.MFM_F_STREAM_TAPS if args.kernel == "mfma1s" else 0),
+                     (pkg.binding.MFM_F_STREAM_TAPS if args.kernel == "mfma1s" else 0) |
+                     (pkg.binding.MFM_F_V3L_ONE_ROW_BLOCK if args.kernel == "v3l1" else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))
@@ -777,6 +778,7 @@ def main():
             "config": {"workload": f"{args.config}: {cpg} FM channels per GPU ({total_ch} total), {T}-tap 25 kHz LPF, "
                                    f"decimation {decim}, fs {fs} Hz-shaped int16 IQ, block 2^{args.block_log2} samples",
                        "channels_per_gpu": cpg, "channels_total": total_ch, "block_samples": block,
+                       "decimation": int(decim), "taps": int(T), "sample_rate_hz": int(fs),
                        "input_msamp_per_s": msamp,
                        "parallelism": "1 GPU" if not use_dist else
                                       f"channel shards x{world} + RCCL {exchange.algo} of the IQ block"},

@@ -88,6 +88,9 @@ extern "C" {
                                   its last tile and a dispatch.  mfm_engine_stream() then returns the stream of the most
                                   recent launch; per-launch durations (MFM_F_TIMING) include the time a launch waits for
                                   slots and are no longer kernel time.  Ignored by the other kernels. */
+#define MFM_F_V3L_ONE_ROW_BLOCK 0x400u /* long filters on the second generation (mfm_kernel_v3l.hip): one row block (8 channels) per
+                                  wave - slices of 64 channels - also where two would fit (slices of 128: the default for more
+                                  than 64 channels when two row blocks' taps fit 128 registers); same bits; parity tests, A/B timing */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 

@@ -156,7 +156,8 @@ def test_hand_counted_lds_waits_cover_their_reads():
     assert (reads, viol, unv) == (2, 2, 0)
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("no llvm tools here")
-    for obj, flt, least in (("mfm_kernel_mfma.o", "mfm_channel_kernel_mfma<", 100), ("mfm_kernel_v3.o", "mfm_channel_kernel_v3<", 60)):
+    long_objs = [(f"mfm_kernel_v3l_kq{k}.o", "mfm_channel_kernel_v3l<", 40) for k in (6, 8, 9, 10, 11, 12, 14, 16)]
+    for obj, flt, least in [("mfm_kernel_mfma.o", "mfm_channel_kernel_mfma<", 100), ("mfm_kernel_v3.o", "mfm_channel_kernel_v3<", 60)] + long_objs:
         path = os.path.join(root, "tsl-sdr_amd", "build", obj)
         if not os.path.exists(path):
             pytest.skip("no built object")
@@ -164,3 +165,31 @@ def test_hand_counted_lds_waits_cover_their_reads():
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("mfm_channel_kernel")]
         assert r.returncode == 0 and len(lines) >= least, (r.returncode, len(lines), r.stdout[-2000:])
         assert all(" violations 0 " in ln for ln in lines)
+
+
+def test_long_filter_instances_do_not_spill_where_it_would_matter():
+    """mfm_kernel_v3l.hip: the instances with one row block per wave must not use scratch at all; those with two (128 tap
+    registers) may park chunk set-up values there - outside the matrix phase, which test_hand_counted_lds_waits_cover_their_reads
+    checks instruction by instruction (a fragment register spilled between its request and its wait would be a violation)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no llvm tools here")
+    seen = 0
+    for k in (6, 8, 9, 10, 11, 12, 14, 16):
+        path = os.path.join(root, "tsl-sdr_amd", "build", f"mfm_kernel_v3l_kq{k}.o")
+        if not os.path.exists(path):
+            pytest.skip("no built object")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py"), path, "mfm_channel_kernel_v3l<"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for ln in r.stdout.splitlines():
+            m = re.match(r"mfm_channel_kernel_v3l<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)>.*vgpr +(\d+).*scratch +(\d+)", ln)
+            assert m, ln
+            seen += 1
+            if int(m.group(6)) == 1:
+                assert int(m.group(8)) == 0, ln
+            assert int(m.group(7)) <= 256
+    assert seen >= 300

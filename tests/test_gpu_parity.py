@@ -414,7 +414,9 @@ def test_decimations_that_are_not_multiples_of_8_run_on_the_matrix_kernel(pkg, o
     # decimation 25 with up to 150 taps: the second generation on padded rows (round 4) - unless a channel wants its filtered
     # IQ; every other decimation of this list: the first generation
     # ... and, round 5, filters of 129 taps and more (mfm_kernel_v3l.hip takes any decimation the first generation takes)
-    assert st["kernel_variant"] == (2 if decim == 25 or ntaps > 128 else 1), st
+    row_bytes = (2 * decim + 15) & ~15
+    k_steps = -(-(((ntaps - 1) // decim) * row_bytes + 2 * ((ntaps - 1) % decim) + 2) // 64)  # of 64 elements, padding included
+    assert st["kernel_variant"] == (2 if decim == 25 or k_steps >= 5 else 1), st
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, want_iq=(nch == 2))
     _check(pkg, ora, fs, decim, taps, offs, iq, 5000, want_iq=False)
     if decim == 25:
@@ -735,7 +737,9 @@ def test_gpu_8bit_blocks_read_as_bytes_by_the_matrix_kernel(pkg, ora, fmt, geom)
                     # 7 / 5 / 5 k-steps of taps held in registers (one and two staging chunks per thread)
                     "d25_t170": (25, 170), "d30_t150": (30, 150), "d24_t140": (24, 140)}[geom]
     # d40: chunk-row layout; d25_t128: padded rows (round 4; 170 taps span seven rows and stay on the first generation)
-    variant = 2 if geom in ("d96_t128", "d32_t32", "d64_t64", "d128_t128", "d40_t64", "d25_t128") else 1
+    # round 5: the long filters and the odd decimations whose padded filter spans five k-steps or more run the second
+    # generation's long-filter kernel (mfm_kernel_v3l.hip)
+    variant = 1 if geom in ("d96_t128_gen1", "d7_t33") else 2
     base_flags = pkg.binding.MFM_F_FORCE_MFMA_V1 if geom == "d96_t128_gen1" else 0
     taps = pkg.synth.design_lpf(ntaps, 9000.0, fs) * (3.0 if geom in ("d96_t512", "d7_t33") else 1.0)
     offs = [25000 * k + (137 if k % 3 == 0 else 0) for k in range(-9, 10)]

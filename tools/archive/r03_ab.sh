@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants on one box: tools/r03_ab.sh <variant...>   ("lib" = the shipped library, else tools/exp/libexp_<v>.so)
+# A/B of library variants on one box: tools/archive/r03_ab.sh <variant...>   ("lib" = the shipped library, else tools/exp/libexp_<v>.so)
 # per variant: a quick parity run (cfg2 + mixed rotator classes), then alternating bench runs at 2^26 and 2^22-sample blocks
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03ab; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants on the long-filter shapes, same box: tools/r03_resab.sh <variant...>  ("lib" = the shipped library)
+# A/B of library variants on the long-filter shapes, same box: tools/archive/r03_resab.sh <variant...>  ("lib" = the shipped library)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03resab; mkdir -p $O
 B="--no-fp32 --no-chain --no-cpu-baseline --steps 40 --warmup 20"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# clock and counters with one workgroup per CU against two (tools/r04_call16.sh has the times)
+# clock and counters with one workgroup per CU against two (tools/archive/r04_call16.sh has the times)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04p; rm -rf $O; mkdir -p $O
 B="--no-cpu-baseline --no-fp32 --no-chain --no-series"

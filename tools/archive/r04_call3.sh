@@ -2,7 +2,7 @@
 # round 4, third GPU call: v_rcp_f32's table + the division proof on it; the coalescing / overlap tests; the default bench line
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04c; rm -rf $O; mkdir -p $O
-timeout 300 tools/rcp_check $O/rcp_dev.bin > $O/rcp_check.txt 2>&1; echo "rcp_check rc=$?"; cat $O/rcp_check.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/rcp_check tools/rcp_check.hip && timeout 300 /tmp/rcp_check $O/rcp_dev.bin > $O/rcp_check.txt 2>&1; echo "rcp_check rc=$?"; cat $O/rcp_check.txt
 gcc -O2 -ffp-contract=off -march=native -o /tmp/div_proof tools/div_proof.c -lm -lpthread
 for st in 1 2; do timeout 300 /tmp/div_proof $st 32 - $O/rcp_dev.bin > $O/div_proof_steps$st.txt 2>&1; echo "rc=$?" >> $O/div_proof_steps$st.txt; tail -4 $O/div_proof_steps$st.txt; done
 rm -f $O/rcp_dev.bin

@@ -55,7 +55,7 @@ def case(pkg, ora, rng, long_only=False):
         iq = pkg.synth.synth_iq(n, fs, offs[: min(nch, 6)], seed=int(rng.randint(1 << 30)))
     max_block = int(rng.choice([n, 65536, 8192, 100000]))
     flags = (b.MFM_F_FORCE_DOT2 if kernel == "dot2" else 0) | (b.MFM_F_FORCE_MFMA_V1 if kernel == "mfma1" else 0) | \
-            (b.MFM_F_STREAM_TAPS if stream else 0)
+            (b.MFM_F_STREAM_TAPS if stream else 0) | (b.MFM_F_V3L_ONE_ROW_BLOCK if rng.rand() < 0.3 else 0)
     try:
         eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
         for o, g in zip(offs, gains):

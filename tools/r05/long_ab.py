@@ -65,7 +65,7 @@ def main():
     out = {}
     for key, plan, nch in SHAPES:
         row = {}
-        for name, flags in (("v3l", 0), ("v1", b.MFM_F_FORCE_MFMA_V1), ("v3l_again", 0)):
+        for name, flags in (("v3l", 0), ("v1", b.MFM_F_FORCE_MFMA_V1), ("v3l_again", b.MFM_F_V3L_ONE_ROW_BLOCK)):
             try:
                 row[name] = one(plan, nch, block, flags)
             except Exception as e:
@@ -75,7 +75,7 @@ def main():
         if "kernel_ms" in a and "kernel_ms" in c:
             print(f"{key:32s} D={a['decimation']:4d} T={a['taps']:4d} C={nch:4d} mask={a['mask']:#06x} v3l {a['kernel_ms']:.4f} ms "
                   f"({a['ps_per_chan_out']:.2f} ps, variant {a['variant']}, lds {a['lds']})  v1 {c['kernel_ms']:.4f} ms "
-                  f"({c['ps_per_chan_out']:.2f} ps)  ratio {a['kernel_ms'] / c['kernel_ms']:.3f}  again {row['v3l_again'].get('kernel_ms', 0):.4f}",
+                  f"({c['ps_per_chan_out']:.2f} ps)  ratio {a['kernel_ms'] / c['kernel_ms']:.3f}  one-row-block {row['v3l_again'].get('kernel_ms', 0):.4f}",
                   flush=True)
         else:
             print(key, row, flush=True)

@@ -54,9 +54,12 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "quick":
             break
     # the bench's shapes at a small size
-    for plan, nch in (("cfg5_airspy", 256), ("pocsag_rtlsdr_256taps", 64), ("pocsag_airspy", 64), ("multifm_airspy", 64)):
+    for plan, nch in (("cfg5_airspy", 256), ("cfg5_airspy", 130), ("cfg5_airspy", 77), ("pocsag_rtlsdr_256taps", 64), ("pocsag_rtlsdr_256taps", 200),
+                      ("pocsag_airspy", 64), ("pocsag_airspy", 129), ("multifm_airspy", 64), ("multifm_airspy", 192)):
         fs2, decim, taps, offs2, gains = pkg.synth.plan(plan, nr_channels=nch)
         ok &= run(plan, fs2, decim, taps, offs2, decim * 700 + len(taps) + 3, 1 << 17, gains=gains)
+        ok &= run(plan + "/30001", fs2, decim, taps, offs2, decim * 700 + len(taps) + 3, 30001, gains=gains)
+        ok &= run(plan + "/one-rb", fs2, decim, taps, offs2, decim * 700 + len(taps) + 3, 1 << 17, gains=gains, flags=b.MFM_F_V3L_ONE_ROW_BLOCK)
     print("ALL OK" if ok else "FAILURES")
     return 0 if ok else 1
 

@@ -24,6 +24,7 @@ MFM_F_GROUP_SHARED_DEVICE = 0x40
 MFM_F_STREAM_TAPS = 0x80
 MFM_F_GATHER = 0x100
 MFM_F_OVERLAP = 0x200
+MFM_F_V3L_ONE_ROW_BLOCK = 0x400
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)

@@ -176,7 +176,8 @@ struct mfm_engine {
              v_within[4] = { 0, 0, 0, 0 };
     uint32_t v_layout = 0, v_t_per = 0, v_t_pitch = 0; /* mfm_launch_v3::layout: chunk rows for decimations % 32 != 0 */
     /* layout 3, long filters (mfm_kernel_v3l.hip): plain rows; v_rs = row stride, v_plane = bytes of one byte plane */
-    uint32_t v_plane = 0, v_ng = 0, v_nstage_p = 0, v_sta_bytes = 0;
+    uint32_t v_plane = 0, v_ng = 0, v_nstage_p = 0, v_sta_bytes = 0, v_rb = 1;
+    uint32_t v_nslices = 0; /* channel slices of the second-generation launches: of 64 channels, or of 128 (v_rb = 2) */
     uint32_t v_kq = 0, v_nh = 0, v_kperm[4] = { 0, 0, 0, 0 }; /* the instance's k-step count, k-steps with a high-byte tap plane,
                                                                  and the order the k-steps are laid out in (mfm_launch_v3::kperm) */
     uint32_t *d_afrag = nullptr;
@@ -313,9 +314,10 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
             V.kperm[k] = e->v_kperm[k];
         }
         V.ng = e->v_ng;
+        V.rb = e->v_rb;
         V.nstage_p = e->v_nstage_p;
     }
-    V.nslices = e->m_nslices;
+    V.nslices = e->v_nslices;
     V.nrb = e->m_nrb;
     V.nchan = (uint32_t)e->chans.size();
     V.out_stride = e->out_stride;
@@ -1157,7 +1159,16 @@ static int commit_locked(struct mfm_engine *e)
         }
         const uint32_t reach = (k_elems - 1u) / row_bytes;                       /* rows the last window reaches past its own */
         const uint32_t reach_read = (64u * kq_inst - 1u) / row_bytes + 1u;       /* ... and what the instance's fragment reads touch */
-        for (uint32_t ng : { 4u, 2u }) {
+        /* (row blocks per wave, column groups per image), best first: slices of 128 channels - half the staging work and
+         * half the B-fragment traffic per (channel, output) - where there are more than 64 channels and two row blocks' taps
+         * fit 128 registers, on quarter-tile images; else slices of 64 on whole- or half-tile images */
+        const uint32_t nh_inst = mfm_v3l_built_nh(kq_inst, (uint32_t)__builtin_popcount(hi_mask));
+        struct { uint32_t rb, ng; } cand[3] = { { 2u, 1u }, { 1u, 4u }, { 1u, 2u } };
+        for (const auto &cd : cand) {
+            const uint32_t ng = cd.ng, rbw = cd.rb;
+            if (2u == rbw && (e->m_nrb <= 8u || 8u * (kq_inst + nh_inst) > 128u || (e->cfg.flags & MFM_F_V3L_ONE_ROW_BLOCK))) {
+                continue;
+            }
             const uint32_t opi = 16u * ng;
             const uint32_t plane = (opi + std::max(reach, reach_read)) * rs_l;
             const uint32_t nstage4 = ((opi + reach) * D + 3u) / 4u;
@@ -1165,27 +1176,29 @@ static int commit_locked(struct mfm_engine *e)
             if (nch > MFM_V3_CH_MAX || plane >= 65536u || kq_inst > e->m_ks) {
                 continue;
             }
-            const uint32_t sta = mfm_v3l_built_nch(nch) * 2048u; /* the instance's count: a surplus chunk is loaded and not stored */
-            const uint32_t aux = 8u * 8u * MFM_V3L_TP * 4u + 512u + 512u + 2048u;
+            /* the instance's count of chunks (a surplus chunk is loaded and not stored); 16-bit offsets where no chunk straddles rows */
+            const uint32_t sta = mfm_v3l_built_nch(nch) * ((D % 4u) != 0u ? 2048u : 1024u);
+            const uint32_t aux = 8u * 8u * rbw * MFM_V3L_TP * 4u + 512u * rbw + 2048u * rbw;
             const uint32_t lds = 4u * plane + 2048u + sta + aux;
             if (lds > 160u * 1024u) {
                 continue;
             }
-            /* is the int16 instance for this geometry and tap-plane mask built?  (All are but the sixteen-step form that
-             * holds every high-byte plane with many staging chunks in flight: it would spill.)  The mask must be known HERE:
-             * the second generation orders its rows by rotator class, the first does not. */
+            /* is the int16 instance for this geometry built?  (All are but a few that would need more than 256 registers.)  It
+             * must be known HERE: the second generation orders its rows by rotator class, the first does not. */
             mfm_launch_v3 probe{};
             probe.layout = 3u;
             probe.kq = kq_inst;
             probe.kq_used = e->m_kq_used;
             probe.nh = (uint32_t)__builtin_popcount(hi_mask);
             probe.ng = ng;
+            probe.rb = rbw;
             probe.nstage4 = nstage4;
             probe.ah_mask = hi_mask;
             const void *fn = nullptr;
             if (mfm_select_channel_kernel_v3(&probe, 0, &fn) != hipSuccess) {
                 continue;
             }
+            e->v_rb = rbw;
             e->use_v3 = true;
             e->v_layout = 3u;
             e->v_rs = rs_l;
@@ -1222,6 +1235,8 @@ static int commit_locked(struct mfm_engine *e)
             break;
         }
     }
+
+    e->v_nslices = (e->use_v3 && 3u == e->v_layout) ? (e->m_nrb + 8u * e->v_rb - 1u) / (8u * e->v_rb) : e->m_nslices;
 
     /* ---- rotator classes and row order (filter/direct_fir.c:151-172,406-413).  An increment of exactly (16384, 0) - every
      *      channel whose offset is a multiple of the output rate, e.g. a 25 kHz grid at 2.4 MS/s / 96 - leaves the rotator at
@@ -1625,7 +1640,7 @@ int launch_locked(mfm_engine *e)
          * behind the [hist | tail] front of this buffer, which the previous launch's carry wrote on the OTHER stream: the
          * copy below is then ordered behind everything it reads (the H2D copies, through in_ready) without a wait of its
          * own.  True for every launch of more than a tile per slot; spelled out so that it does not rest on that. */
-        two = (uint64_t)ntiles * e->m_nslices > slots && (uint64_t)n_new * D >= (uint64_t)e->tail + D;
+        two = (uint64_t)ntiles * e->v_nslices > slots && (uint64_t)n_new * D >= (uint64_t)e->tail + D;
     }
     hipStream_t S_after = two ? e->cs[e->si ^ 1u] : S;
     if (e->ncs > 1u && !two && e->in_free_wait[nxt]) {

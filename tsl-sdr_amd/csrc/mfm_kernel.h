@@ -235,10 +235,14 @@ struct mfm_launch_v3 {
                              needs no mask - then the other ones that hold taps, then (up to kq, the instance's count) steps
                              of zero taps.  Integer sums do not care about the order. */
     uint32_t kperm[4];    /* byte j: which 64-element step of the window is multiplied j-th */
-    uint32_t ng;          /* column groups per staged image: 4 or 2 */
+    uint32_t ng;          /* column groups per staged image: 4, 2 or 1 */
+    uint32_t rb;          /* row blocks (16 GEMM rows = 8 channels) per wave: 1 - slices of 64 channels - or 2 - slices of 128:
+                             half the staging work and half the B-fragment traffic per (channel, output), where two row
+                             blocks' taps fit 128 registers (no or few high-byte planes: configs[4]'s filter) */
     uint32_t nstage_p;    /* 4-sample chunks of the one-group image in front of a chunk's first tile (its column 0 is the
                              output in front of the chunk, recomputed) */
-    uint32_t tp_off;      /* LDS byte offset of the transposition areas: [8 waves][8 channels][72] dwords */
+    uint32_t tp_off;      /* LDS byte offset of the transposition areas: [8 waves][8 * rb channels][72] dwords, then the fold
+                             constants (512 * rb bytes) and the exact-rotator tables (2048 * rb bytes) */
     uint32_t *tail_dst;
     const uint32_t *afrag;
     const int32_t *krow;

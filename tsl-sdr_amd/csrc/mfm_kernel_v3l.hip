@@ -82,16 +82,17 @@ static __device__ __forceinline__ void mfm3l_wait_fragments(int younger, mfm_v4i
  * all zero are neither held (four registers each) nor multiplied (two matrix instructions each), and the matrix phase is
  * straight-line code: run-time tests of a mask between the matrix instructions cost the compiler's lane-mask arithmetic
  * and a full LDS wait per k-step (first measurement of this file, profiles/r05_long_filters.txt). */
-template <int KQ, int NH, int NG, int NCH, bool IN8>
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB>
 __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_launch_v3 L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    static_assert(NG == 2 || NG == 4, "an image is a tile or half a tile");
+    static_assert(NG == 1 || NG == 2 || NG == 4, "an image is a tile, half or a quarter of one");
+    static_assert(RB == 1 || RB == 2, "row blocks (of 16 rows = 8 channels) per wave");
     constexpr uint32_t NSUB = 4u / (uint32_t)NG; /* images per tile */
     constexpr uint32_t OPI = 16u * (uint32_t)NG; /* outputs per image */
     static_assert(NH >= 0 && NH <= KQ, "planes held");
     /* two k-steps ahead where the taps take 112 registers or more and the fragments are pairs */
-    constexpr int PF = (4 * (KQ + NH) >= 112 && !IN8) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
+    constexpr int PF = (4 * RB * (KQ + NH) >= 112 && !IN8) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
     using chunk_t = typename std::conditional<IN8, uint2, uint4>::type;
 
     const uint32_t tid = threadIdx.x;
@@ -111,12 +112,18 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     /* staging: this thread owns the 4-sample chunks q = tid + j * 512 of every image; where they go never changes:
      * samples 4q .. 4q + 3 of the image sit in row (4q) / D, two plane bytes per sample; bits 16..18: how many of the four
      * still belong to that row (fewer than 4 only when D is not a multiple of 4) */
+    /* (a table of 16-bit offsets where no chunk straddles rows: LDS is what limits the image size at large decimations) */
     uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
+    uint16_t *sta16_s = reinterpret_cast<uint16_t *>(smem + L.sta_off);
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const uint32_t s0 = (tid + (uint32_t)j * MFM3_NT) * 4u;
         const uint32_t r0 = s0 / D, c0 = s0 % D;
-        sta_s[j * MFM3_NT + tid] = ((r0 * rs + 2u * c0) & 0xffffu) | (min(4u, D - c0) << 16);
+        if (split_rows) {
+            sta_s[j * MFM3_NT + tid] = ((r0 * rs + 2u * c0) & 0xffffu) | (min(4u, D - c0) << 16);
+        } else {
+            sta16_s[j * MFM3_NT + tid] = (uint16_t)(r0 * rs + 2u * c0);
+        }
     }
 
     /* B fragments: column n of the image's first column group, k-step kq, lane group kg reads 16 bytes at element
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
         if (tid + (uint32_t)j * MFM3_NT >= nchunk) {
             return;
         }
-        const uint32_t st = sta_s[j * MFM3_NT + tid];
+        const uint32_t st = split_rows ? sta_s[j * MFM3_NT + tid] : (uint32_t)sta16_s[j * MFM3_NT + tid];
         uint8_t *base = smem + buf * buf_pitch + (st & 0xffffu); /* own slot: no barrier needed */
         const uint32_t in_row = st >> 16, hop = rs - 2u * D;
         if constexpr (IN8) {
@@ -206,20 +213,20 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     uint32_t tile = (uint32_t)(((uint64_t)chunk * L.ntiles) / L.nchunks);
     uint32_t tend = (uint32_t)(((uint64_t)(chunk + 1u) * L.ntiles) / L.nchunks);
 
-    /* LDS behind the images: atan table, staging offsets, then per wave: transposition area, (512 bytes unused), fold constants,
-     * exact-rotator table */
+    /* LDS behind the images: atan table, staging offsets, then: the waves' transposition areas ([8 * RB channels][TP]
+     * dwords each), fold constants, exact-rotator tables */
     uint8_t *aux = smem + L.tp_off;
-    uint32_t *tp_s = reinterpret_cast<uint32_t *>(aux) + wave * (8u * MFM_V3L_TP);
-    /* what this lane writes after a column group (channel 2 kg + c at + c * TP dwords, output 16 g + n at + 16 g) and what
-     * it reads back for the epilogue (outputs 4n .. 4n + 3) */
+    uint32_t *tp_s = reinterpret_cast<uint32_t *>(aux) + wave * (8u * RB * MFM_V3L_TP);
+    /* what this lane writes after a column group (row block r, channel 2 kg + c at + (8 r + c) * TP dwords, output 16 g + n
+     * at + 16 g) and what it reads back for the epilogue (outputs 4n .. 4n + 3) */
     uint32_t *tp_w = tp_s + (2u * kg) * MFM_V3L_TP + n;
     const uint4 *tp_r = reinterpret_cast<const uint4 *>(tp_s + (2u * kg) * MFM_V3L_TP + 4u * n);
-    uint8_t *per_wave = aux + 8u * 8u * MFM_V3L_TP * 4u;
-    uint2 *fold_s = reinterpret_cast<uint2 *>(per_wave + 512u) + (wave * 4u + kg) * 2u;
-    uint32_t *xq_s = reinterpret_cast<uint32_t *>(per_wave + 1024u) + (wave * 4u + kg) * 16u;
+    uint8_t *per_wave = aux + 8u * 8u * RB * MFM_V3L_TP * 4u;
+    uint2 *fold_s = reinterpret_cast<uint2 *>(per_wave) + (wave * 4u + kg) * (2u * RB);
+    uint32_t *xq_s = reinterpret_cast<uint32_t *>(per_wave + 512u * RB) + (wave * 4u + kg) * (16u * RB);
 
-    mfm_v4i a_h[NH > 0 ? NH : 1], a_l[KQ];
-    mfm_v4i krow = { 0, 0, 0, 0 }; /* 128 * sum(W) + 8192 (or the 8-bit form's constant) of the lane's rows */
+    mfm_v4i a_h[RB][NH > 0 ? NH : 1], a_l[RB][KQ];
+    mfm_v4i krow[RB]; /* 128 * sum(W) + 8192 (or the 8-bit form's constant) of the lane's rows */
     uint32_t slice_loaded = 0xffffffffu;
 
     /* ---- the workgroup's first image, staged synchronously into buffer 0 ---- */
@@ -240,28 +247,41 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     uint32_t cur = 0;
     bool first_of_chunk = true;
 
-    /* per-lane state of the chunk: two channels */
-    uint32_t kb8[2] = { 0, 0 };   /* byte offset into the rotator table of the entry of (this tile's first output + 4n) */
-    uint32_t voff[2] = { 0, 0 };  /* byte offset into pcm of (channel, this tile's first output + 4n) */
-    uint32_t hist[2] = { 0, 0 };  /* lanes n = 0: filtered sample of the output in front of this tile */
-    bool ch_ok[2] = { false, false };
-    bool w_exact = false;         /* wave uniform: all eight channels of the wave have exact rotators */
+    /* per-lane state of the chunk: two channels per row block */
+    uint32_t kb8[RB][2];   /* byte offset into the rotator table of the entry of (this tile's first output + 4n) */
+    uint32_t voff[RB][2];  /* byte offset into pcm of (channel, this tile's first output + 4n) */
+    uint32_t hist[RB][2];  /* lanes n = 0: filtered sample of the output in front of this tile */
+    bool ch_ok[RB][2];
+    bool w_exact[RB];      /* wave uniform: all eight channels of the row block have exact rotators */
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        kb8[r][0] = kb8[r][1] = voff[r][0] = voff[r][1] = hist[r][0] = hist[r][1] = 0;
+        ch_ok[r][0] = ch_ok[r][1] = w_exact[r] = false;
+    }
 
-    /* One image's matrix phase: NGC column groups of 16 rows x 16 columns x 64 * KQ elements, four byte-plane products per
-     * k-step (two with one sample plane), B fragments requested PF k-steps ahead across the groups.  sink(g, f) takes the
-     * packed filtered samples (first Q14 rounding done) of column group g: lane (kg, n) holds channels 2 kg, 2 kg + 1 of
-     * column n. */
+    /* One image's matrix phase: NGC column groups of (RB x 16) rows x 16 columns x 64 * KQ elements, four byte-plane products
+     * per k-step and row block (two with one sample plane), B fragments requested PF k-steps ahead across the groups and
+     * used by every row block of the wave.  sink(g, r, f) takes the packed filtered samples (first Q14 rounding done) of
+     * column group g, row block r: lane (kg, n) holds channels 2 kg, 2 kg + 1 of column n. */
     auto matrix_phase = [&](auto ngc_tag, uint32_t lds_h, auto &&sink) {
         constexpr int NGC = decltype(ngc_tag)::value;
         constexpr int RPK = IN8 ? 1 : 2, SLOTS = PF + 1, NS = NGC * KQ;
         static_assert(PF * RPK <= 8, "the wait helper counts up to eight younger requests");
-        mfm_v4i hh = { 0, 0, 0, 0 }, md = { 0, 0, 0, 0 }, ll = { 0, 0, 0, 0 };
+        mfm_v4i hh[RB], md[RB], ll[RB];
         mfm_v4i bh[SLOTS], bl[SLOTS];
+        /* (the address arithmetic is inline asm as well: left to the compiler, "fragment offset + group offset (+ plane
+         * pitch)" is loop invariant and gets hoisted - a register per (column group, k-step, plane), which the instances
+         * with 128 tap registers do not have) */
+        const uint32_t lds_u = (uint32_t)__builtin_amdgcn_readfirstlane(lds_h);
         auto request = [&](int st) { /* step st = column group st / KQ, k-step st % KQ */
-            const uint32_t at = lds_h + (uint32_t)(st / KQ) * 16u * rs + boff[st % KQ];
+            const uint32_t gbase = lds_u + (uint32_t)(st / KQ) * 16u * rs;
+            uint32_t at;
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(at) : "s"(gbase), "v"(boff[st % KQ]));
             asm volatile("ds_read_b128 %0, %1" : "=v"(bh[st % SLOTS]) : "v"(at) : "memory");
-            if (!IN8) {
-                const uint32_t at_l = at + plane_pitch;
+            if constexpr (!IN8) {
+                const uint32_t gbase_l = gbase + plane_pitch;
+                uint32_t at_l;
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(at_l) : "s"(gbase_l), "v"(boff[st % KQ]));
                 asm volatile("ds_read_b128 %0, %1" : "=v"(bl[st % SLOTS]) : "v"(at_l) : "memory");
             }
         };
@@ -273,145 +293,167 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
         for (int st = 0; st < NS; st++) {
             const int gq = st / KQ, kq = st % KQ, cb = st % SLOTS;
             if (kq == 0) {
-                hh = mfm_v4i{ 0, 0, 0, 0 };
-                md = mfm_v4i{ 0, 0, 0, 0 };
-                ll = krow;
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    hh[r] = mfm_v4i{ 0, 0, 0, 0 };
+                    md[r] = mfm_v4i{ 0, 0, 0, 0 };
+                    ll[r] = krow[r];
+                }
             }
             if (st + PF < NS) {
                 request(st + PF);
             }
             mfm3l_wait_fragments<IN8>((NS - 1 - st < PF ? NS - 1 - st : PF) * RPK, bh[cb], bl[cb]);
-            if constexpr (IN8) {
-                if (kq < NH) {
-                    hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq < NH ? kq : 0], bh[cb], hh, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                if constexpr (IN8) {
+                    if (kq < NH) {
+                        hh[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[r][kq < NH ? kq : 0], bh[cb], hh[r], 0, 0, 0);
+                    }
+                    ll[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[r][kq], bh[cb], ll[r], 0, 0, 0);
+                } else {
+                    if (kq < NH) { /* the k-steps whose high-byte tap plane is not all zero come first (L.kperm) */
+                        hh[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[r][kq < NH ? kq : 0], bh[cb], hh[r], 0, 0, 0);
+                        md[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[r][kq < NH ? kq : 0], bl[cb], md[r], 0, 0, 0);
+                    }
+                    ll[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[r][kq], bl[cb], ll[r], 0, 0, 0);
+                    md[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[r][kq], bh[cb], md[r], 0, 0, 0);
                 }
-                ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], ll, 0, 0, 0);
-            } else {
-                if (kq < NH) { /* the k-steps whose high-byte tap plane is not all zero come first (L.kperm) */
-                    hh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq < NH ? kq : 0], bh[cb], hh, 0, 0, 0);
-                    md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[kq < NH ? kq : 0], bl[cb], md, 0, 0, 0);
-                }
-                ll = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bl[cb], ll, 0, 0, 0);
-                md = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[kq], bh[cb], md, 0, 0, 0);
             }
             if (kq == KQ - 1) {
                 /* MFMA -> VALU read hazard: 16 wait states cover a 16x16x64 MFMA (hipcc has been seen to leave it unpadded) */
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                uint32_t a_re[2], a_im[2], f[2];
-                if constexpr (IN8) {
 #pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_re[c]) : "v"(hh[2 * c]), "v"(ll[2 * c]));
-                        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_im[c]) : "v"(hh[2 * c + 1]), "v"(ll[2 * c + 1]));
-                    }
-                    mfm3_round_pack2_s(a_re, a_im, in8_sh, f);
-                } else {
+                for (int r = 0; r < RB; r++) {
+                    uint32_t a_re[2], a_im[2], f[2];
+                    if constexpr (IN8) {
 #pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        a_re[c] = mfm3_combine(hh[2 * c], md[2 * c], ll[2 * c]);
-                        a_im[c] = mfm3_combine(hh[2 * c + 1], md[2 * c + 1], ll[2 * c + 1]);
+                        for (int c = 0; c < 2; c++) {
+                            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_re[c]) : "v"(hh[r][2 * c]), "v"(ll[r][2 * c]));
+                            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_im[c]) : "v"(hh[r][2 * c + 1]), "v"(ll[r][2 * c + 1]));
+                        }
+                        mfm3_round_pack2_s(a_re, a_im, in8_sh, f);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            a_re[c] = mfm3_combine(hh[r][2 * c], md[r][2 * c], ll[r][2 * c]);
+                            a_im[c] = mfm3_combine(hh[r][2 * c + 1], md[r][2 * c + 1], ll[r][2 * c + 1]);
+                        }
+                        mfm3_round_pack2(a_re, a_im, f);
                     }
-                    mfm3_round_pack2(a_re, a_im, f);
+                    sink(gq, r, f);
                 }
-                sink(gq, f);
             }
         }
     };
 
     while (true) {
-        const uint32_t rb = slice * 8u + wave;
-        const bool rb_valid = rb < L.nrb; /* wave uniform */
+        /* this wave's row blocks: RB consecutive ones of the slice's 8 * RB; a row block past the last one recomputes the
+         * last (its channels are past the end: nothing of it is stored) */
+        const uint32_t rb0 = (slice * 8u + wave) * RB;
+        const bool rb_valid = rb0 < L.nrb; /* wave uniform */
         const uint32_t first_out = tile * MFM_V3_OT;
 
         if (rb_valid && slice != slice_loaded) {
             /* A operand: 16 rows x (64 * KQ) elements, both byte planes, in fragment order, the k-steps in the order L.kperm */
-            const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rb * KQ * 2 * 64 + mfm3_opaque(lane);
 #pragma unroll
-            for (int kq = 0; kq < KQ; kq++) {
-                if (kq < NH) {
-                    a_h[kq < NH ? kq : 0] = ap[(kq * 2 + 0) * 64];
+            for (int r = 0; r < RB; r++) {
+                const uint32_t rb = rb0 + r < L.nrb ? rb0 + r : L.nrb - 1u;
+                const mfm_v4i *ap = reinterpret_cast<const mfm_v4i *>(L.afrag) + (size_t)rb * KQ * 2 * 64 + mfm3_opaque(lane);
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    if (kq < NH) {
+                        a_h[r][kq < NH ? kq : 0] = ap[(kq * 2 + 0) * 64];
+                    }
+                    a_l[r][kq] = ap[(kq * 2 + 1) * 64];
                 }
-                a_l[kq] = ap[(kq * 2 + 1) * 64];
+                krow[r] = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rb * 16 + 4 * mfm3_opaque(kg));
             }
-            krow = *reinterpret_cast<const mfm_v4i *>(L.krow + (size_t)rb * 16 + 4 * mfm3_opaque(kg));
             /* settled here: they stay live across the whole chunk */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int kq = 0; kq < KQ; kq++) {
-                if (kq < NH) {
-                    asm volatile("" : "+v"(a_h[kq < NH ? kq : 0]));
+            for (int r = 0; r < RB; r++) {
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq++) {
+                    if (kq < NH) {
+                        asm volatile("" : "+v"(a_h[r][kq < NH ? kq : 0]));
+                    }
+                    asm volatile("" : "+v"(a_l[r][kq]));
                 }
-                asm volatile("" : "+v"(a_l[kq]));
+                asm volatile("" : "+v"(krow[r]));
             }
-            asm volatile("" : "+v"(krow));
             slice_loaded = slice;
         }
 
         if (first_of_chunk) {
             const bool has_front = first_out != 0 || L.hist != 0; /* uniform over the workgroup */
-            uint32_t wrx[2] = { 0, 0 }, wry[2] = { 0, 0 };
+            uint32_t wrx[RB][2], wry[RB][2];
             if (rb_valid) {
-                /* ---- chunk set-up: where the lane's two channels stand in their rotator tables and in the output ---- */
-                const uint32_t ch0 = rb * 8u + 2u * kg;
-                uint32_t kbg[2], cls[2], selq[2], sgq[2];
-                uint2 fog[2];
+                /* ---- chunk set-up: where the lane's channels stand in their rotator tables and in the output ---- */
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t chn = ch0 + c;
-                    ch_ok[c] = chn < L.nchan;
-                    const uint32_t chs = ch_ok[c] ? chn : 0u;
-                    const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chs * 8;
-                    const uint4 inf = *reinterpret_cast<const uint4 *>(ip);
-                    const uint32_t lam_magic = ip[4];
-                    const uint32_t mu = inf.z, lam = inf.w;
-                    /* where output k_base + first_out stands in the channel's rotator table (wave uniform which way) */
-                    const uint64_t kabs = L.k_base + first_out;
-                    const uint32_t k0 = (kabs >> 32) == 0 ? mfm3_fold((uint32_t)kabs, 0u, mu, lam, lam_magic)
-                                                          : mfm3_fold64(kabs, mu, lam, lam_magic);
-                    kbg[c] = (inf.x + k0 + 4u * n) * MFM3_ES;
-                    fog[c] = make_uint2((inf.x + mu + lam) * MFM3_ES, lam * MFM3_ES);
-                    const uint32_t rcw = ch_ok[c] ? ip[7] : MFM_RC_IDENT;
-                    cls[c] = rcw & 15u;
-                    /* an exact rotator (mfm_kernel_v3.hip): output k0 + g is rotated by m = turns * (k0 + g) quarter turns -
-                     * selector and sign word of the lane's output g, computed by lane n = g */
-                    const uint32_t mq = ((rcw >> 4) * (k0 + n)) & 3u;
-                    selq[c] = (mq & 1u) ? 0x01000302u : 0x03020100u;
-                    sgq[c] = mq == 0u ? 0x00010001u : mq == 1u ? 0x0001ffffu : mq == 2u ? 0xffffffffu : 0xffff0001u;
-                    voff[c] = (ip[6] * L.out_stride + first_out + 4u * n) * 2u; /* ip[6]: the row this channel's output goes to */
-                    if (has_front) {
-                        /* rotator entry of the output in front (the entry in front of a period is not the period's last
-                         * one: position mu is reached from mu - 1 the first time and from mu + lam - 1 ever after) */
-                        const uint32_t kw = (k0 != mu || kabs == (uint64_t)mu) ? k0 - 1u : mu + lam - 1u;
-#if MFM3_ROT4
-                        const uint32_t r = reinterpret_cast<const uint32_t *>(L.rot)[inf.x + kw];
-                        wrx[c] = mfm3_rot_x(r);
-                        wry[c] = mfm3_rot_y(r);
-#else
-                        const uint2 e = reinterpret_cast<const uint2 *>(L.rot)[inf.x + kw];
-                        wrx[c] = e.x;
-                        wry[c] = e.y;
-#endif
-                    }
-                    hist[c] = 0; /* nothing in front: multifm/fm_demod.c:16-17,29, the last sample starts at zero */
-                }
-                /* rows are ordered by rotator class (the engine): a wave whose eight channels are all exact derotates with the
-                 * permute-and-sign form and reads the table's first line only */
-                w_exact = MFM3_WAVE_EXACT &&
-                          __builtin_amdgcn_ballot_w64(cls[0] == MFM_RC_GENERAL || cls[1] == MFM_RC_GENERAL) == 0;
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    kb8[c] = w_exact ? 0u : kbg[c];
-                    if (n == 0) {
-                        fold_s[c] = fog[c]; /* only this wave reads it */
-                    }
-                }
-                if (w_exact && n < 4u) {
+                for (int r = 0; r < RB; r++) {
+                    const uint32_t ch0 = (rb0 + r) * 8u + 2u * kg;
+                    uint32_t kbg[2], cls[2], selq[2], sgq[2];
+                    uint2 fog[2];
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
-                        xq_s[c * 8 + n] = selq[c]; /* only this wave reads them */
-                        xq_s[c * 8 + 4 + n] = sgq[c];
+                        const uint32_t chn = ch0 + c;
+                        ch_ok[r][c] = chn < L.nchan;
+                        const uint32_t chs = ch_ok[r][c] ? chn : 0u;
+                        const uint32_t *ip = reinterpret_cast<const uint32_t *>(L.info) + (size_t)chs * 8;
+                        const uint4 inf = *reinterpret_cast<const uint4 *>(ip);
+                        const uint32_t lam_magic = ip[4];
+                        const uint32_t mu = inf.z, lam = inf.w;
+                        /* where output k_base + first_out stands in the channel's rotator table (wave uniform which way) */
+                        const uint64_t kabs = L.k_base + first_out;
+                        const uint32_t k0 = (kabs >> 32) == 0 ? mfm3_fold((uint32_t)kabs, 0u, mu, lam, lam_magic)
+                                                              : mfm3_fold64(kabs, mu, lam, lam_magic);
+                        kbg[c] = (inf.x + k0 + 4u * n) * MFM3_ES;
+                        fog[c] = make_uint2((inf.x + mu + lam) * MFM3_ES, lam * MFM3_ES);
+                        const uint32_t rcw = ch_ok[r][c] ? ip[7] : MFM_RC_IDENT;
+                        cls[c] = rcw & 15u;
+                        /* an exact rotator (mfm_kernel_v3.hip): output k0 + g is rotated by m = turns * (k0 + g) quarter turns -
+                         * selector and sign word of the lane's output g, computed by lane n = g */
+                        const uint32_t mq = ((rcw >> 4) * (k0 + n)) & 3u;
+                        selq[c] = (mq & 1u) ? 0x01000302u : 0x03020100u;
+                        sgq[c] = mq == 0u ? 0x00010001u : mq == 1u ? 0x0001ffffu : mq == 2u ? 0xffffffffu : 0xffff0001u;
+                        voff[r][c] = (ip[6] * L.out_stride + first_out + 4u * n) * 2u; /* ip[6]: the row this channel's output goes to */
+                        wrx[r][c] = wry[r][c] = 0;
+                        if (has_front) {
+                            /* rotator entry of the output in front (the entry in front of a period is not the period's last
+                             * one: position mu is reached from mu - 1 the first time and from mu + lam - 1 ever after) */
+                            const uint32_t kw = (k0 != mu || kabs == (uint64_t)mu) ? k0 - 1u : mu + lam - 1u;
+#if MFM3_ROT4
+                            const uint32_t rr = reinterpret_cast<const uint32_t *>(L.rot)[inf.x + kw];
+                            wrx[r][c] = mfm3_rot_x(rr);
+                            wry[r][c] = mfm3_rot_y(rr);
+#else
+                            const uint2 e = reinterpret_cast<const uint2 *>(L.rot)[inf.x + kw];
+                            wrx[r][c] = e.x;
+                            wry[r][c] = e.y;
+#endif
+                        }
+                        hist[r][c] = 0; /* nothing in front: multifm/fm_demod.c:16-17,29, the last sample starts at zero */
+                    }
+                    /* rows are ordered by rotator class (the engine): a row block whose eight channels are all exact derotates
+                     * with the permute-and-sign form and reads the table's first line only */
+                    w_exact[r] = MFM3_WAVE_EXACT &&
+                                 __builtin_amdgcn_ballot_w64(cls[0] == MFM_RC_GENERAL || cls[1] == MFM_RC_GENERAL) == 0;
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        kb8[r][c] = w_exact[r] ? 0u : kbg[c];
+                        if (n == 0) {
+                            fold_s[r * 2 + c] = fog[c]; /* only this wave reads it */
+                        }
+                    }
+                    if (w_exact[r] && n < 4u) {
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            xq_s[r * 16 + c * 8 + n] = selq[c]; /* only this wave reads them */
+                            xq_s[r * 16 + c * 8 + 4 + n] = sgq[c];
+                        }
                     }
                 }
             }
@@ -432,15 +474,19 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
                 }
                 __syncthreads();
                 if (rb_valid) {
-                    uint32_t fw[2] = { 0, 0 }, qw[2];
+                    uint32_t fw[RB][2];
                     matrix_phase(std::integral_constant<int, 1>{}, (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch),
-                                 [&](int, const uint32_t (&f)[2]) {
-                                     fw[0] = f[0];
-                                     fw[1] = f[1];
+                                 [&](int, int r, const uint32_t (&f)[2]) {
+                                     fw[r][0] = f[0];
+                                     fw[r][1] = f[1];
                                  });
-                    derotate2(fw, wrx, wry, qw);
-                    hist[0] = qw[0];
-                    hist[1] = qw[1];
+#pragma unroll
+                    for (int r = 0; r < RB; r++) {
+                        uint32_t qw[2];
+                        derotate2(fw[r], wrx[r], wry[r], qw);
+                        hist[r][0] = qw[0];
+                        hist[r][1] = qw[1];
+                    }
                 }
                 __syncthreads(); /* the idle buffer is free again: the first image's successor goes there */
             }
@@ -456,8 +502,8 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
             n_tend = (uint32_t)(((uint64_t)(n_chunk + 1u) * L.ntiles) / L.nchunks);
             n_first = true;
         }
-        uint4 rva[2];
-        /* (not unrolled for half-tile images: two copies of the matrix phase cost the compiler 20-60 registers) */
+        uint4 rva[RB][2];
+        /* (not unrolled for part-tile images: several copies of the matrix phase cost the compiler 20-60 registers) */
 #pragma unroll 1
         for (uint32_t h = 0; h < NSUB; h++) {
             /* the image behind this one: the tile's next, or the first of the workgroup's next tile (a workgroup's last image
@@ -478,17 +524,22 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
             }
             if (rb_valid) {
                 matrix_phase(std::integral_constant<int, NG>{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch),
-                             [&](int gq, const uint32_t (&f)[2]) {
-                                 tp_w[16u * (h * (uint32_t)NG + (uint32_t)gq)] = f[0];
-                                 tp_w[MFM_V3L_TP + 16u * (h * (uint32_t)NG + (uint32_t)gq)] = f[1];
+                             [&](int gq, int r, const uint32_t (&f)[2]) {
+                                 uint32_t *w = tp_w + (uint32_t)r * (8u * MFM_V3L_TP) + 16u * (h * (uint32_t)NG + (uint32_t)gq);
+                                 w[0] = f[0];
+                                 w[MFM_V3L_TP] = f[1];
                              });
                 if (h + 1u == NSUB) {
                     /* rotator entries of this tile, four consecutive ones per channel: requested behind the tile's last matrix
-                     * phase, needed behind the staging stores and the barrier */
+                     * phase, needed behind the staging stores and the barrier.  (In front of it - a matrix phase more to
+                     * arrive - measured 1 % slower: profiles/r05_long_filters.txt) */
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        rva[c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + kb8[c]);
+                    for (int r = 0; r < RB; r++) {
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            rva[r][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + kb8[r][c]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -507,76 +558,86 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
         if (rb_valid) {
             static_assert(MFM3_ROT4, "the long-filter kernel is written for 4-byte rotator entries");
             const uint32_t n_left = L.n_new - first_out; /* >= 1 */
-            uint32_t q[4][2];
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                /* this lane's four consecutive outputs of channel 2 kg + c, as the wave's column groups left them */
-                const uint4 fv = tp_r[c * (MFM_V3L_TP / 4u)];
-                const uint32_t f[4] = { fv.x, fv.y, fv.z, fv.w };
-                if (w_exact) {
-                    /* exact rotators: r14(f * rot) = f * j^m - swap the halves for odd m, then two signs */
-                    const uint4 sel4 = *reinterpret_cast<const uint4 *>(xq_s + c * 8);
-                    const uint4 sg4 = *reinterpret_cast<const uint4 *>(xq_s + c * 8 + 4);
-                    const uint32_t sel[4] = { sel4.x, sel4.y, sel4.z, sel4.w }, sg[4] = { sg4.x, sg4.y, sg4.z, sg4.w };
+            for (int r = 0; r < RB; r++) {
+                uint32_t q[4][2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    /* this lane's four consecutive outputs of channel 2 kg + c of row block r, as the column groups left them */
+                    const uint4 fv = tp_r[(r * 8 + c) * (MFM_V3L_TP / 4u)];
+                    const uint32_t f[4] = { fv.x, fv.y, fv.z, fv.w };
+                    if (w_exact[r]) {
+                        /* exact rotators: r14(f * rot) = f * j^m - swap the halves for odd m, then two signs */
+                        const uint4 sel4 = *reinterpret_cast<const uint4 *>(xq_s + r * 16 + c * 8);
+                        const uint4 sg4 = *reinterpret_cast<const uint4 *>(xq_s + r * 16 + c * 8 + 4);
+                        const uint32_t sel[4] = { sel4.x, sel4.y, sel4.z, sel4.w }, sg[4] = { sg4.x, sg4.y, sg4.z, sg4.w };
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const uint32_t t = __builtin_amdgcn_perm(f[g], f[g], sel[g]);
+                            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(q[g][c]) : "v"(t), "v"(sg[g]));
+                        }
+                    } else {
+                        /* derotation + second rounding, two outputs per call */
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; h2++) {
+                            const uint32_t r0 = h2 ? rva[r][c].z : rva[r][c].x, r1 = h2 ? rva[r][c].w : rva[r][c].y;
+                            const uint32_t fin[2] = { f[2 * h2], f[2 * h2 + 1] };
+                            const uint32_t rx[2] = { mfm3_rot_x(r0), mfm3_rot_x(r1) }, ry[2] = { mfm3_rot_y(r0), mfm3_rot_y(r1) };
+                            uint32_t qo[2];
+                            derotate2(fin, rx, ry, qo);
+                            q[2 * h2][c] = qo[0];
+                            q[2 * h2 + 1][c] = qo[1];
+                        }
+                    }
+                    /* discriminator: previous output = the one before in the same lane; for the first the neighbouring lane's
+                     * last, and for lane n = 0 the last output of the previous tile */
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp((int)hist[r][c], (int)q[3][c], 0x111 /* row_shr:1 */,
+                                                                              0xf, 0xf, false);
+                    const uint32_t pp[4] = { p0, q[0][c], q[1][c], q[2][c] };
+                    int s_re[4], s_im[4], pcm[4];
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
-                        const uint32_t t = __builtin_amdgcn_perm(f[g], f[g], sel[g]);
-                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(q[g][c]) : "v"(t), "v"(sg[g]));
+                        mfm3_conj_mul(q[g][c], pp[g], &s_re[g], &s_im[g]);
                     }
-                } else {
-                    /* derotation + second rounding, two outputs per call */
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; h2++) {
-                        const uint32_t r0 = h2 ? rva[c].z : rva[c].x, r1 = h2 ? rva[c].w : rva[c].y;
-                        const uint32_t fin[2] = { f[2 * h2], f[2 * h2 + 1] };
-                        const uint32_t rx[2] = { mfm3_rot_x(r0), mfm3_rot_x(r1) }, ry[2] = { mfm3_rot_y(r0), mfm3_rot_y(r1) };
-                        uint32_t qo[2];
-                        derotate2(fin, rx, ry, qo);
-                        q[2 * h2][c] = qo[0];
-                        q[2 * h2 + 1][c] = qo[1];
+                    mfm3_discriminate4(s_re, s_im, lut_addr, pcm);
+                    /* lane 0 of each row of 16 lanes gets lane 15's last sample: the next tile's history */
+                    hist[r][c] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[3][c], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
+                    if (RB > 1 && c == 0) {
+                        __builtin_amdgcn_sched_barrier(0); /* ... and one channel after the other */
                     }
-                }
-                /* discriminator: previous output = the one before in the same lane; for the first the neighbouring lane's last,
-                 * and for lane n = 0 the last output of the previous tile */
-                const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp((int)hist[c], (int)q[3][c], 0x111 /* row_shr:1 */,
-                                                                          0xf, 0xf, false);
-                const uint32_t pp[4] = { p0, q[0][c], q[1][c], q[2][c] };
-                int s_re[4], s_im[4], pcm[4];
+                    if (n_left >= MFM_V3_OT) {
+                        if (ch_ok[r][c]) {
+                            uint2 w;
+                            w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
+                            w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
+                            typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
+                            mfm_v2u wv = { w.x, w.y };
+                            __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[r][c]));
+                        }
+                    } else {
+                        /* the last tile of the pass, partly filled */
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    mfm3_conj_mul(q[g][c], pp[g], &s_re[g], &s_im[g]);
-                }
-                mfm3_discriminate4(s_re, s_im, lut_addr, pcm);
-                /* lane 0 of each row of 16 lanes gets lane 15's last sample: the next tile's history */
-                hist[c] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[3][c], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
-                if (n_left >= MFM_V3_OT) {
-                    if (ch_ok[c]) {
-                        uint2 w;
-                        w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
-                        w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
-                        typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
-                        mfm_v2u wv = { w.x, w.y };
-                        __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]));
-                    }
-                } else {
-                    /* the last tile of the pass, partly filled */
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        if (ch_ok[c] && 4u * n + (uint32_t)g < n_left) {
-                            *reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c] + 2u * g) = (int16_t)pcm[g];
+                        for (int g = 0; g < 4; g++) {
+                            if (ch_ok[r][c] && 4u * n + (uint32_t)g < n_left) {
+                                *reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[r][c] + 2u * g) = (int16_t)pcm[g];
+                            }
                         }
                     }
                 }
-            }
-            /* next tile of the chunk: 64 outputs on */
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                if (!w_exact) {
-                    const uint2 fo = fold_s[c]; /* at or past table position mu + lam the position folds back by lam */
-                    kb8[c] += MFM_V3_OT * MFM3_ES;
-                    kb8[c] = kb8[c] >= fo.x + 4u * MFM3_ES * n ? kb8[c] - fo.y : kb8[c];
+                if (RB > 1) {
+                    /* two row blocks' taps leave the epilogue some 100 registers: one row block after the other */
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                voff[c] += MFM_V3_OT * 2u;
+                /* next tile of the chunk: 64 outputs on */
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (!w_exact[r]) {
+                        const uint2 fo = fold_s[r * 2 + c]; /* at or past table position mu + lam the position folds back by lam */
+                        kb8[r][c] += MFM_V3_OT * MFM3_ES;
+                        kb8[r][c] = kb8[r][c] >= fo.x + 4u * MFM3_ES * n ? kb8[r][c] - fo.y : kb8[r][c];
+                    }
+                    voff[r][c] += MFM_V3_OT * 2u;
+                }
             }
         }
 
@@ -593,39 +654,49 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
 }
 
 /* Not built: the instances that would need more than 256 registers - many k-steps with most high-byte planes held, int16
- * input and eight staging chunks in flight.  No instance may spill: a fragment register saved to scratch between its
- * request and its wait would save what was in it before the data arrived.  The engine runs such a geometry on the first
- * generation (tests/test_abi.py checks the spill counts of everything that IS built). */
-template <int KQ, int NH, int NG, int NCH, bool IN8>
+ * input and eight staging chunks in flight - and two row blocks per wave where their taps alone take more than 128.  No
+ * instance may spill: a fragment register saved to scratch between its request and its wait would save what was in it
+ * before the data arrived.  The engine asks (mfm_select_channel_kernel_v3) and runs what is not built on one row block per
+ * wave, or on the first generation (tests/test_abi.py checks the spill counts of everything that IS built). */
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB>
 constexpr bool mfm3l_fits()
 {
-    return IN8 || 4 * (KQ + NH) + (NCH == 8 ? 32 : 16) + (NG == 2 ? 8 : 0) <= 160;
+    if (RB == 2) {
+        /* 128-channel slices: whole- and half-tile images of two row blocks' transposition areas do not fit LDS at the
+         * decimations that want them; built for quarter-tile images */
+        return NG == 1 && 8 * (KQ + NH) <= 128; /* (half-tile images with eight staging chunks per thread spill in the tile loop:
+                                                   0.26 -> 0.36 ms at configs[4]'s share, profiles/r05_long_filters.txt) */
+    }
+    return NG != 1 && (IN8 || 4 * (KQ + NH) + (NCH == 8 ? 32 : 16) + (NG == 2 ? 8 : 0) <= 160);
 }
 
-template <int KQ, int NH, int NG, int NCH, bool IN8>
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB>
 static const void *mfm3l_instance_ptr()
 {
-    if constexpr (mfm3l_fits<KQ, NH, NG, NCH, IN8>()) {
-        return reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, NG, NCH, IN8>);
+    if constexpr (mfm3l_fits<KQ, NH, NG, NCH, IN8, RB>()) {
+        return reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, NG, NCH, IN8, RB>);
     } else {
         return nullptr;
     }
 }
 
+template <int KQ, int NH, int NG, int RB>
+static const void *mfm3l_instance_fmt(const mfm_launch_v3 *L, uint32_t nch)
+{
+    const bool big = mfm_v3l_built_nch(nch) == 8u;
+    if (L->in8) {
+        return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, true, RB>() : mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB>();
+    }
+    return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, false, RB>() : mfm3l_instance_ptr<KQ, NH, NG, 4, false, RB>();
+}
+
 template <int KQ, int NH>
 static const void *mfm3l_instance_geo(const mfm_launch_v3 *L, uint32_t nch)
 {
-    const bool big = mfm_v3l_built_nch(nch) == 8u;
-    if (L->ng == 4u) {
-        if (L->in8) {
-            return big ? mfm3l_instance_ptr<KQ, NH, 4, 8, true>() : mfm3l_instance_ptr<KQ, NH, 4, 4, true>();
-        }
-        return big ? mfm3l_instance_ptr<KQ, NH, 4, 8, false>() : mfm3l_instance_ptr<KQ, NH, 4, 4, false>();
+    if (L->rb == 2u) {
+        return L->ng == 1u ? mfm3l_instance_fmt<KQ, NH, 1, 2>(L, nch) : nullptr;
     }
-    if (L->in8) {
-        return big ? mfm3l_instance_ptr<KQ, NH, 2, 8, true>() : mfm3l_instance_ptr<KQ, NH, 2, 4, true>();
-    }
-    return big ? mfm3l_instance_ptr<KQ, NH, 2, 8, false>() : mfm3l_instance_ptr<KQ, NH, 2, 4, false>();
+    return L->ng == 4u ? mfm3l_instance_fmt<KQ, NH, 4, 1>(L, nch) : L->ng == 2u ? mfm3l_instance_fmt<KQ, NH, 2, 1>(L, nch) : nullptr;
 }
 
 /* the instance for a launch description (geometry fields only, all fixed at commit): L->kq k-steps (a built count), the
