@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_DOT2_PEAK = 256 * 4 * 32 * 2.4e9  # lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 (v_dot2 measured at half of it)
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8/fp8 MFMA, MI355X_MICROARCH.md (measured 4.1-4.4 POPS)
+MFMA_I8_MEASURED_TOPS = 3944.0  # the guide's measured ceiling for v_mfma_i32_16x16x64_i8 (">= 3944 TOPS")
+SIMDS = 1024                # 256 CUs x 4
+MFMA_ISSUE_CYCLES = 16      # v_mfma_i32_16x16x64_i8: 4 passes x 4 cycles
+VALU_ISSUE_CYCLES = 3       # mean issue cost of the kernels' other vector instructions (profiles/r02_ubench_ops.txt: 2 .. 4)
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # packed FP32 on the vector ALUs: 256 CU x 256 flop/clk x 2.4 GHz
 
 
@@ -55,6 +59,13 @@ def parse():
     ap.add_argument("--input", choices=["cs16", "rtlsdr_u8"], default="cs16",
                     help="rtlsdr_u8: the wideband block is 8-bit IQ as an RTL-SDR delivers it (multifm/rtl_sdr_if.c:146-148); the matrix "
                          "kernel reads the bytes and, at N > 1, the exchange moves half the bytes")
+    ap.add_argument("--exchange", choices=["group", "torch"], default="group",
+                    help="N > 1: 'group' = ONE process drives the N devices through the library's own device group (mfm_group_*: channel "
+                         "shards, the C library's RCCL scatter + all-gather of every block - what multifm_amd runs); 'torch' = one process "
+                         "per GPU with torch.distributed collectives (rounds 1-4)")
+    ap.add_argument("--group-shards", type=int, default=0,
+                    help="TEST AID: run the group path with this many shards on device 0 (MFM_F_GROUP_SHARED_DEVICE; needs a transport "
+                         "that accepts one device several times: tests/hoststub/fake_rccl.cpp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the float32-IQ comparison line")
     ap.add_argument("--no-chain", action="store_true", help="skip the device-resident FLEX chain line")
@@ -262,6 +273,164 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
     return {"chain": "engine -> resampler 16/25 (821 taps) -> FLEX stage, device resident", "block_samples": block,
             "pcm_16k_per_channel": int(ny), "ms_engine": float(med[0]), "ms_resampler": float(med[1]), "ms_flex": float(med[2]),
             "ms_per_block": total, "value": block * len(offs) / total / 1e3, "unit": "MSamp/s x channels"}
+
+
+def library_sha16(pkg):
+    """first 16 hex digits of the SHA-256 of libmultifm_hip.so: ties instruction counts in profiles/ to the build they belong to"""
+    import hashlib
+    path = os.path.join(ROOT, "tsl-sdr_amd", "libmultifm_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def instance_name(pkg, st, in8):
+    """key of a (kernel, geometry) in profiles/r05_issue_model.json"""
+    return "variant%d_ch%d_taps%d_ksteps%d_mask%x_tile%d%s" % (st["kernel_variant"], st["nr_channels"], st["nr_taps"], st["k_steps"],
+                                                                st["tap_hi_mask"], st["outputs_per_tile"], "_in8" if in8 else "")
+
+
+def gpu_sysfs_sample(local_rank=0):
+    """One sample of the board's shader clock and power from sysfs (what rocm-smi prints, without starting a process inside the
+    timed region): {sclk_mhz, power_w, source} or None where the files are not there or not readable."""
+    import glob
+    cards = []
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+        except OSError:
+            continue
+        hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+        if hw:
+            cards.append(hw[0])
+    if not cards:
+        return None
+    hw = cards[min(local_rank, len(cards) - 1)]
+
+    def rd(name):
+        try:
+            return float(open(os.path.join(hw, name)).read().strip())
+        except (OSError, ValueError):
+            return None
+    sclk = rd("freq1_input")
+    power = rd("power1_average") or rd("power1_input")
+    if sclk is None and power is None:
+        return None
+    return {"sclk_mhz": sclk / 1e6 if sclk else None, "power_w": power / 1e6 if power else None, "source": hw}
+
+
+def launch_clocks(eng, n):
+    """The last n launches as the kernel stamped them itself (mfm_engine_get_launch_cycles): median shader-clock ticks of the
+    longest workgroup, the 100 MHz reference ticks beside them, and the clock that makes of the two."""
+    sh, ref = eng.launch_cycles(int(n))
+    ok = (sh > 0) & (ref > 0)
+    if not ok.any():
+        return None
+    sh, ref = sh[ok].astype(np.float64), ref[ok].astype(np.float64)
+    return {"launches": int(ok.sum()), "shader_ticks_median": float(np.median(sh)), "ref_ticks_100mhz_median": float(np.median(ref)),
+            "kernel_ms_by_ref_ticks": float(np.median(ref)) / 1e5,
+            "sclk_mhz_effective": float(np.median(sh / ref)) * 100.0,
+            "source": "s_memtime / s_memrealtime stamped by the kernel's workgroups, this run"}
+
+
+def issue_model(kname_full, st, cycles, hbm_frac, lib_sha16):
+    """How much of the launch the SIMDs spent issuing: (matrix instructions x 16 + other vector instructions x 3 cycles) / 1024
+    SIMDs against THIS run's shader cycles.  The instruction counts are properties of (binary, geometry), not of a box: SQ_INSTS_*
+    per launch from the committed rocprofv3 passes of this command (profiles/r05_issue_model.json), only used when that file was
+    collected on this very library (sha) and kernel instance.  ceiling_frac = the HBM fraction the kernel would reach if every
+    issue slot of the launch were used."""
+    path = os.path.join(ROOT, "profiles", "r05_issue_model.json")
+    if cycles is None or not os.path.exists(path):
+        return None
+    im = json.load(open(path))
+    ent = im.get("shapes", {}).get(kname_full)
+    if ent is None or im.get("library_sha16") != lib_sha16:
+        return {"ceiling_frac": None, "reason": "profiles/r05_issue_model.json was collected on another build or kernel instance",
+                "library_sha16": lib_sha16, "profile_library_sha16": im.get("library_sha16")}
+    mfma, valu = ent["mfma_insts_per_launch"], ent["other_valu_insts_per_launch"]
+    issue_cycles = (mfma * MFMA_ISSUE_CYCLES + valu * VALU_ISSUE_CYCLES) / SIMDS
+    busy = issue_cycles / cycles["shader_ticks_median"]
+    return {"mfma_insts_per_launch": mfma, "other_valu_insts_per_launch": valu,
+            "counts_source": "profiles/r05_issue_model.json: SQ_INSTS_MFMA, SQ_INSTS_VALU - SQ_INSTS_MFMA per launch (rocprofv3 --pmc of this "
+                             "command on this library; instruction counts do not depend on the box)",
+            "mfma_issue_cycles": MFMA_ISSUE_CYCLES, "valu_issue_cycles": VALU_ISSUE_CYCLES, "simds": SIMDS,
+            "issue_cycles_per_simd": issue_cycles, "launch_shader_cycles": cycles["shader_ticks_median"],
+            "simd_busy_fraction": busy, "ceiling_frac": hbm_frac / busy if busy > 0 else None,
+            "library_sha16": lib_sha16}
+
+
+def north_star_shape(pkg, torch, block, steps=12, settle_s=0.3):
+    """north_star's target shape in the driver's line (outside the timed region, never part of `value`): the 1024 channels of
+    the configs[2] plan on ONE GPU (the reference builds one demod_thread per "channels" entry without limit,
+    multifm/receiver.c:195-244), 2^26-sample blocks resident in HBM, same protocol as the headline.  The kernel is
+    compute-bound there: `bound_frac` is the HBM fraction the matrix instructions it has to issue would allow all by
+    themselves - what `frac` is to be read against, not 0.70."""
+    b = pkg.binding
+    lib = pkg.load_library()
+    try:
+        nch = 1024
+        fs, decim, taps, offs, gains = pkg.synth.plan("cfg3_1024ch", nr_channels=nch)
+        in_bytes = lib.mfm_engine_input_bytes(block, len(taps))
+        bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+        eng = pkg.Engine(fs, decim, block, device=torch.cuda.current_device(), flags=b.MFM_F_DEVICE_ONLY | b.MFM_F_TIMING,
+                         ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
+        for o, g in zip(offs, gains):
+            eng.add_channel(int(o), taps, float(g))
+        eng.commit()
+        base = pkg.synth.synth_iq(1 << 22, fs, offs[:: len(offs) // 8][:8], seed=13)
+        host = np.tile(base, (-(-(in_bytes // 4) // base.shape[0]), 1))[: in_bytes // 4].reshape(-1)
+        for t in bufs:
+            t.copy_(torch.from_numpy(host))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < settle_s:
+            for _ in range(4):
+                eng.acquire_input()
+                eng.submit(block, producer_stream=0, wait_producer=False)
+            eng.sync()
+        w0 = time.perf_counter()
+        for _ in range(steps):
+            eng.acquire_input()
+            eng.submit(block, producer_stream=0, wait_producer=False)
+        eng.sync()
+        wall_ms = (time.perf_counter() - w0) * 1e3 / steps
+        per = eng.launch_ms(steps).astype(np.float64)
+        ms = float(np.mean(per))
+        cyc = launch_clocks(eng, steps)
+        st = eng.stats()
+        eng.close()
+        del bufs
+        T, n_out = len(taps), block // decim
+        bytes_alg = 4.0 * block + 2.0 * nch * n_out                       # SURVEY.md 8(d): 4 + 2 C / D bytes per input sample
+        ops4 = 2.0 * 4.0 * 4.0 * nch * T * n_out                          # four byte-plane products of 4 real MACs per complex tap
+        ks, hi = max(1, st["k_steps"]), bin(st["tap_hi_mask"]).count("1")
+        issued = ops4 * (2.0 * ks + 2.0 * hi) / (4.0 * ks)
+        frac = bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        out = {"workload": "cfg3_1024ch: 1024 FM channels on one GPU, 128-tap 25 kHz LPF, decimation 96, 2.4 MS/s-shaped int16 IQ, "
+                           "block 2^26 samples", "channels": nch, "block_samples": block,
+               "value": block * nch / ms / 1e3, "unit": "MSamp/s x channels", "kernel_ms": ms,
+               "kernel_ms_min": float(per.min()), "kernel_ms_max": float(per.max()), "wall_ms_per_block": wall_ms,
+               "kernel_variant": st["kernel_variant"], "rot_exact_channels": st["rot_exact_channels"],
+               "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": frac, "bytes_per_launch": bytes_alg},
+               "compute_roofline": {
+                   "bound": "mfma_i8", "unit": "TOP/s", "four_plane_ops_per_launch": ops4, "issued_ops_per_launch": issued,
+                   "peak_nominal": MFMA_I8_PEAK_TOPS, "peak_measured_guide": MFMA_I8_MEASURED_TOPS,
+                   "frac_four_planes_of_nominal": ops4 / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                   "frac_issued_of_nominal": issued / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                   "frac_issued_of_measured": issued / (ms * 1e-3) / 1e12 / MFMA_I8_MEASURED_TOPS,
+                   "mfma_only_ms_at_nominal": issued / (MFMA_I8_PEAK_TOPS * 1e12) * 1e3,
+                   "mfma_only_ms_at_measured": issued / (MFMA_I8_MEASURED_TOPS * 1e12) * 1e3},
+               # the HBM fraction a kernel of nothing but its matrix instructions would show: what `frac` stands against
+               "bound_frac": {"at_nominal_5000_tops": bytes_alg / (issued / (MFMA_I8_PEAK_TOPS * 1e12)) / 1e9 / HBM_PEAK_GBPS,
+                              "at_measured_3944_tops": bytes_alg / (issued / (MFMA_I8_MEASURED_TOPS * 1e12)) / 1e9 / HBM_PEAK_GBPS},
+               "clocks": cyc}
+        out["frac_of_bound"] = {k: frac / v for k, v in out["bound_frac"].items()}
+        return out
+    except Exception as e:  # a side line must never take the headline down
+        return {"error": repr(e)}
 
 
 def other_geometries(pkg, torch, block, steps=24, settle_s=0.25):
@@ -494,6 +663,67 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
                          "outputs_per_channel": int(outs)}
         except Exception as e:  # a side line must never take the headline down
             out[mode] = {"error": repr(e)}
+    # the link by itself, for what the figures above are to be read against: bare hipMemcpyAsync out of one page-locked arena
+    # in pieces of one sample_buf (512 KiB) and of 64 MiB, with the PCM's share of bytes coming back on a second stream
+    try:
+        back = 2.0 * nch / decim / 4.0
+        link = {"d2h_bytes_per_h2d_byte": back}
+        for name, piece in (("pieces_512KiB", buf_samples * 4), ("pieces_64MiB", 64 << 20)):
+            h, d = ctypes.c_double(), ctypes.c_double()
+            rc = lib0.mfm_link_probe(0, piece, 2 << 30, back, ctypes.byref(h), ctypes.byref(d))
+            link[name] = {"h2d_GBps": h.value, "d2h_GBps": d.value} if rc == 0 else {"error": rc}
+            h2, d2 = ctypes.c_double(), ctypes.c_double()
+            rc = lib0.mfm_link_probe(0, piece, 2 << 30, 0.0, ctypes.byref(h2), ctypes.byref(d2))
+            link[name]["h2d_alone_GBps"] = h2.value if rc == 0 else None
+        best = out.get("c_loop_pinned_pool_coalesced_128_buffers", {}).get("h2d_GBps")
+        if best and "h2d_GBps" in link["pieces_512KiB"]:
+            link["end_to_end_over_link_512KiB"] = best / link["pieces_512KiB"]["h2d_GBps"]
+            link["end_to_end_over_link_64MiB"] = best / link["pieces_64MiB"]["h2d_GBps"]
+        out["link"] = link
+    except Exception as e:
+        out["link"] = {"error": repr(e)}
+    # latency: deliver -> PCM fetched, for a feed paced at the front ends' rates (one 131 072-sample buffer every 54.6 ms at
+    # 2.4 MS/s, every 13.1 ms at 10 MS/s), under the three gathering settings.  The device is idle when a paced buffer arrives,
+    # so the engine launches it at once whatever it may gather up to - the figure says what that costs.
+    try:
+        lat = {}
+        for name, co in (("launch_per_buffer", 0), ("gather_up_to_one_pool_128_buffers", 128 * buf_samples), ("gather_up_to_2^26_samples", 1 << 26)):
+            grp = b.Group(fs, decim, buf_samples, devices=(0,), coalesce_samples=co)
+            for o, g in zip(offs, gains):
+                grp.add_channel(int(o), taps, float(g))
+            grp.commit()
+            blks = (b.Block * 1)()
+            lib = grp.lib
+            for rate in (2400000, 10000000):
+                period = buf_samples / rate
+                ms = []
+                t_next = time.perf_counter()
+                for i in range(20):
+                    while time.perf_counter() < t_next:
+                        pass
+                    t0 = time.perf_counter()
+                    rc = lib.mfm_group_push_pinned(grp.h, pinned[i & 7], buf_samples, b.MFM_IN_CS16, None)
+                    if rc != 0:
+                        raise RuntimeError(f"push: {rc}")
+                    got = 0
+                    while got == 0 and time.perf_counter() - t0 < 2.0:
+                        rc = lib.mfm_group_fetch(grp.h, blks)   # waits for a block that is in flight
+                        if rc == 0:
+                            got = blks[0].nr_outputs
+                            lib.mfm_group_release(grp.h)
+                        elif rc == b.MFM_E_DONE:
+                            lib.mfm_group_flush(grp.h)             # (nothing launched yet: a deferred buffer)
+                        else:
+                            raise RuntimeError(f"fetch: {rc}")
+                    if i >= 4:
+                        ms.append((time.perf_counter() - t0) * 1e3)
+                    t_next += period
+                lat.setdefault(name, {})[f"feed_{rate / 1e6:g}_MSps"] = {"latency_ms_median": float(np.median(ms)), "latency_ms_max": float(np.max(ms)),
+                                                                         "buffers": len(ms), "buffer_period_ms": period * 1e3}
+            grp.close()
+        out["latency"] = lat
+    except Exception as e:
+        out["latency"] = {"error": repr(e)}
     for ptr in pinned:
         lib0.mfm_host_free(ptr)
     return out
@@ -577,8 +807,169 @@ def spawn_ranks(args):
     return subprocess.run(cmd).returncode
 
 
+def hip_memcpy_h2d(dst_ptr, arr):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    if hip.hipMemcpy(C.c_void_p(dst_ptr), arr.ctypes.data, arr.nbytes, 1) != 0:
+        raise SystemExit("hipMemcpy (host to device) failed")
+
+
+def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, steps, warmup, settle_s):
+    """One pass of the protocol through the library's device group (mfm_group_*; csrc/mfm_group.hip): the channels are cut into
+    contiguous shards, one engine per device, every block goes from the root's input buffer to the others by the library's own
+    RCCL exchange (scatter + all-gather) and is submitted on every shard - what host/mfm_receiver.c runs for "gpuDevices": [..].
+    One process, one host thread.  Blocks are resident in the root's HBM buffers before the timed region."""
+    b = pkg.binding
+    S = len(devices)
+    g = b.Group(fs, decim, block, devices=tuple(devices),
+                flags=b.MFM_F_DEVICE_ONLY | b.MFM_F_TIMING | (b.MFM_F_TIMING_SPARSE if steps >= 64 else 0) |
+                (b.MFM_F_GROUP_SHARED_DEVICE if shared else 0),
+                exchange=b.MFM_X_RCCL_ALLGATHER if S > 1 else b.MFM_X_AUTO)
+    for o, gn in zip(offs, gains):
+        g.add_channel(int(o), taps, float(gn))
+    g.commit()
+    base = pkg.synth.synth_iq(1 << 22, fs, list(offs)[:: max(1, len(offs) // 8)][:8], seed=7)
+    host = np.ascontiguousarray(np.tile(base, (-(-block // base.shape[0]), 1))[:block])
+    filled = []
+
+    def step():
+        ptr, cap = g.acquire_input()
+        if all(abs(ptr - q) > (1 << 20) for q in filled):   # the root's two input buffers, each filled once (before the timed region)
+            hip_memcpy_h2d(ptr, host)
+            filled.append(ptr)
+        while g.submit(block) == b.MFM_E_BUSY:
+            raise SystemExit("mfm_group_submit: busy in device-only mode")
+
+    for _ in range(4):
+        step()
+    g.sync()
+    t_s = time.perf_counter()
+    for _ in range(8):
+        step()
+    g.sync()
+    per = max((time.perf_counter() - t_s) / 8, 1e-6)
+    for _ in range(int(min(20000, max(0, settle_s / per)))):
+        step()
+    g.sync()
+    for _ in range(warmup):
+        step()
+    g.sync()
+    st0 = [g.stats(s) for s in range(g.nr_shards)]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    smi = gpu_sysfs_sample(0)
+    g.sync()
+    dt = time.perf_counter() - t0
+    st1 = [g.stats(s) for s in range(g.nr_shards)]
+    uses, nblk, moved = g.exchange_info()
+    shards = []
+    for s in range(g.nr_shards):
+        lo, n, dev = g.shard_info(s)
+        timed = st1[s]["timed_launches"] - st0[s]["timed_launches"]
+        shards.append({"shard": s, "device": dev, "first_channel": lo, "channels": n,
+                       "kernel_ms": (st1[s]["kernel_ms"] - st0[s]["kernel_ms"]) / max(1, timed), "timed_launches": int(timed),
+                       "launches": int(st1[s]["launches"] - st0[s]["launches"]), "outputs": int(st1[s]["outputs"] - st0[s]["outputs"]),
+                       "kernel_variant": st1[s]["kernel_variant"], "k_steps": st1[s]["k_steps"], "tap_hi_mask": st1[s]["tap_hi_mask"],
+                       "rot_exact_channels": st1[s]["rot_exact_channels"], "pending_blocks": st1[s]["pending_blocks"],
+                       "submits": int(st1[s]["submits"] - st0[s]["submits"])})
+    eng0 = g.shard_engine(0)
+    lo0, n0, _ = g.shard_info(0)
+    n_last = eng0.last_output_device()[2]
+    verified = verify_last_block(pkg, eng0, fs, decim, taps, list(offs)[lo0:lo0 + n0], list(gains)[lo0:lo0 + n0], st1[0]["outputs"] - n_last)
+    cycles = launch_clocks(eng0, min(steps, 1024))
+    out = {"dt": dt, "shards": shards, "exchange": {"uses_rccl": bool(uses), "blocks": int(nblk), "bytes_to_other_devices": int(moved),
+                                                    "mode": "scatter + all-gather (MFM_X_RCCL_ALLGATHER)" if S > 1 else "none (one device)"},
+           "verified": verified, "clocks": cycles, "board_sample": smi, "st1": st1[0]}
+    g.close()
+    return out
+
+
+def group_main(args, pkg, devices, shared, world_for_line):
+    """`--exchange group`: the whole line from one process."""
+    S = len(devices)
+    cpg = args.channels_per_gpu or (64 if S == 1 else 128)
+    total_ch = cpg * S
+    fs, decim, taps, offs, gains = pkg.synth.plan(args.config, nr_channels=total_ch)
+    block = 1 << args.block_log2
+    T = len(taps)
+    r = group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, args.steps, args.warmup, args.settle_seconds)
+    dt = r["dt"]
+    sh0 = r["shards"][0]
+    k_ms = max(sh["kernel_ms"] for sh in r["shards"])
+    outs = sh0["outputs"] / max(1, sh0["launches"])
+    bytes_per_launch = 4.0 * block + 2.0 * sh0["channels"] * outs   # per GPU: SURVEY.md 8(d), 4 + 2 C_g / D bytes per input sample
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    msamp = args.steps * block / dt / 1e6
+    kname = {0: "mfm_channel_kernel", 1: "mfm_channel_kernel_mfma", 2: "mfm_channel_kernel_v3"}[sh0["kernel_variant"]]
+    need = 4.0 * block / (k_ms * 1e-3) / 1e9 if S > 1 else 0.0
+    line = {
+        "metric": "input IQ MSamp/s x channels demodulated", "value": msamp * total_ch, "unit": "MSamp/s x channels",
+        "n_gpus": world_for_line, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cpg} FM channels per GPU ({total_ch} total), {T}-tap 25 kHz LPF, decimation {decim}, "
+                               f"fs {fs} Hz-shaped int16 IQ, block 2^{args.block_log2} samples",
+                   "channels_per_gpu": cpg, "channels_total": total_ch, "block_samples": block, "decimation": int(decim),
+                   "taps": int(T), "sample_rate_hz": int(fs), "input_msamp_per_s": msamp,
+                   "parallelism": ("1 GPU, through the device group" if S == 1 else
+                                   f"channel shards x{S} in ONE process (mfm_group_*), the library's RCCL scatter + all-gather of every IQ block")
+                                  + (" [TEST AID: all shards on one device]" if shared else "")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": kname, "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch,
+                     "per": "GPU (the slowest shard's kernel)", "clocks": r["clocks"], "board_sample": r["board_sample"]},
+        "cpu_baseline": None,
+        "verified": r["verified"]["verified"], "verification": r["verified"],
+        "group": {"shards": r["shards"], "exchange_info": r["exchange"],
+                  "needed_GBps_per_peer": need, "api": "mfm_group_acquire_input + mfm_group_submit (include/multifm_hip.h)"},
+        "protocol": {"settle_seconds": args.settle_seconds, "warmup_steps": args.warmup, "timed_steps": args.steps},
+    }
+    return line
+
+
+def idle_rank(args):
+    """`--exchange group` under torch.distributed.run: rank 0 drives every GPU of the node through the device group; the other
+    ranks the driver started take part in the barriers and nothing else (they never touch a GPU)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    dist.barrier()   # start
+    dist.barrier()   # rank 0 is through
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    group = args.exchange == "group" and (args.gpus > 1 or args.group_shards > 0)
+    if group:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        if world > 1 and rank != 0:
+            return idle_rank(args)
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("gloo", rank=0, world_size=world)
+            dist.barrier()
+        shared = args.group_shards > 0
+        devices = [0] * args.group_shards if shared else list(range(args.gpus))
+        line = group_main(args, pkg, devices, shared, args.gpus)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
+        if not line["verified"]:
+            raise SystemExit(f"bench.py: the timed kernel's output differs from the oracle: {line['verification']}")
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
     import torch
@@ -618,9 +1009,9 @@ def main():
     in_bytes = lib.mfm_engine_input_bytes(block, T)
     bufs = [torch.empty(in_bytes // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
     eng = pkg.Engine(fs, decim, block, device=local_rank,
-                     # one launch in four carries the event pair (runs too short to hold a few samples time every launch)
+                     # one launch in four carries the event pair; runs of fewer than 64 steps time every launch (the driver's 20)
                      flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
-                     (pkg.binding.MFM_F_TIMING_SPARSE if args.steps >= 16 else 0) |
+                     (pkg.binding.MFM_F_TIMING_SPARSE if args.steps >= 64 else 0) |
                      (pkg.binding.MFM_F_OVERLAP if args.overlap else 0) |
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
                      (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0) |
@@ -703,9 +1094,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    smi = gpu_sysfs_sample(local_rank) if rank == 0 else None  # the steps are queued, the GPU is in the middle of them
     fence()
     dt = time.perf_counter() - t0
     st1 = eng.stats()
+    cycles = launch_clocks(eng, min(args.steps, 1024)) if rank == 0 else None
     if use_dist:
         dt = pkg.dist.max_over_ranks(dt, device="cuda")
 
@@ -740,7 +1133,7 @@ def main():
     # its own rocprofv3 --pmc run, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): only quoted for the
     # exact workload and kernel they were collected on
     traffic, traffic_source = None, None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
         if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and not in8 and \
                 args.config == "cfg2_64ch" and os.path.exists(tpath):
@@ -748,18 +1141,13 @@ def main():
             traffic_source = f"profiles/{rnd}_hbm_traffic.json (rocprofv3 --pmc passes of this command, not this run)"
             break
 
-    # the issue ceiling of this formulation on this chip (profiles/r04_issue_model.json, from the committed SQ counter passes of
-    # this command): matrix and other vector instructions of a SIMD do not overlap on gfx950, so a launch cannot be shorter
-    # than their issue cycles; what the kernel takes beyond that is latency it does not hide.  The HBM roof (0.70 in the
-    # north star) is not what bounds this kernel - this is.
+    # the issue ceiling of this formulation on this chip: matrix and other vector instructions of a SIMD do not overlap on gfx950,
+    # so a launch cannot be shorter than their issue cycles; what the kernel takes beyond that is latency it does not hide.  The
+    # HBM roof (0.70 in the north star) is not what bounds this kernel - this is.  Cycles and clock: this run's, stamped by the
+    # kernel; instruction counts: of this library and kernel instance (issue_model()).
     ceiling = None
-    ipath = os.path.join(ROOT, "profiles", "r04_issue_model.json")
-    if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and args.config == "cfg2_64ch" and \
-            os.path.exists(ipath) and not args.overlap and not in8:
-        im = json.load(open(ipath))
-        ceiling = {"ceiling_frac": achieved / HBM_PEAK_GBPS / im["busy_fraction_3cycle"], "simd_busy_fraction": im["busy_fraction_3cycle"],
-                   "mfma_busy_cycles_per_simd": im["mfma_busy_cycles_per_simd"], "valu_cycles_per_simd": im["valu_cycles_per_simd_at_3"],
-                   "source": "profiles/r04_issue_model.json (SQ counters of this command; not this run)"}
+    if rank == 0 and st1["kernel_variant"] == 2 and world == 1:
+        ceiling = issue_model(instance_name(pkg, st1, in8), st1, cycles, achieved / HBM_PEAK_GBPS, library_sha16(pkg))
 
     verified = None
     if rank == 0:
@@ -792,7 +1180,9 @@ def main():
                          "bytes_per_launch": bytes_per_launch,
                          # what holds the kernel below the HBM roof (SQ counters in profiles/)
                          "binding": "simd_issue" if mfma else "valu_dot2",
-                         "ceiling_frac": ceiling["ceiling_frac"] if ceiling else None, "issue_model": ceiling},
+                         "ceiling_frac": ceiling["ceiling_frac"] if ceiling else None, "issue_model": ceiling,
+                         # the kernel's own clocks for the timed launches, and one sysfs sample taken while they ran
+                         "clocks": cycles, "board_sample": smi},
             "verified": verified["verified"], "verification": verified,
             "rotators": {"exact_channels": st1["rot_exact_channels"], "channels": len(offs)},
             "protocol": {"settle_seconds": args.settle_seconds, "settle_steps": settle_steps + 8,
@@ -834,6 +1224,18 @@ def main():
         if line["roofline"]["kernel"].startswith("mfm_channel_kernel_v3"):
             line["ingest_8bit"] = ingest_8bit(pkg, fs, decim, taps, offs, gains, block, line["roofline"]["kernel_ms"])
         line["other_geometries"] = other_geometries(pkg, torch, block)
+        line["north_star_shape"] = north_star_shape(pkg, torch, block)
+        if not in8 and args.kernel == "auto" and not args.overlap:
+            # the same workload through the product's device-group path (one device: no exchange): must agree with `value`
+            try:
+                gr = group_run(pkg, args, [local_rank], False, fs, decim, taps, offs, gains, block, args.steps, args.warmup, 0.25)
+                gv = args.steps * block / gr["dt"] / 1e6 * total_ch
+                line["group_path"] = {"value": gv, "unit": "MSamp/s x channels", "ms_per_step": gr["dt"] / args.steps * 1e3,
+                                      "ratio_to_value": gv / line["value"], "kernel_ms": gr["shards"][0]["kernel_ms"],
+                                      "verified": gr["verified"]["verified"], "shards": gr["shards"], "exchange_info": gr["exchange"],
+                                      "how": "mfm_group_acquire_input + mfm_group_submit on one device, same blocks, same step counts"}
+            except Exception as e:
+                line["group_path"] = {"error": repr(e)}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

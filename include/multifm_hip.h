@@ -229,6 +229,11 @@ int mfm_engine_push_bytes(struct mfm_engine *e, const void *bytes, size_t nr_sam
  * mfm_engine_copy_wait returns) - that is when the reference would sample_buf_decref() it (filter/direct_fir.c:395).
  */
 void *mfm_host_alloc(size_t bytes); /* page-locked host memory (hipHostMalloc); NULL on failure */
+/* The host <-> device link by itself, as a yardstick for host-fed throughput (bench.py `link`): total_bytes leave an arena of
+ * page-locked memory in pieces of piece_bytes (one hipMemcpyAsync each on one stream, as the engine's pinned pushes do per
+ * sample_buf), while d2h_per_h2d bytes per input byte come back on a second stream (the PCM mirror; 0: none).  Rates in
+ * GB/s over the second of two passes. */
+int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2h_per_h2d, double *h2d_GBps, double *d2h_GBps);
 void mfm_host_free(void *p);
 int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_samples, int format, uint64_t *ticket);
 int mfm_engine_copy_done(struct mfm_engine *e, uint64_t ticket); /* 1: read, 0: not yet, < 0: error */
@@ -287,6 +292,13 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st);
 /* MFM_F_TIMING: durations (ms, HIP events on the compute stream) of the most recent launches, oldest first; at most
  * `cap` and at most the last 4096.  Returns how many were written. */
 size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap);
+/* MFM_F_TIMING, second-generation kernels: the last launches' durations in the shader's own clocks, oldest first - the
+ * longest workgroup's s_memtime (shader-clock ticks) and s_memrealtime (100 MHz reference ticks) difference, stamped by the
+ * kernel itself.  shader / ref * 100 MHz is the clock the launch really ran at; shader ticks against the kernel's issue
+ * cycles is how much of the launch the SIMDs were issuing (bench.py: roofline.issue_model).  Waits for the engine to drain.
+ * 0 entries for launches that left no stamp; returns the number of entries written (0 without MFM_F_TIMING or on the other
+ * kernels).  Either array may be NULL. */
+size_t mfm_engine_get_launch_cycles(struct mfm_engine *e, uint64_t *shader_ticks, uint64_t *ref_ticks, size_t cap);
 
 /* The engine's compute stream (hipStream_t) - with MFM_F_OVERLAP the one the most recent launch went to - for callers that
  * order their own work after it. */
@@ -321,7 +333,7 @@ struct mfm_group_config {
     uint32_t sample_rate_hz;
     uint32_t decimation;
     uint32_t max_block_samples;
-    uint32_t flags;             /* MFM_F_* handed to every engine (MFM_F_DEVICE_ONLY is not valid here) */
+    uint32_t flags;             /* MFM_F_* handed to every engine (MFM_F_DEVICE_ONLY: see mfm_group_submit) */
     uint32_t exchange;          /* MFM_X_* */
     uint32_t coalesce_samples;  /* as mfm_engine_config::coalesce_samples; the shards launch or defer together */
     uint32_t reserved;          /* 0 */
@@ -342,6 +354,17 @@ int mfm_group_add_channel(struct mfm_group *g, int32_t offset_hz, const double *
 int mfm_group_commit(struct mfm_group *g);
 int mfm_group_nr_shards(struct mfm_group *g); /* >= 1 after commit */
 int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_channel, uint32_t *nr_channels, int32_t *device);
+/* Blocks that are in device memory already (a producer kernel, a peer copy, another library's collective wrote them): the
+ * ROOT's input buffer is where they go - acquire_input() names the address, as mfm_engine_acquire_input() - and submit()
+ * exchanges the nr_samples int16 samples there to the other shards and submits them on every shard, in the same order and
+ * under the same all-or-nothing rules as a host block (mfm_group_push).  The caller has made sure the block is complete
+ * before it submits.  With MFM_F_DEVICE_ONLY in the group's flags the shards keep their outputs in HBM (no host mirror, no
+ * mfm_group_fetch): a throughput measurement, or a consumer that works on the device. */
+int mfm_group_acquire_input(struct mfm_group *g, void **d_dst, size_t *capacity_samples);
+int mfm_group_submit(struct mfm_group *g, size_t nr_samples);
+/* shard `shard`'s engine, for the READ-ONLY engine calls (get_stats, get_launch_ms / _cycles, last_output_device,
+ * last_launch_input, get_channel with the shard's own channel numbers); NULL when there is no such shard */
+struct mfm_engine *mfm_group_shard_engine(struct mfm_group *g, uint32_t shard);
 /* host ingest of one block in any MFM_IN_* format.  MFM_E_BUSY when a shard's output ring is full (nothing was
  * staged on any shard: fetch/release and retry). */
 int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format);

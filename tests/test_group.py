@@ -277,6 +277,49 @@ def test_bench_runs_its_distributed_path_on_one_rank(pkg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 4])
+def test_bench_group_path_over_the_fake_transport(tmp_path, shards):
+    """bench.py --gpus N goes through the PRODUCT's multi-GPU code (mfm_group_acquire_input / mfm_group_submit: channel shards, the
+    library's RCCL scatter + all-gather of every block, one process).  No multi-GPU node here: the same call path with
+    --group-shards S puts S shards on the one device (MFM_F_GROUP_SHARED_DEVICE) over the test double of the RCCL calls.  The
+    line must carry the exchange's counters and every shard's statistics, the shards must have moved in lock step, and
+    the self-check (shard 0's last launch against the oracle) must hold."""
+    so = tmp_path / "librccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
+                        os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--group-shards", str(shards), "--channels-per-gpu", "40",
+                        "--steps", "5", "--warmup", "2", "--settle-seconds", "0", "--block-log2", "21"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    g = line["group"]
+    assert line["verified"] is True and line["value"] > 0 and "mfm_group" in line["config"]["parallelism"]
+    assert len(g["shards"]) == shards and sum(sh["channels"] for sh in g["shards"]) == 40 * shards
+    assert g["exchange_info"]["uses_rccl"] and g["exchange_info"]["bytes_to_other_devices"] >= 5 * (shards - 1) * (4 << 21)
+    assert len({sh["launches"] for sh in g["shards"]}) == 1 and all(sh["launches"] == 5 and sh["kernel_variant"] == 2 for sh in g["shards"])
+    assert all(sh["pending_blocks"] == 0 for sh in g["shards"])
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_group_path_and_the_north_star_shape():
+    """the N = 1 line: `group_path` - the same workload through mfm_group_* on one device - within 3 % of `value` here (small
+    blocks; 2 % at the driver's size), and `north_star_shape` - 1024 channels on the one GPU - with its matrix-instruction bound"""
+    r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--settle-seconds", "0.3",
+                        "--no-cpu-baseline", "--no-fp32", "--no-chain", "--no-series", "--block-log2", "24"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    gp, ns = line["group_path"], line["north_star_shape"]
+    assert gp["verified"] is True and 0.9 < gp["ratio_to_value"] < 1.1, gp
+    assert ns["channels"] == 1024 and ns["kernel_variant"] == 2 and 0.0 < ns["roofline"]["frac"] < ns["bound_frac"]["at_nominal_5000_tops"] < 1.0, ns
+    clk = line["roofline"]["clocks"]
+    assert clk and clk["launches"] == 20 and 500.0 < clk["sclk_mhz_effective"] < 3000.0, clk
+    assert line["roofline"]["timed_launches"] == 20  # fewer than 64 steps: every launch carries the event pair
+
+
+@pytest.mark.gpu
 def test_bench_exchanges_8bit_blocks_as_bytes(pkg):
     """bench.py --input rtlsdr_u8 on its distributed path (one rank): the block lies in the engine's buffer as the bytes an
     RTL-SDR delivers, the exchange moves 2 bytes per sample instead of 4, the matrix kernel reads the bytes, and the line's

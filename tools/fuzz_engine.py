@@ -86,7 +86,7 @@ def case(pkg, ora, rng, long_only=False):
     qs = [q for q in outq if q is not None]
     if want_iq and refq is not None and refq.shape[1] > 0 and (not qs or not np.array_equal(np.concatenate(qs, axis=1), refq)):
         return "filtered IQ differs: " + desc, desc
-    return None, 3 if resident else variant
+    return None, (3 if variant == 1 and resident else 4 if variant == 2 and resident else variant)
 
 
 def case8(pkg, ora, rng, long_only=False):
@@ -332,7 +332,7 @@ def main():
             continue
         key = info if isinstance(info, (int, np.integer)) else "refused"
         counts[int(key) if key != "refused" else key] = counts.get(int(key) if key != "refused" else key, 0) + 1
-    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2, 3 matrix gen 1 with resident taps; --ingest8: by how the blocks were read)", counts)
+    print("ok: cases per kernel variant (0 v_dot2, 1 matrix gen 1, 2 matrix gen 2, 3 matrix gen 1 with resident taps, 4 matrix gen 2 long-filter kernel; --ingest8: by how the blocks were read)", counts)
     return 0
 
 

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "mfm_engine_acquire_input_bytes",
     "mfm_engine_submit", "mfm_engine_push", "mfm_engine_push_bytes", "mfm_engine_fetch", "mfm_engine_release",
     "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
-    "mfm_engine_stream", "mfm_engine_get_launch_ms", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
+    "mfm_engine_stream", "mfm_engine_get_launch_ms", "mfm_engine_get_launch_cycles", "mfm_group_acquire_input", "mfm_group_submit", "mfm_group_shard_engine", "mfm_link_probe", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
     "mfm_resampler_create", "mfm_resampler_destroy", "mfm_resampler_max_out", "mfm_resampler_process_device",
     "mfm_resampler_process_host", "mfm_resampler_process_host_to_device",
@@ -225,8 +225,15 @@ def load_library():
     lib.mfm_group_sync.argtypes = [vp]
     lib.mfm_group_get_stats.argtypes = [vp, C.c_uint32, C.POINTER(Stats)]
     lib.mfm_group_exchange_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.mfm_group_acquire_input.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.mfm_group_submit.argtypes = [vp, C.c_size_t]
+    lib.mfm_group_shard_engine.argtypes = [vp, C.c_uint32]
+    lib.mfm_group_shard_engine.restype = vp
+    lib.mfm_link_probe.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mfm_engine_get_launch_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
     lib.mfm_engine_get_launch_ms.restype = C.c_size_t
+    lib.mfm_engine_get_launch_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]
+    lib.mfm_engine_get_launch_cycles.restype = C.c_size_t
     lib.mfm_engine_stream.restype = vp
     lib.mfm_strerror.argtypes = [C.c_int]
     lib.mfm_strerror.restype = C.c_char_p
@@ -324,9 +331,9 @@ class Engine:
         return rc
 
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "_borrowed", False):  # (a shard engine of a Group belongs to the group)
             self.lib.mfm_engine_destroy(C.byref(self.h))
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -491,6 +498,14 @@ class Engine:
         n = self.lib.mfm_engine_get_launch_ms(self.h, buf.ctypes.data_as(C.POINTER(C.c_float)), last)
         return buf[:n].copy()
 
+    def launch_cycles(self, last=1024):
+        """MFM_F_TIMING, second-generation kernels: (shader-clock ticks, 100 MHz reference ticks) of the most recent `last`
+        launches, oldest first, as the kernel stamped them (0 where a launch left no stamp)."""
+        a, b = np.zeros(last, np.uint64), np.zeros(last, np.uint64)
+        n = self.lib.mfm_engine_get_launch_cycles(self.h, a.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   b.ctypes.data_as(C.POINTER(C.c_uint64)), last)
+        return a[:n].copy(), b[:n].copy()
+
     @property
     def stream(self):
         return self.lib.mfm_engine_stream(self.h)
@@ -523,6 +538,7 @@ class Group:
         if rc < 0:
             raise MfmError(rc, "mfm_group_create", self.lib.mfm_last_error().decode())
         self.nr_channels = 0
+        self._decimation, self._sample_rate_hz, self._nr_taps = decimation, sample_rate_hz, 0
 
     def _chk(self, rc, what):
         if rc < 0:
@@ -543,6 +559,7 @@ class Group:
     def add_channel(self, offset_hz, lpf_taps, gain=1.0, want_iq=False):
         t = np.ascontiguousarray(lpf_taps, dtype=np.float64)
         self.nr_channels += 1
+        self._nr_taps = t.size
         return self._chk(self.lib.mfm_group_add_channel(self.h, int(offset_hz), t.ctypes.data_as(C.POINTER(C.c_double)),
                                                         t.size, float(gain), int(want_iq)), "mfm_group_add_channel")
 
@@ -594,6 +611,32 @@ class Group:
         st = Stats()
         self._chk(self.lib.mfm_group_get_stats(self.h, shard, C.byref(st)), "mfm_group_get_stats")
         return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def acquire_input(self):
+        """(device address, capacity in samples) of where the next device-resident block goes: the root's input buffer"""
+        p, cap = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.mfm_group_acquire_input(self.h, C.byref(p), C.byref(cap)), "mfm_group_acquire_input")
+        return p.value, cap.value
+
+    def submit(self, nr_samples):
+        """the block at acquire_input()'s address: exchanged and submitted on every shard; returns 0 or MFM_E_BUSY"""
+        rc = self.lib.mfm_group_submit(self.h, nr_samples)
+        if rc == MFM_E_BUSY:
+            return rc
+        return self._chk(rc, "mfm_group_submit")
+
+    def shard_engine(self, shard):
+        """shard `shard`'s engine as an Engine object for the read-only calls (stats, launch_ms, launch_cycles,
+        last_output_device, last_launch_input, get_channel); it does not own the handle"""
+        h = self.lib.mfm_group_shard_engine(self.h, shard)
+        if not h:
+            raise MfmError(-1, "mfm_group_shard_engine", "no such shard")
+        e = Engine.__new__(Engine)
+        e.lib, e.h, e._borrowed = self.lib, C.c_void_p(h), True
+        e.decimation, e.sample_rate_hz = self._decimation, self._sample_rate_hz
+        e.nr_channels = self.shard_info(shard)[1]
+        e.nr_taps = self._nr_taps
+        return e
 
     def exchange_info(self):
         u, b, x = C.c_int(), C.c_uint64(), C.c_uint64()

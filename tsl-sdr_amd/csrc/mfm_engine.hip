@@ -74,6 +74,7 @@ constexpr int kOutSlots = 4;      /* output ring depth (2 in device-only mode) *
 constexpr int kMaxInBufs = 3;     /* input buffers: 2, or 3 when the engine coalesces (mfm_engine_config::coalesce_samples) */
 constexpr int kTimingPairs = 256; /* event pairs kept before the oldest is folded into the total */
 constexpr uint64_t kSparseTiming = 4; /* MFM_F_TIMING_SPARSE: one launch in this many is bracketed */
+constexpr uint64_t kCycleRing = 1024; /* launches whose shader-clock stamps are kept (mfm_engine_get_launch_cycles) */
 constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine_get_launch_ms() */
 constexpr uint32_t kMaxOutputsPerTile = 128;
 constexpr uint64_t kMaxRotEntries = 1ull << 26; /* per distinct increment: 512 MiB of table */
@@ -271,6 +272,8 @@ struct mfm_engine {
     bool timing_events = false;
     uint64_t t_head = 0, t_tail = 0;
     double kernel_ms = 0.0;
+    /* MFM_F_TIMING, second-generation kernels: per-launch durations in the shader's own clocks (mfm_launch_v3::cyc) */
+    unsigned long long *d_cyc = nullptr; /* [kCycleRing][2] */
     std::vector<float> launch_ms; /* ring of the last kLaunchRing launch durations */
     uint64_t launch_ms_n = 0;     /* durations folded so far */
 };
@@ -521,6 +524,7 @@ void free_device(mfm_engine *e)
     e->d_tailtmp = nullptr;
     (void)hipFree(e->d_info);
     (void)hipFree(e->d_rot);
+    (void)hipFree(e->d_cyc);
     (void)hipFree(e->d_lut);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(e->d_state[i]);
@@ -602,6 +606,7 @@ void free_device(mfm_engine *e)
     e->d_krow = nullptr;
     e->d_info = nullptr;
     e->d_rot = nullptr;
+    e->d_cyc = nullptr;
     e->d_lut = nullptr;
     for (int i = 0; i < 2; i++) {
         e->d_state[i] = nullptr;
@@ -1522,6 +1527,10 @@ static int commit_locked(struct mfm_engine *e)
         }
         HIP_TRY(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
     }
+    if ((e->cfg.flags & MFM_F_TIMING) && e->use_v3) {
+        HIP_TRY(hipMalloc(&e->d_cyc, kCycleRing * 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(e->d_cyc, 0, kCycleRing * 2 * sizeof(unsigned long long)));
+    }
     if (e->cfg.flags & MFM_F_TIMING) {
         e->timing_events = true;
         for (int i = 0; i < kTimingPairs; i++) {
@@ -1741,6 +1750,10 @@ int launch_locked(mfm_engine *e)
             }
             V.pcm = slot->d_pcm;
             V.iq_dbg = L.iq_dbg;
+            if (e->d_cyc) {
+                V.cyc = e->d_cyc + 2u * (e->launches % kCycleRing);
+                V.cyc_tag = (uint32_t)((e->launches + 1u) & 0xffffffu);
+            }
             if (raw8) {
                 e->launches_8bit++;
             }
@@ -2228,6 +2241,77 @@ int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_sam
     return mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 
+/* The host <-> device link by itself (include/multifm_hip.h): what a host-fed figure is to be read against. */
+int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2h_per_h2d, double *h2d_GBps, double *d2h_GBps)
+{
+    if (0 == piece_bytes || total_bytes < piece_bytes || d2h_per_h2d < 0.0 || d2h_per_h2d > 4.0) {
+        return fail(MFM_E_INVAL, "piece / total bytes, or the D2H share");
+    }
+    HIP_TRY(hipSetDevice(device));
+    /* one arena of page-locked memory cut into pieces, like the receiver's sample_buf pool (host/mfm_receiver.c) */
+    const size_t arena = std::min<size_t>(total_bytes, (size_t)64 << 20) / piece_bytes * piece_bytes;
+    const size_t pieces_in_arena = arena / piece_bytes;
+    const size_t back_piece = (size_t)((double)piece_bytes * d2h_per_h2d) & ~(size_t)15;
+    uint8_t *h_src = nullptr, *h_dst = nullptr, *d_in = nullptr, *d_out = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, f0 = nullptr, f1 = nullptr;
+    int rc = MFM_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_src), arena, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), arena));
+        memset(h_src, 0x5a, arena);
+        if (back_piece) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_dst), back_piece * pieces_in_arena, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), back_piece * pieces_in_arena));
+            HIP_TRY(hipMemset(d_out, 0, back_piece * pieces_in_arena));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventCreate(&f0));
+        HIP_TRY(hipEventCreate(&f1));
+        const size_t n = total_bytes / piece_bytes;
+        for (int pass = 0; pass < 2; pass++) { /* the first pass warms the mappings up */
+            HIP_TRY(hipEventRecord(e0, s_in));
+            HIP_TRY(hipEventRecord(f0, s_out));
+            for (size_t i = 0; i < n; i++) {
+                const size_t k = i % pieces_in_arena;
+                HIP_TRY(hipMemcpyAsync(d_in + k * piece_bytes, h_src + k * piece_bytes, piece_bytes, hipMemcpyHostToDevice, s_in));
+                if (back_piece) {
+                    HIP_TRY(hipMemcpyAsync(h_dst + k * back_piece, d_out + k * back_piece, back_piece, hipMemcpyDeviceToHost, s_out));
+                }
+            }
+            HIP_TRY(hipEventRecord(e1, s_in));
+            HIP_TRY(hipEventRecord(f1, s_out));
+            HIP_TRY(hipStreamSynchronize(s_in));
+            HIP_TRY(hipStreamSynchronize(s_out));
+        }
+        float ms_in = 0.0f, ms_out = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms_in, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&ms_out, f0, f1));
+        if (h2d_GBps) {
+            *h2d_GBps = (double)(n * piece_bytes) / ((double)ms_in * 1e6);
+        }
+        if (d2h_GBps) {
+            *d2h_GBps = back_piece ? (double)(n * back_piece) / ((double)ms_out * 1e6) : 0.0;
+        }
+        return MFM_OK;
+    };
+    rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (f0) (void)hipEventDestroy(f0);
+    if (f1) (void)hipEventDestroy(f1);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_out) (void)hipStreamDestroy(s_out);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipHostFree(h_src);
+    (void)hipHostFree(h_dst);
+    return rc;
+}
+
 void *mfm_host_alloc(size_t bytes)
 {
     void *p = nullptr;
@@ -2523,6 +2607,34 @@ size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap)
     const size_t n = std::min(have, cap);
     for (size_t i = 0; i < n && dst; i++) {
         dst[i] = e->launch_ms[(e->launch_ms_n - n + i) % kLaunchRing];
+    }
+    return n;
+}
+
+size_t mfm_engine_get_launch_cycles(struct mfm_engine *e, uint64_t *shader_ticks, uint64_t *ref_ticks, size_t cap)
+{
+    if (!e || !e->committed || !e->d_cyc) {
+        return 0;
+    }
+    if (hipSetDevice(e->cfg.device) != hipSuccess || mfm_engine_sync(e) != MFM_OK) {
+        return 0;
+    }
+    std::vector<unsigned long long> ring(kCycleRing * 2);
+    if (hipMemcpy(ring.data(), e->d_cyc, ring.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
+        return 0;
+    }
+    const uint64_t have = std::min<uint64_t>(e->launches, kCycleRing);
+    const size_t n = (size_t)std::min<uint64_t>(have, cap);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t seq = e->launches - n + i; /* 0-based index of the launch */
+        const uint64_t tag = ((seq + 1u) & 0xffffffu) << 40, mask = (1ull << 40) - 1ull;
+        const unsigned long long a = ring[2 * (seq % kCycleRing)], b = ring[2 * (seq % kCycleRing) + 1];
+        if (shader_ticks) {
+            shader_ticks[i] = (a & ~mask) == tag ? (a & mask) : 0u; /* 0: the launch left no stamp (no work, or not this kernel) */
+        }
+        if (ref_ticks) {
+            ref_ticks[i] = (b & ~mask) == tag ? (b & mask) : 0u;
+        }
     }
     return n;
 }

@@ -170,9 +170,9 @@ int mfm_group_create(struct mfm_group **pg, const struct mfm_group_config *cfg)
     if (0 == cfg->decimation || 0 == cfg->sample_rate_hz || 0 == cfg->max_block_samples) {
         return gfail(MFM_E_INVAL, "decimation, sample rate and max block must be non-zero");
     }
-    if (cfg->flags & MFM_F_DEVICE_ONLY) {
-        return gfail(MFM_E_INVAL, "a device group delivers its blocks through mfm_group_fetch(): MFM_F_DEVICE_ONLY is not valid");
-    }
+    /* (MFM_F_DEVICE_ONLY: the shards keep their outputs in HBM - mfm_group_fetch() is not available then; blocks are handed
+     * over in device memory with mfm_group_acquire_input() / mfm_group_submit(), outputs are read through
+     * mfm_group_shard_engine()) */
     mfm_group *g = new (std::nothrow) mfm_group();
     if (!g) {
         return gfail(MFM_E_NOMEM, "group allocation failed");
@@ -362,6 +362,7 @@ namespace {
 struct GroupOps {
     mfm_group *g;
     bool pinned = false; /* the block lies in page-locked memory: the root's H2D reads it where it is */
+    bool resident = false; /* the block already lies in the root's input buffer (mfm_group_acquire_input): nothing to stage */
     size_t shards() { return g->eng.size(); }
     int plan(size_t i, size_t n, bool *must, bool *may, bool *want)
     {
@@ -382,6 +383,11 @@ struct GroupOps {
     }
     int stage_root(const void *data, size_t n, int fmt, bool raw, void **d_root)
     {
+        if (resident) {
+            size_t cap = 0;
+            const int rc = mfm_engine_acquire_input(g->eng[0], d_root, &cap);
+            return rc != MFM_OK ? rc : cap < n ? gfail(MFM_E_INVAL, "the root's input buffer has room for %zu samples, the block has %zu", cap, n) : MFM_OK;
+        }
         return mfm_engine_stage(g->eng[0], data, n, fmt, (raw ? MFM_STAGE_ALLOW_RAW : 0) | (pinned ? MFM_STAGE_PINNED : 0), d_root);
     }
     int nccl_fail(int nrc, const char *what, size_t bytes)
@@ -452,6 +458,47 @@ struct GroupOps {
 } /* namespace */
 
 extern "C" {
+
+/* ---- blocks that are in device memory already: the root's input buffer is where they are written (by a producer kernel, a
+ *      peer-to-peer copy, another library's collective), the exchange and the submits are the same as for a host block ---- */
+
+int mfm_group_acquire_input(struct mfm_group *g, void **d_dst, size_t *capacity_samples)
+{
+    if (!g || !d_dst) {
+        return gfail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    return mfm_engine_acquire_input(g->eng[0], d_dst, capacity_samples);
+}
+
+int mfm_group_submit(struct mfm_group *g, size_t nr_samples)
+{
+    if (!g) {
+        return gfail(MFM_E_INVAL, "NULL group");
+    }
+    if (!g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    if (!g->exchange) {
+        return mfm_engine_submit(g->eng[0], nr_samples, nullptr, 0);
+    }
+    GroupOps ops{ g };
+    ops.resident = true;
+    size_t bytes = 0;
+    const int rc = mfm_group_push_seq(ops, &g->broken, nullptr, nr_samples, MFM_IN_CS16, false, &bytes);
+    if (rc == MFM_OK) {
+        g->blocks++;
+        g->bytes_exchanged += (uint64_t)bytes * (g->eng.size() - 1u);
+    }
+    return rc;
+}
+
+struct mfm_engine *mfm_group_shard_engine(struct mfm_group *g, uint32_t shard)
+{
+    return (g && g->committed && shard < g->eng.size()) ? g->eng[shard] : nullptr;
+}
 
 int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format)
 {

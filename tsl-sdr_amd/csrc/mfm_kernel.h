@@ -244,6 +244,13 @@ struct mfm_launch_v3 {
     uint32_t tp_off;      /* LDS byte offset of the transposition areas: [8 waves][8 * rb channels][72] dwords, then the fold
                              constants (512 * rb bytes) and the exact-rotator tables (2048 * rb bytes) */
     uint32_t *tail_dst;
+    /* MFM_F_TIMING: how long the launch took in the shader's own clocks.  Every workgroup that had work stamps itself at its
+     * start and its end (s_memtime: shader-clock ticks; s_memrealtime: the constant 100 MHz reference) and folds its duration
+     * into cyc[0] / cyc[1] with an atomic maximum - the workgroups of these kernels are persistent, so the longest one IS the
+     * launch.  The values carry the launch's tag in their top 24 bits (cyc_tag << 40), which makes a slot reusable without
+     * clearing it.  NULL: no stamps. */
+    unsigned long long *cyc;
+    uint32_t cyc_tag, pad2;
     const uint32_t *afrag;
     const int32_t *krow;
     const struct mfm_chan_info *info;

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     if (!mfm3_decode_item(L, item, &chunk, &slice)) {
         return;
     }
+    const uint64_t stamp_t0 = L.cyc ? __builtin_amdgcn_s_memtime() : 0ull, stamp_r0 = L.cyc ? __builtin_amdgcn_s_memrealtime() : 0ull;
     /* chunk j = tiles [j * ntiles / nchunks, (j + 1) * ntiles / nchunks): lengths differ by at most one tile */
     uint32_t tile = (uint32_t)(((uint64_t)chunk * L.ntiles) / L.nchunks);
     uint32_t tend = (uint32_t)(((uint64_t)(chunk + 1u) * L.ntiles) / L.nchunks);
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
         tend = n_tend;
         first_of_chunk = n_first;
     }
+    mfm3_stamp_end(L, stamp_t0, stamp_r0);
 }
 
 /* Not built: the instances that would need more than 256 registers - many k-steps with most high-byte planes held, int16

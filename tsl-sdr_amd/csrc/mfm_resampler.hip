@@ -332,15 +332,20 @@ __global__ __launch_bounds__(64) void mfm_dc_block_kernel(int16_t *y, uint32_t o
                 u32x4 o;
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
+                    /* three instructions per sample on the chain y -> r -> acc -> y (round 5; five before): the multiply-add of
+                     * the leak, (x << 14) + r as ONE v_mad_i32_i16 that picks the sample's half of the packed word itself
+                     * (x * 16384 + r, wrapping like the reference's int32), the arithmetic shift; half a v_perm to pack */
+                    uint32_t acc;
                     r += (uint32_t)__mul24(yp, np);
-                    xl = (int32_t)(int16_t)(w[d] & 0xffffu);
-                    yp = (int32_t)(((uint32_t)xl << 14) + r) >> 14;
+                    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(acc) : "v"(w[d]), "s"(16384), "v"(r));
+                    yp = (int32_t)acc >> 14;
                     const uint32_t lo = (uint32_t)yp;
                     r += (uint32_t)__mul24(yp, np);
-                    xl = (int32_t)w[d] >> 16;
-                    yp = (int32_t)(((uint32_t)xl << 14) + r) >> 14;
+                    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(acc) : "v"(w[d]), "s"(16384), "v"(r));
+                    yp = (int32_t)acc >> 14;
                     o[d] = __builtin_amdgcn_perm((uint32_t)yp, lo, 0x05040100u); /* low halves of (lo, yp) */
                 }
+                xl = (int32_t)w[3] >> 16; /* the group's last sample: x_(n-1) of whatever follows */
                 dst[i / 8u + k] = o;
             }
 #pragma unroll

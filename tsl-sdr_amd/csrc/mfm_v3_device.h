@@ -306,6 +306,18 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
 #endif
 }
 
+/* the workgroup's duration in shader-clock ticks and in 100 MHz reference ticks, folded into the launch's maximum
+ * (mfm_launch_v3::cyc); t0 / r0: the stamps taken at the workgroup's start */
+static __device__ __forceinline__ void mfm3_stamp_end(const mfm_launch_v3 &L, uint64_t t0, uint64_t r0)
+{
+    if (L.cyc != nullptr && threadIdx.x == 0) {
+        const uint64_t tag = (uint64_t)(L.cyc_tag & 0xffffffu) << 40, mask = (1ull << 40) - 1ull;
+        const uint64_t dt = (__builtin_amdgcn_s_memtime() - t0) & mask, dr = (__builtin_amdgcn_s_memrealtime() - r0) & mask;
+        atomicMax(L.cyc, (unsigned long long)(tag | dt));
+        atomicMax(L.cyc + 1, (unsigned long long)(tag | dr));
+    }
+}
+
 /* one work item = (chunk of consecutive tiles, 64-channel slice); XCD-aware: the slices of a chunk run back to back
  * on one XCD, so the chunk's input is fetched from HBM once and re-read from that XCD's L2 */
 static __device__ __forceinline__ bool mfm3_decode_item(const mfm_launch_v3 &L, uint32_t item, uint32_t *chunk, uint32_t *slice)
