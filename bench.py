@@ -321,6 +321,31 @@ def gpu_sysfs_sample(local_rank=0):
     return {"sclk_mhz": sclk / 1e6 if sclk else None, "power_w": power / 1e6 if power else None, "source": hw}
 
 
+class BoardSampler:
+    """One gpu_sysfs_sample() taken WHILE the timed steps run, on a thread of its own: a hwmon read is a message to the SMU and
+    takes a millisecond or two - on the submitting thread it would sit in the middle of a 2.4 ms timed region (first try of this
+    round: ms_per_step 0.124 -> 0.221).  start() right before the timed loop, result() behind it."""
+
+    def __init__(self, local_rank=0):
+        import threading
+        self.out, self.t_rel = None, None
+        self.local_rank = local_rank
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        t0 = time.perf_counter()
+        self.out = gpu_sysfs_sample(self.local_rank)
+        if self.out is not None:
+            self.out["read_ms"] = (time.perf_counter() - t0) * 1e3
+
+    def start(self):
+        self.thread.start()
+
+    def result(self):
+        self.thread.join(timeout=5.0)
+        return self.out
+
+
 def launch_clocks(eng, n):
     """The last n launches as the kernel stamped them itself (mfm_engine_get_launch_cycles): median shader-clock ticks of the
     longest workgroup, the 100 MHz reference ticks beside them, and the clock that makes of the two."""
@@ -859,10 +884,18 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    smi = gpu_sysfs_sample(0)
     g.sync()
     dt = time.perf_counter() - t0
     st1 = [g.stats(s) for s in range(g.nr_shards)]
+    eng0 = g.shard_engine(0)
+    cycles = launch_clocks(eng0, min(steps, 1024))
+    sampler = BoardSampler(0)   # behind the timed region, while the same steps keep running (see main())
+    for k in range(max(steps, 16)):
+        step()
+        if k == 2:
+            sampler.start()
+    g.sync()
+    smi = sampler.result()
     uses, nblk, moved = g.exchange_info()
     shards = []
     for s in range(g.nr_shards):
@@ -874,11 +907,10 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
                        "kernel_variant": st1[s]["kernel_variant"], "k_steps": st1[s]["k_steps"], "tap_hi_mask": st1[s]["tap_hi_mask"],
                        "rot_exact_channels": st1[s]["rot_exact_channels"], "pending_blocks": st1[s]["pending_blocks"],
                        "submits": int(st1[s]["submits"] - st0[s]["submits"])})
-    eng0 = g.shard_engine(0)
     lo0, n0, _ = g.shard_info(0)
     n_last = eng0.last_output_device()[2]
-    verified = verify_last_block(pkg, eng0, fs, decim, taps, list(offs)[lo0:lo0 + n0], list(gains)[lo0:lo0 + n0], st1[0]["outputs"] - n_last)
-    cycles = launch_clocks(eng0, min(steps, 1024))
+    verified = verify_last_block(pkg, eng0, fs, decim, taps, list(offs)[lo0:lo0 + n0], list(gains)[lo0:lo0 + n0],
+                                 g.stats(0)["outputs"] - n_last)
     out = {"dt": dt, "shards": shards, "exchange": {"uses_rccl": bool(uses), "blocks": int(nblk), "bytes_to_other_devices": int(moved),
                                                     "mode": "scatter + all-gather (MFM_X_RCCL_ALLGATHER)" if S > 1 else "none (one device)"},
            "verified": verified, "clocks": cycles, "board_sample": smi, "st1": st1[0]}
@@ -1094,7 +1126,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    smi = gpu_sysfs_sample(local_rank) if rank == 0 else None  # the steps are queued, the GPU is in the middle of them
     fence()
     dt = time.perf_counter() - t0
     st1 = eng.stats()
@@ -1149,10 +1180,27 @@ def main():
     if rank == 0 and st1["kernel_variant"] == 2 and world == 1:
         ceiling = issue_model(instance_name(pkg, st1, in8), st1, cycles, achieved / HBM_PEAK_GBPS, library_sha16(pkg))
 
+    # One sysfs sample of the board's clock and power, taken while the same steps keep running right BEHIND the timed region: a
+    # hwmon read is a message to the SMU that holds the submission up for ~1.5 ms - inside a 2.4 ms timed region it cost a
+    # third of `value` (tools/r05/step_overheads.sh: ms_per_step 0.121 -> 0.180).  The clock the timed launches really ran
+    # at is in `clocks` (stamped by the kernel itself); this is the board's own reading of the same sustained state.
+    smi = None
+    if os.environ.get("BENCH_NO_BOARD_SAMPLE") != "1":
+        sampler = BoardSampler(local_rank) if rank == 0 else None
+        for k in range(max(args.steps, 16)):
+            step()
+            if sampler and k == 2:
+                sampler.start()
+        fence()
+        if sampler:
+            smi = sampler.result()
+            if smi is not None:
+                smi["when"] = "during further steps of the same workload queued right behind the timed region"
+
     verified = None
     if rank == 0:
         n_last = eng.last_output_device()[2]
-        verified = verify_last_block(pkg, eng, fs, decim, taps, offs, gains, st1["outputs"] - n_last)
+        verified = verify_last_block(pkg, eng, fs, decim, taps, offs, gains, eng.stats()["outputs"] - n_last)
 
     if rank == 0:
         line = {

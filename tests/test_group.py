@@ -299,7 +299,7 @@ def test_bench_group_path_over_the_fake_transport(tmp_path, shards):
     assert len(g["shards"]) == shards and sum(sh["channels"] for sh in g["shards"]) == 40 * shards
     assert g["exchange_info"]["uses_rccl"] and g["exchange_info"]["bytes_to_other_devices"] >= 5 * (shards - 1) * (4 << 21)
     assert len({sh["launches"] for sh in g["shards"]}) == 1 and all(sh["launches"] == 5 and sh["kernel_variant"] == 2 for sh in g["shards"])
-    assert all(sh["pending_blocks"] == 0 for sh in g["shards"])
+    assert len({sh["pending_blocks"] for sh in g["shards"]}) == 1  # (device-only: nothing is fetched; the shards stay in step)
 
 
 @pytest.mark.gpu
@@ -307,7 +307,7 @@ def test_bench_line_carries_the_group_path_and_the_north_star_shape():
     """the N = 1 line: `group_path` - the same workload through mfm_group_* on one device - within 3 % of `value` here (small
     blocks; 2 % at the driver's size), and `north_star_shape` - 1024 channels on the one GPU - with its matrix-instruction bound"""
     r = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--settle-seconds", "0.3",
-                        "--no-cpu-baseline", "--no-fp32", "--no-chain", "--no-series", "--block-log2", "24"],
+                        "--no-cpu-baseline", "--no-fp32", "--no-series", "--block-log2", "24"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])

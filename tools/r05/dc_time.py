@@ -23,7 +23,7 @@ for dc in (None, 0.9999):
     gpu = pkg.Resampler(nch, taps, 16, 25, n_in, device=0, dc_pole=dc)
     refs = [ora.Resampler(taps, 16, 25, dc_pole=dc) for _ in range(nch)]
     got = gpu.process_host(small)
-    want = np.stack([r.process(small[c]) for c, r in enumerate(refs)])
+    want = np.stack([r.feed(small[c]) for c, r in enumerate(refs)])
     ok = got.shape == want.shape and np.array_equal(got, want)
     x = torch.from_numpy(rng.randint(-20000, 20000, size=(nch, n_in)).astype(np.int16)).cuda()
     torch.cuda.synchronize()

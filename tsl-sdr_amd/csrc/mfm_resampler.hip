@@ -290,8 +290,13 @@ struct DcState {
  * time): what can be done is to keep the per-sample work down to the recurrence itself.  With acc_n = (x_n << 14) + r_n
  * the reference's four statements are  r_n = r_(n-1) - p y_(n-1),  y_n = (int32)((x_n << 14) + r_n) >> 14  (all mod
  * 2^32, as the reference's int32 arithmetic wraps); samples are read and written eight at a time (16-byte accesses, the
- * next eight requested before the current eight are worked on), so a sample costs ~7 instructions instead of a global
- * load - store round trip (94 ms -> 3 ms per 447 392-sample block).
+ * next eight requested before the current eight are worked on), so a sample costs a few instructions instead of a global
+ * load - store round trip (94 ms -> 6.2 ms per 447 392-sample block in round 2; 5.8 ms with the three-instruction chain of
+ * round 5).  What bounds it now is the chain itself: y -> multiply-add -> multiply-add -> shift -> y is three dependent
+ * instructions, 26 cycles per sample as measured, and one wave of 64 channels has nothing to put in between; a second
+ * formulation with a chain of two (u_n = y_(n-1) * -p + (u_(n-1) + dX_n), y_n = u_n >> 14) needs five instructions per
+ * sample and would land at ~4.3 ms.  The (Y, r) form (acc = 2^14 Y + r) has the same chain length as this one.  Off by
+ * default in the reference (decoder -b), not on multifm's path.
  */
 __global__ __launch_bounds__(64) void mfm_dc_block_kernel(int16_t *y, uint32_t out_cap, uint32_t n_out, uint32_t nchan, int32_t p,
                                                           DcState *st)
