@@ -688,6 +688,47 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
                          "outputs_per_channel": int(outs)}
         except Exception as e:  # a side line must never take the headline down
             out[mode] = {"error": repr(e)}
+    # what the C host's submit thread does with a backlog since round 5: the pool hands its frames out in address order, so
+    # buffers delivered one after the other are neighbours in the slab and go to the device as ONE strided copy command per run
+    # (mfm_group_push_pinned_run).  An arena laid out like the pool (64 bytes of sample_buf header between the data of two
+    # frames), the producer loop in C (mfm_group_replay_arena); RTL-SDR-sized and file_if-sized buffers.
+    for bs, nb, runs in ((buf_samples, nr_bufs, (1, 16, 64)), (4096, 32 * nr_bufs, (1, 64))):
+        stride = 64 + bs * 4
+        frames = 128 if bs == buf_samples else 2048
+        arena = lib0.mfm_host_alloc(frames * stride)
+        if not arena:
+            continue
+        for k in range(frames):
+            ctypes.memmove(arena + k * stride + 64, data[k & 7].ctypes.data, bs * 4)
+        for mr in runs:
+            mode = f"c_loop_pool_arena_{bs}_sample_buffers_runs_of_up_to_{mr}"
+            try:
+                grp = b.Group(fs, decim, bs, devices=(0,), coalesce_samples=128 * buf_samples)
+                for o, g in zip(offs, gains):
+                    grp.add_channel(int(o), taps, float(g))
+                grp.commit()
+                got, cmds = ctypes.c_uint64(), ctypes.c_uint64()
+
+                def run_arena(n):
+                    rc = grp.lib.mfm_group_replay_arena(grp.h, ctypes.c_void_p(arena + 64), stride, frames, bs, b.MFM_IN_CS16, n, mr,
+                                                        ctypes.byref(got), ctypes.byref(cmds))
+                    if rc != 0:
+                        raise RuntimeError(f"mfm_group_replay_arena: {rc} {grp.lib.mfm_last_error()}")
+                run_arena(max(64, nb // 8))
+                st0 = grp.stats(0)
+                t0 = time.perf_counter()
+                run_arena(nb)
+                dt = time.perf_counter() - t0
+                st1 = grp.stats(0)
+                grp.close()
+                n_in = nb * bs
+                out[mode] = {"launches": st1["launches"] - st0["launches"], "copy_commands": int(cmds.value), "buffers": nb,
+                             "input_msamp_per_s": n_in / dt / 1e6, "value": n_in * nch / dt / 1e6, "unit": "MSamp/s x channels",
+                             "us_per_buffer": dt / nb * 1e6, "h2d_GBps": n_in * 4 / dt / 1e9,
+                             "d2h_GBps": got.value * nch * 2 / dt / 1e9, "outputs_per_channel": int(got.value)}
+            except Exception as e:
+                out[mode] = {"error": repr(e)}
+        lib0.mfm_host_free(arena)
     # the link by itself, for what the figures above are to be read against: bare hipMemcpyAsync out of one page-locked arena
     # in pieces of one sample_buf (512 KiB) and of 64 MiB, with the PCM's share of bytes coming back on a second stream
     try:
@@ -700,10 +741,16 @@ def end_to_end(pkg, fs, decim, taps, offs, gains, buf_samples=131072, nr_bufs=40
             h2, d2 = ctypes.c_double(), ctypes.c_double()
             rc = lib0.mfm_link_probe(0, piece, 2 << 30, 0.0, ctypes.byref(h2), ctypes.byref(d2))
             link[name]["h2d_alone_GBps"] = h2.value if rc == 0 else None
-        best = out.get("c_loop_pinned_pool_coalesced_128_buffers", {}).get("h2d_GBps")
-        if best and "h2d_GBps" in link["pieces_512KiB"]:
-            link["end_to_end_over_link_512KiB"] = best / link["pieces_512KiB"]["h2d_GBps"]
-            link["end_to_end_over_link_64MiB"] = best / link["pieces_64MiB"]["h2d_GBps"]
+        h, d = ctypes.c_double(), ctypes.c_double()
+        rc = lib0.mfm_link_probe_runs(0, buf_samples * 4, 64, 16, 2 << 30, back, ctypes.byref(h), ctypes.byref(d))
+        link["pieces_512KiB_runs_of_16_strided"] = {"h2d_GBps": h.value, "d2h_GBps": d.value} if rc == 0 else {"error": rc}
+        per_buf = out.get("c_loop_pinned_pool_coalesced_128_buffers", {}).get("h2d_GBps")
+        runs16 = out.get(f"c_loop_pool_arena_{buf_samples}_sample_buffers_runs_of_up_to_16", {}).get("h2d_GBps")
+        if per_buf and "h2d_GBps" in link["pieces_512KiB"]:
+            link["end_to_end_one_command_per_buffer_over_link_512KiB"] = per_buf / link["pieces_512KiB"]["h2d_GBps"]
+        if runs16 and "h2d_GBps" in link["pieces_64MiB"]:
+            link["end_to_end_runs_of_16_over_link_64MiB"] = runs16 / link["pieces_64MiB"]["h2d_GBps"]
+            link["end_to_end_runs_of_16_over_link_strided_runs"] = runs16 / max(1e-9, link["pieces_512KiB_runs_of_16_strided"].get("h2d_GBps", 0.0))
         out["link"] = link
     except Exception as e:
         out["link"] = {"error": repr(e)}

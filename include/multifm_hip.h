@@ -234,6 +234,11 @@ void *mfm_host_alloc(size_t bytes); /* page-locked host memory (hipHostMalloc); 
  * sample_buf), while d2h_per_h2d bytes per input byte come back on a second stream (the PCM mirror; 0: none).  Rates in
  * GB/s over the second of two passes. */
 int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2h_per_h2d, double *h2d_GBps, double *d2h_GBps);
+/* the same with the pieces gap_bytes apart in the arena (a sample_buf's header between the data of two frames) and
+ * pieces_per_command of them per copy command - one strided hipMemcpy2DAsync that packs them on the device, what
+ * mfm_engine_push_pinned_run() issues for a run of adjacent frames */
+int mfm_link_probe_runs(int device, size_t piece_bytes, size_t gap_bytes, size_t pieces_per_command, size_t total_bytes,
+                        double d2h_per_h2d, double *h2d_GBps, double *d2h_GBps);
 void mfm_host_free(void *p);
 int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_samples, int format, uint64_t *ticket);
 int mfm_engine_copy_done(struct mfm_engine *e, uint64_t ticket); /* 1: read, 0: not yet, < 0: error */
@@ -370,6 +375,20 @@ struct mfm_engine *mfm_group_shard_engine(struct mfm_group *g, uint32_t shard);
 int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int format);
 /* the same out of page-locked memory (mfm_host_alloc), without the staging copy: as mfm_engine_push_pinned() */
 int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_samples, int format, uint64_t *ticket);
+/* A RUN of page-locked buffers of nr_samples_each samples that lie stride_bytes apart in one arena - a pool that hands its
+ * frames out in address order delivers neighbours one after the other (host/mfm_tsl.c frame_alloc, host/mfm_receiver.c) - goes
+ * to the device as ONE strided copy command and is accepted as one block.  One command per 512 KiB sample_buf runs at half the
+ * link's rate, one per 16 KiB file_if buffer at a ninth (bench.py end_to_end.link).  *accepted (>= 1 on MFM_OK) = how many
+ * buffers of the run were taken: fewer than `count` when less fits the buffer being filled or the gathering policy would have
+ * launched in between; the caller offers the rest again.  One ticket covers the accepted buffers. */
+int mfm_engine_push_pinned_run(struct mfm_engine *e, const void *first, size_t stride_bytes, size_t nr_samples_each, size_t count,
+                               int format, uint64_t *ticket, size_t *accepted);
+int mfm_group_push_pinned_run(struct mfm_group *g, const void *first, size_t stride_bytes, size_t nr_samples_each, size_t count,
+                              int format, uint64_t *ticket, size_t *accepted);
+size_t mfm_engine_input_room(struct mfm_engine *e); /* samples the buffer being filled still takes */
+/* mfm_group_replay_pinned() over one arena of buffers stride_bytes apart, in runs of up to max_run neighbours (measurements) */
+int mfm_group_replay_arena(struct mfm_group *g, const void *arena, size_t stride_bytes, size_t nr_bufs, size_t buf_samples, int format,
+                           size_t nr_pushes, size_t max_run, uint64_t *outputs_per_channel, uint64_t *copy_commands);
 int mfm_group_copy_done(struct mfm_group *g, uint64_t ticket);
 /* A host loop in C, for measurements (bench.py end_to_end): nr_pushes buffers of buf_samples samples, taken in turn from the
  * caller's nr_bufs page-locked buffers, pushed with mfm_group_push_pinned(); blocks are fetched and released whenever the

@@ -66,6 +66,30 @@ int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_sampl
     }
     return rc;
 }
+/* a run of neighbouring buffers: the stand-in takes up to three of them at a time (so that "fewer than offered" is exercised) */
+int mfm_group_push_pinned_run(struct mfm_group *g, const void *first, size_t stride_bytes, size_t nr_samples_each, size_t count,
+                              int format, uint64_t *ticket, size_t *accepted)
+{
+    size_t k = count > 3 ? 3 : count;
+    (void)stride_bytes;
+    if (accepted) {
+        *accepted = 0;
+    }
+    if (g_busy) {
+        g_busy_returns++;
+        return MFM_E_BUSY;
+    }
+    for (size_t i = 0; i < k; i++) {
+        (void)mfm_group_push(g, first, nr_samples_each, format);
+    }
+    if (ticket) {
+        *ticket = ++g_tickets;
+    }
+    if (accepted) {
+        *accepted = k;
+    }
+    return MFM_OK;
+}
 int mfm_group_copy_done(struct mfm_group *g, uint64_t ticket) { (void)g, (void)ticket; return 1; }
 int mfm_group_copy_wait(struct mfm_group *g, uint64_t ticket) { (void)g, (void)ticket; return MFM_OK; }
 void *mfm_host_alloc(size_t bytes) { void *p = NULL; return 0 == posix_memalign(&p, 64, bytes) ? p : NULL; }

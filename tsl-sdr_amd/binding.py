@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "mfm_engine_acquire_input_bytes",
     "mfm_engine_submit", "mfm_engine_push", "mfm_engine_push_bytes", "mfm_engine_fetch", "mfm_engine_release",
     "mfm_engine_last_output_device", "mfm_engine_sync", "mfm_engine_reset", "mfm_engine_get_stats",
-    "mfm_engine_stream", "mfm_engine_get_launch_ms", "mfm_engine_get_launch_cycles", "mfm_group_acquire_input", "mfm_group_submit", "mfm_group_shard_engine", "mfm_link_probe", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
+    "mfm_engine_stream", "mfm_engine_get_launch_ms", "mfm_engine_get_launch_cycles", "mfm_group_acquire_input", "mfm_group_submit", "mfm_group_shard_engine", "mfm_link_probe", "mfm_link_probe_runs", "mfm_engine_push_pinned_run", "mfm_group_push_pinned_run", "mfm_engine_input_room", "mfm_group_replay_arena", "mfm_strerror", "mfm_last_error", "mfm_hosttwin_discriminate", "mfm_hosttwin_discriminate_batch", "mfm_hosttwin_r14",
     "mfm_hosttwin_pcm_range", "mfm_hosttwin_atan_table", "mfm_hosttwin_atan_table_ok",
     "mfm_resampler_create", "mfm_resampler_destroy", "mfm_resampler_max_out", "mfm_resampler_process_device",
     "mfm_resampler_process_host", "mfm_resampler_process_host_to_device",
@@ -230,6 +230,14 @@ def load_library():
     lib.mfm_group_shard_engine.argtypes = [vp, C.c_uint32]
     lib.mfm_group_shard_engine.restype = vp
     lib.mfm_link_probe.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mfm_engine_push_pinned_run.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    lib.mfm_group_push_pinned_run.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    lib.mfm_engine_input_room.argtypes = [vp]
+    lib.mfm_engine_input_room.restype = C.c_size_t
+    lib.mfm_group_replay_arena.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64)]
+    lib.mfm_link_probe_runs.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double)]
     lib.mfm_engine_get_launch_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
     lib.mfm_engine_get_launch_ms.restype = C.c_size_t
     lib.mfm_engine_get_launch_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]

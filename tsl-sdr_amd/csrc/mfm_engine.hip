@@ -1970,7 +1970,15 @@ int mfm_engine_acquire_input_bytes(struct mfm_engine *e, int format, void **d_ds
 
 /* mode: MFM_SUBMIT_AUTO - the engine decides whether the buffer is launched now (mfm_engine_config::coalesce_samples);
  * _DEFER / _LAUNCH - a device group has decided for all its shards (mfm_engine_internal.h) */
+static int submit_impl(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer, int mode, bool run);
+
 int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer, int mode)
+{
+    return submit_impl(e, nr_samples, producer_stream, wait_producer, mode, false);
+}
+
+/* run: several blocks of at most max_block_samples each, staged next to each other, accepted as one (mfm_engine_push_pinned_run) */
+static int submit_impl(struct mfm_engine *e, size_t nr_samples, void *producer_stream, int wait_producer, int mode, bool run)
 {
     if (!e) {
         return fail(MFM_E_INVAL, "NULL engine");
@@ -1982,7 +1990,7 @@ int mfm_engine_submit_mode(struct mfm_engine *e, size_t nr_samples, void *produc
         /* receiver_sample_buf_deliver() treats an empty buffer as a bug (receiver.c:84) */
         return fail(MFM_E_INVAL, "empty block");
     }
-    if (nr_samples > (size_t)e->cap_in - e->hist - e->tail - e->pend || nr_samples > e->cfg.max_block_samples) {
+    if (nr_samples > (size_t)e->cap_in - e->hist - e->tail - e->pend || (!run && nr_samples > e->cfg.max_block_samples)) {
         return fail(MFM_E_INVAL, "block of %zu samples exceeds max_block_samples %u", nr_samples,
                     e->cfg.max_block_samples);
     }
@@ -2241,16 +2249,113 @@ int mfm_engine_push_pinned(struct mfm_engine *e, const void *data, size_t nr_sam
     return mfm_engine_submit(e, nr_samples, e->s_in, 1);
 }
 
+size_t mfm_engine_input_room(struct mfm_engine *e)
+{
+    if (!e || !e->committed) {
+        return 0;
+    }
+    std::lock_guard<std::mutex> guard(e->mu);
+    return (size_t)e->cap_in - e->hist - e->tail - e->pend;
+}
+
+/*
+ * A run of `count` page-locked buffers of nr_samples_each samples that lie stride_bytes apart (the receiver's pool hands its
+ * frames out in address order, so buffers delivered one after the other are neighbours in the arena): ONE strided copy command
+ * packs them into the input buffer, and they are accepted as one block.  A copy command per 512 KiB sample_buf runs at half the
+ * link's rate, one per 16 KiB file_if buffer at a ninth (bench.py end_to_end.link).  *accepted = how many of the buffers were
+ * taken - fewer than `count` when the buffer being filled has less room, 1 where a block has to be widened on the device.
+ */
+int mfm_engine_push_pinned_run(struct mfm_engine *e, const void *first, size_t stride_bytes, size_t nr_samples_each, size_t count,
+                               int format, uint64_t *ticket, size_t *accepted)
+{
+    if (accepted) {
+        *accepted = 0;
+    }
+    if (!e || !first || 0 == count || 0 == nr_samples_each) {
+        return fail(MFM_E_INVAL, "NULL or empty run");
+    }
+    if (!e->committed) {
+        return fail(MFM_E_STATE, "commit first");
+    }
+    const size_t bps = (format == MFM_IN_CS16) ? 4u : 2u;
+    if (nr_samples_each > e->cfg.max_block_samples || stride_bytes < nr_samples_each * bps) {
+        return fail(MFM_E_INVAL, "run of blocks of %zu samples, %zu bytes apart (max block %u)", nr_samples_each, stride_bytes,
+                    e->cfg.max_block_samples);
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const bool raw = format != MFM_IN_CS16 && mfm_engine_can_take_bytes(e, format, nr_samples_each);
+    size_t k = count;
+    if (format != MFM_IN_CS16 && !raw) {
+        k = 1; /* widened on the device through a scratch buffer: one block at a time */
+    }
+    if (k > 1) {
+        /* what is there of another format goes out first (then the room is that of an empty buffer) */
+        const int rcf = flush_for_format(e, raw ? format : MFM_IN_CS16);
+        if (rcf != MFM_OK) {
+            return rcf;
+        }
+        const size_t room = mfm_engine_input_room(e);
+        k = std::min(k, room / nr_samples_each);
+        /* a run must not gather past the point where the engine would have launched: what is gathered plus the run stays
+         * within coalesce_samples + one block */
+        const size_t co = e->cfg.coalesce_samples;
+        if (co) {
+            const size_t pend = (size_t)mfm_engine_pending_samples(e);
+            const size_t until = co > pend ? (co - pend + nr_samples_each - 1u) / nr_samples_each : 1u;
+            k = std::min(k, std::max<size_t>(until, 1u));
+        } else {
+            k = 1; /* no gathering: every buffer is a launch of its own */
+        }
+    }
+    if (k <= 1) {
+        const int rc = mfm_engine_push_pinned(e, first, nr_samples_each, format, ticket);
+        if (rc == MFM_OK && accepted) {
+            *accepted = 1;
+        }
+        return rc;
+    }
+    const size_t total = nr_samples_each * k;
+    int rc = check_output_room(e, total);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    void *dst = nullptr;
+    size_t cap = 0;
+    rc = raw ? mfm_engine_acquire_input_bytes(e, format, &dst, &cap) : mfm_engine_acquire_input(e, &dst, &cap);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    HIP_TRY(hipMemcpy2DAsync(dst, nr_samples_each * bps, first, stride_bytes, nr_samples_each * bps, k, hipMemcpyHostToDevice, e->s_in));
+    e->copy_seq++; /* one ticket for the run: its copy is one command */
+    if (ticket) {
+        *ticket = e->copy_seq;
+    }
+    rc = submit_impl(e, total, e->s_in, 1, MFM_SUBMIT_AUTO, true);
+    if (rc == MFM_OK && accepted) {
+        *accepted = k;
+    }
+    return rc;
+}
+
 /* The host <-> device link by itself (include/multifm_hip.h): what a host-fed figure is to be read against. */
 int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2h_per_h2d, double *h2d_GBps, double *d2h_GBps)
 {
-    if (0 == piece_bytes || total_bytes < piece_bytes || d2h_per_h2d < 0.0 || d2h_per_h2d > 4.0) {
+    return mfm_link_probe_runs(device, piece_bytes, 0, 1, total_bytes, d2h_per_h2d, h2d_GBps, d2h_GBps);
+}
+
+int mfm_link_probe_runs(int device, size_t piece_bytes, size_t gap_bytes, size_t pieces_per_command, size_t total_bytes,
+                        double d2h_per_h2d, double *h2d_GBps, double *d2h_GBps)
+{
+    if (0 == piece_bytes || total_bytes < piece_bytes || d2h_per_h2d < 0.0 || d2h_per_h2d > 4.0 || 0 == pieces_per_command) {
         return fail(MFM_E_INVAL, "piece / total bytes, or the D2H share");
     }
     HIP_TRY(hipSetDevice(device));
-    /* one arena of page-locked memory cut into pieces, like the receiver's sample_buf pool (host/mfm_receiver.c) */
-    const size_t arena = std::min<size_t>(total_bytes, (size_t)64 << 20) / piece_bytes * piece_bytes;
-    const size_t pieces_in_arena = arena / piece_bytes;
+    /* one arena of page-locked memory cut into pieces (gap_bytes apart: a sample_buf's header sits between the data of two
+     * frames), like the receiver's sample_buf pool (host/mfm_receiver.c) */
+    const size_t stride = piece_bytes + gap_bytes;
+    size_t pieces_in_arena = std::max<size_t>(std::min<size_t>(total_bytes, (size_t)64 << 20) / stride, pieces_per_command);
+    pieces_in_arena = pieces_in_arena / pieces_per_command * pieces_per_command;
+    const size_t arena = pieces_in_arena * stride;
     const size_t back_piece = (size_t)((double)piece_bytes * d2h_per_h2d) & ~(size_t)15;
     uint8_t *h_src = nullptr, *h_dst = nullptr, *d_in = nullptr, *d_out = nullptr;
     hipStream_t s_in = nullptr, s_out = nullptr;
@@ -2258,7 +2363,7 @@ int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2
     int rc = MFM_OK;
     auto body = [&]() -> int {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_src), arena, hipHostMallocDefault));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), arena));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_in), pieces_in_arena * piece_bytes));
         memset(h_src, 0x5a, arena);
         if (back_piece) {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_dst), back_piece * pieces_in_arena, hipHostMallocDefault));
@@ -2275,11 +2380,18 @@ int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2
         for (int pass = 0; pass < 2; pass++) { /* the first pass warms the mappings up */
             HIP_TRY(hipEventRecord(e0, s_in));
             HIP_TRY(hipEventRecord(f0, s_out));
-            for (size_t i = 0; i < n; i++) {
+            for (size_t i = 0; i + pieces_per_command <= n; i += pieces_per_command) {
                 const size_t k = i % pieces_in_arena;
-                HIP_TRY(hipMemcpyAsync(d_in + k * piece_bytes, h_src + k * piece_bytes, piece_bytes, hipMemcpyHostToDevice, s_in));
+                if (1 == pieces_per_command) {
+                    HIP_TRY(hipMemcpyAsync(d_in + k * piece_bytes, h_src + k * stride, piece_bytes, hipMemcpyHostToDevice, s_in));
+                } else {
+                    /* a run of frames that lie next to each other in the arena: ONE strided command, packed on the device */
+                    HIP_TRY(hipMemcpy2DAsync(d_in + k * piece_bytes, piece_bytes, h_src + k * stride, stride, piece_bytes,
+                                             pieces_per_command, hipMemcpyHostToDevice, s_in));
+                }
                 if (back_piece) {
-                    HIP_TRY(hipMemcpyAsync(h_dst + k * back_piece, d_out + k * back_piece, back_piece, hipMemcpyDeviceToHost, s_out));
+                    HIP_TRY(hipMemcpyAsync(h_dst + k * back_piece, d_out + k * back_piece, back_piece * pieces_per_command,
+                                           hipMemcpyDeviceToHost, s_out));
                 }
             }
             HIP_TRY(hipEventRecord(e1, s_in));
@@ -2290,11 +2402,12 @@ int mfm_link_probe(int device, size_t piece_bytes, size_t total_bytes, double d2
         float ms_in = 0.0f, ms_out = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms_in, e0, e1));
         HIP_TRY(hipEventElapsedTime(&ms_out, f0, f1));
+        const size_t done = n / pieces_per_command * pieces_per_command;
         if (h2d_GBps) {
-            *h2d_GBps = (double)(n * piece_bytes) / ((double)ms_in * 1e6);
+            *h2d_GBps = (double)(done * piece_bytes) / ((double)ms_in * 1e6);
         }
         if (d2h_GBps) {
-            *d2h_GBps = back_piece ? (double)(n * back_piece) / ((double)ms_out * 1e6) : 0.0;
+            *d2h_GBps = back_piece ? (double)(done * back_piece) / ((double)ms_out * 1e6) : 0.0;
         }
         return MFM_OK;
     };

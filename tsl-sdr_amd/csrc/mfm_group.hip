@@ -547,6 +547,92 @@ int mfm_group_push_pinned(struct mfm_group *g, const void *data, size_t nr_sampl
     return rc;
 }
 
+/* a run of page-locked buffers that lie stride_bytes apart (mfm_engine_push_pinned_run): one copy command on a group of one
+ * device; a group that exchanges takes the first buffer of the run the usual way (*accepted = 1) */
+int mfm_group_push_pinned_run(struct mfm_group *g, const void *first, size_t stride_bytes, size_t nr_samples_each, size_t count,
+                              int format, uint64_t *ticket, size_t *accepted)
+{
+    if (accepted) {
+        *accepted = 0;
+    }
+    if (!g || !first || 0 == count) {
+        return gfail(MFM_E_INVAL, "NULL or empty run");
+    }
+    if (!g->committed) {
+        return gfail(MFM_E_STATE, "commit first");
+    }
+    if (!g->exchange) {
+        return mfm_engine_push_pinned_run(g->eng[0], first, stride_bytes, nr_samples_each, count, format, ticket, accepted);
+    }
+    const int rc = mfm_group_push_pinned(g, first, nr_samples_each, format, ticket);
+    if (rc == MFM_OK && accepted) {
+        *accepted = 1;
+    }
+    return rc;
+}
+
+/* the producer loop of mfm_group_replay_pinned() over ONE arena of nr_bufs buffers stride_bytes apart, handing the group runs of
+ * up to max_run neighbours at a time (what host/mfm_receiver.c's submit thread does with a backlog) */
+int mfm_group_replay_arena(struct mfm_group *g, const void *arena, size_t stride_bytes, size_t nr_bufs, size_t buf_samples, int format,
+                           size_t nr_pushes, size_t max_run, uint64_t *outputs_per_channel, uint64_t *copy_commands)
+{
+    if (!g || !arena || 0 == nr_bufs || 0 == max_run || !g->committed) {
+        return gfail(MFM_E_INVAL, "bad argument");
+    }
+    std::vector<mfm_block> blks(g->eng.size());
+    uint64_t outs = 0, cmds = 0;
+    auto drain_one = [&]() -> int {
+        const int rc = mfm_group_fetch(g, blks.data());
+        if (rc != MFM_OK) {
+            return rc;
+        }
+        outs += blks[0].nr_outputs;
+        return mfm_group_release(g);
+    };
+    size_t i = 0;
+    while (i < nr_pushes) {
+        const size_t at = i % nr_bufs;
+        const size_t want = std::min(std::min(max_run, nr_bufs - at), nr_pushes - i); /* neighbours up to the arena's end */
+        size_t took = 0;
+        const int rc = mfm_group_push_pinned_run(g, static_cast<const uint8_t *>(arena) + at * stride_bytes, stride_bytes, buf_samples,
+                                                 want, format, nullptr, &took);
+        if (rc == MFM_OK) {
+            i += took;
+            cmds++;
+            continue;
+        }
+        if (rc != MFM_E_BUSY) {
+            return rc;
+        }
+        const int dr = drain_one();
+        if (dr != MFM_OK) {
+            return dr == MFM_E_DONE ? gfail(MFM_E_STATE, "output rings full and nothing to fetch") : dr;
+        }
+    }
+    for (;;) {
+        const int frc = mfm_group_flush(g);
+        if (frc != MFM_OK && frc != MFM_E_BUSY) {
+            return frc;
+        }
+        int dr;
+        while ((dr = drain_one()) == MFM_OK) {
+        }
+        if (dr != MFM_E_DONE) {
+            return dr;
+        }
+        if (frc == MFM_OK) {
+            break;
+        }
+    }
+    if (outputs_per_channel) {
+        *outputs_per_channel = outs;
+    }
+    if (copy_commands) {
+        *copy_commands = cmds;
+    }
+    return MFM_OK;
+}
+
 /* A host loop in C, for measurements: nr_pushes buffers of buf_samples samples each, taken in turn from the caller's nr_bufs
  * page-locked buffers, through mfm_group_push_pinned(); whenever a push finds the output rings full a block is fetched and
  * released (its PCM has reached host memory by then), and at the end everything is flushed and drained.  What this repo's C

@@ -57,6 +57,7 @@ static void _bell_sleep(struct mfm_doorbell *b, unsigned max_ms)
     atomic_store(&b->sleeping, 0);
 }
 
+#define MFM_RUN_MAX 64u /* buffers per strided copy command, at most (16 reach 94 % of the link's rate, bench.py end_to_end.link) */
 #define MFM_IDLE_MS 50u /* how long a thread sleeps at most before it looks at its run flag again */
 
 /* ---- sample buffers ---- */
@@ -367,17 +368,34 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
             continue;
         }
         struct sample_buf *buf = rx->ring[tail % rx->ring_slots]; /* the load of ring_head above acquired it */
+        size_t run = 1;
         if (!rx->failed) {
+            /* a backlog: how many of the buffers behind this one are its neighbours in the pool's slab (the pool hands frames out
+             * in address order), with as many samples and the same format - they go to the device as one strided copy command */
+            const size_t have = rx->ring_head - tail;
+            while (run < have && run < MFM_RUN_MAX) {
+                const struct sample_buf *nb = rx->ring[(tail + run) % rx->ring_slots];
+                if ((const uint8_t *)nb != (const uint8_t *)buf + run * rx->frame_stride || nb->nr_samples != buf->nr_samples ||
+                    nb->sample_type != buf->sample_type) {
+                    break;
+                }
+                run++;
+            }
             for (;;) {
                 /* armed before the attempt: a slot released between a refused push and the sleep still rings */
                 _bell_arm(&rx->room_bell);
                 uint64_t ticket = 0;
-                const int rc = mfm_group_push_pinned(rx->group, buf->data_buf, buf->nr_samples, _format_of(buf), &ticket);
+                size_t took = 0;
+                const int rc = mfm_group_push_pinned_run(rx->group, buf->data_buf, rx->frame_stride, buf->nr_samples, run, _format_of(buf),
+                                                         &ticket, &took);
                 if (MFM_OK == rc) {
-                    rx->copying[rx->copy_head % rx->ring_slots] = buf;
-                    rx->copy_ticket[rx->copy_head % rx->ring_slots] = ticket;
-                    rx->copy_head++;
-                    buf = NULL; /* the copy engine is reading it: _receiver_reap_copies() returns it to the pool */
+                    for (size_t k = 0; k < took; k++) {
+                        rx->copying[rx->copy_head % rx->ring_slots] = rx->ring[(tail + k) % rx->ring_slots];
+                        rx->copy_ticket[rx->copy_head % rx->ring_slots] = ticket;
+                        rx->copy_head++;
+                    }
+                    run = took;
+                    buf = NULL; /* the copy engine is reading them: _receiver_reap_copies() returns them to the pool */
                 }
                 if (MFM_E_BUSY == rc && !rx->failed) {
                     /* every output slot holds a block the drain thread has not written out yet */
@@ -393,13 +411,15 @@ static aresult_t _receiver_submit_thread(struct worker_thread *wthr)
                 break;
             }
         }
-        rx->ring_tail = tail + 1;
-        rx->nr_bufs_submitted++;
-        _bell_ring(&rx->block_bell);
-        _bell_ring(&rx->idle_bell);
         if (NULL != buf) {
+            run = 1;
             TSL_BUG_IF_FAILED(sample_buf_decref(buf)); /* not handed over (a failed receiver): back to the pool */
         }
+        rx->ring_tail = tail + run;
+        rx->nr_bufs_submitted += run;
+        rx->nr_copy_commands++;
+        _bell_ring(&rx->block_bell);
+        _bell_ring(&rx->idle_bell);
     }
     _receiver_reap_copies(rx, true);
     return rx->failed ? A_E_DEVICE : A_OK;
@@ -718,6 +738,8 @@ static void _receiver_zero(struct receiver *rx, receiver_rx_thread_func_t rx_fun
     atomic_store(&rx->failed, 0);
     atomic_store(&rx->nr_bufs_delivered, 0);
     atomic_store(&rx->nr_bufs_submitted, 0);
+    atomic_store(&rx->nr_copy_commands, 0);
+    rx->frame_stride = 0;
     atomic_store(&rx->max_deliver_ns, 0);
     list_init(&rx->demod_threads);
     _bell_init(&rx->ring_bell);
@@ -790,6 +812,7 @@ aresult_t receiver_init(struct receiver *rx, struct config *cfg, receiver_rx_thr
             st.group.devices[0], st.group.exchange == MFM_X_RCCL ? " (RCCL exchange forced)" :
             st.group.exchange == MFM_X_RCCL_ALLGATHER ? " (RCCL scatter + all-gather exchange)" : "");
     rx->ring_slots = (size_t)st.nr_samp_bufs;
+    rx->frame_stride = frame_alloc_frame_bytes(rx->samp_alloc);
     if (FAILED(ret = TACALLOC(&rx->ring, rx->ring_slots, sizeof(*rx->ring), SYS_CACHE_LINE_LENGTH)) ||
         FAILED(ret = TACALLOC(&rx->copying, rx->ring_slots, sizeof(*rx->copying), SYS_CACHE_LINE_LENGTH)) ||
         FAILED(ret = TACALLOC(&rx->copy_ticket, rx->ring_slots, sizeof(*rx->copy_ticket), SYS_CACHE_LINE_LENGTH))) {
@@ -944,6 +967,11 @@ aresult_t receiver_cleanup(struct receiver **prx)
         TSL_BUG_IF_FAILED(worker_thread_delete(&rx->drain_thr));
     }
 
+    if (rx->nr_bufs_submitted) {
+        MFM_MSG(SEV_INFO, "INGEST-SUMMARY", "%zu sample buffers delivered, %zu submitted in %zu copy commands, %zu dropped at the pool, "
+                "%zu blocks written out", (size_t)rx->nr_bufs_delivered, (size_t)rx->nr_bufs_submitted, (size_t)rx->nr_copy_commands,
+                (size_t)rx->nr_samp_buf_alloc_fails, (size_t)rx->nr_blocks_drained);
+    }
     _receiver_teardown(rx);
 
     /* from here on `rx` belongs to the front end */

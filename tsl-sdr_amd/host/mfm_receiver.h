@@ -115,6 +115,8 @@ struct receiver {
     struct sample_buf **ring;     /* delivered, not yet submitted buffers: single producer (front end), single
                                      consumer (submit thread); as many slots as the pool has frames, so it never fills */
     size_t ring_slots;
+    size_t frame_stride;          /* bytes between neighbouring sample_bufs of the pool's slab */
+    _Atomic size_t nr_copy_commands; /* H2D copy commands issued: fewer than buffers when runs of neighbours went as one */
     /* buffers handed to the device group and not yet read by its H2D copy (the pool is page-locked memory: the copy
      * engine reads data_buf where the front end wrote it).  Only the submit thread touches these. */
     struct sample_buf **copying;

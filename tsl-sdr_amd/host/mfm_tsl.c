@@ -151,13 +151,17 @@ void app_request_stop(void)
     app_stop_requested = 1;
 }
 
-/* ---- frame pool: nr_frames equally sized, 64-byte aligned frames on a lock-protected free stack ---- */
+/* ---- frame pool: nr_frames equally sized, 64-byte aligned frames of one slab on a lock-protected free QUEUE.  First in,
+ *      first out: frames are handed out in the order they came back, which - with one producer and buffers that return in
+ *      the order they were delivered - is address order, round and round the slab.  Buffers delivered one after the other
+ *      are then neighbours in memory, and the receiver copies runs of them to the device with one strided command
+ *      (mfm_group_push_pinned_run). ---- */
 
 struct frame_alloc {
     uint8_t *slab;
     void (*slab_free)(void *);
-    void **free_stack;
-    size_t frame_bytes, nr_frames, nr_free;
+    void **free_stack; /* ring of nr_frames slots: [head, head + nr_free) hold free frames */
+    size_t frame_bytes, nr_frames, nr_free, head;
     pthread_mutex_t lock;
 };
 
@@ -203,6 +207,7 @@ aresult_t frame_alloc_new_on(struct frame_alloc **pfa, size_t frame_bytes, size_
         fa->free_stack[i] = fa->slab + i * fa->frame_bytes;
     }
     fa->nr_free = nr_frames;
+    fa->head = 0;
     pthread_mutex_init(&fa->lock, NULL);
     *pfa = fa;
     return A_OK;
@@ -216,7 +221,9 @@ aresult_t frame_alloc(struct frame_alloc *fa, void **pframe)
     *pframe = NULL;
     pthread_mutex_lock(&fa->lock);
     if (fa->nr_free) {
-        *pframe = fa->free_stack[--fa->nr_free];
+        *pframe = fa->free_stack[fa->head];
+        fa->head = (fa->head + 1) % fa->nr_frames;
+        fa->nr_free--;
         ret = A_OK;
     }
     pthread_mutex_unlock(&fa->lock);
@@ -229,10 +236,16 @@ aresult_t frame_free(struct frame_alloc *fa, void **pframe)
     TSL_ASSERT_ARG(NULL != pframe && NULL != *pframe);
     pthread_mutex_lock(&fa->lock);
     TSL_BUG_ON(fa->nr_free == fa->nr_frames);
-    fa->free_stack[fa->nr_free++] = *pframe;
+    fa->free_stack[(fa->head + fa->nr_free) % fa->nr_frames] = *pframe;
+    fa->nr_free++;
     pthread_mutex_unlock(&fa->lock);
     *pframe = NULL;
     return A_OK;
+}
+
+size_t frame_alloc_frame_bytes(struct frame_alloc *fa)
+{
+    return fa->frame_bytes; /* bytes from one frame of the slab to the next */
 }
 
 size_t frame_alloc_nr_free(struct frame_alloc *fa)

@@ -245,5 +245,6 @@ aresult_t frame_alloc(struct frame_alloc *fa, void **pframe); /* A_E_NOMEM when 
 aresult_t frame_free(struct frame_alloc *fa, void **pframe);
 aresult_t frame_alloc_delete(struct frame_alloc **pfa);
 size_t frame_alloc_nr_free(struct frame_alloc *fa);
+size_t frame_alloc_frame_bytes(struct frame_alloc *fa); /* distance between neighbouring frames of the pool's slab */
 
 uint64_t tsl_get_clock_monotonic(void); /* ns */
