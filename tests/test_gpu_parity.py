@@ -186,6 +186,45 @@ def test_decimations_below_eight(pkg, ora, decim, ntaps, kernel):
     _check(pkg, ora, fs, decim, taps, offs, iq, 7001, kernel=kernel)
 
 
+@pytest.mark.parametrize("decim,ntaps,nch", [(1, 128, 3), (1, 128, 70), (1, 16, 5), (1, 200, 9), (1, 512, 4), (2, 128, 64), (2, 33, 3),
+                                             (2, 400, 7), (4, 128, 10), (4, 64, 130), (4, 512, 3), (1, 1, 2), (4, 4, 3)])
+def test_decimations_1_2_4_run_on_the_matrix_cores(pkg, ora, decim, ntaps, nch):
+    """etc/multifm_file.json channelises a cs8 capture WITHOUT decimating (filter/direct_fir.c:328-417 takes any factor >= 1).  A row
+    of 2 D plane bytes is shorter than a 16-byte fragment there, so the long-filter kernel keeps 8 / D shifted copies of the tile's
+    image and every column reads the copy in which its window starts aligned (mfm_kernel_v3l.hip, SHIFT; round 5 - the v_dot2
+    kernel before).  int16 blocks and the three 8-bit forms as bytes, ragged block lengths, mixed rotator classes, 4 .. 16
+    k-steps; a channel that wants its filtered IQ stays on the v_dot2 kernel."""
+    fs = 1000000
+    taps = pkg.synth.design_lpf(ntaps, 100000.0, fs) if ntaps > 1 else np.array([0.9])
+    rng = np.random.RandomState(decim * 100 + ntaps)
+    offs = np.where(rng.randint(0, 2, size=nch) == 0, (fs // (4 * decim)) * rng.randint(-3, 4, size=nch),
+                    rng.randint(-450000, 450000, size=nch)).astype(np.int64)
+    n = 20000 * decim + ntaps + 3
+    iq = pkg.synth.random_iq(n, seed=decim * 1000 + ntaps, full_scale=(ntaps == 128))
+    eng = _mk_engine(pkg, fs, decim, taps, offs, max_block=1 << 15, want_iq=False)
+    st = eng.stats()
+    eng.close()
+    assert st["kernel_variant"] == 2 and st["taps_resident"] == 1, st
+    _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, want_iq=False)
+    _check(pkg, ora, fs, decim, taps, offs, iq, 7001, want_iq=False)
+    eng = _mk_engine(pkg, fs, decim, taps, offs[:2], max_block=1 << 15, want_iq=True)
+    assert eng.stats()["kernel_variant"] == 0
+    eng.close()
+    for fmt in (1, 2, 3):
+        raw = np.random.RandomState(nch + fmt).randint(0, 256, size=(n, 2)).astype(np.uint8)
+        sizes = [32768, 4096, 2, 30000, 8, 12346]
+        blocks, pos, k = [], 0, 0
+        while pos < n:
+            m = min(sizes[k % len(sizes)], n - pos)
+            m -= (m & 1) if fmt == 2 and m > 1 else 0
+            blocks.append((raw[pos:pos + m], fmt))
+            pos += m
+            k += 1
+        got, want, st8 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, blocks, 1 << 15)
+        assert st8["kernel_variant"] == 2 and st8["launches_8bit"] > 0, st8
+        assert got.shape == want.shape and np.array_equal(got, want), (fmt, int((got != want).sum()))
+
+
 @pytest.mark.parametrize("decim,ntaps,nch,want_iq", [(40, 128, 64, False), (40, 128, 9, True), (8, 8, 3, True), (8, 60, 20, False),
                                                      (16, 128, 5, False), (24, 100, 70, False), (48, 128, 64, True),
                                                      (56, 56, 3, False), (72, 128, 130, False), (88, 100, 7, True),

@@ -41,6 +41,7 @@ extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pc
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out);
 extern "C" uint32_t mfm_rot_entry_bytes_v3(void);
 extern "C" uint32_t mfm_sp_pitch_v3(void);
+extern "C" uint32_t mfm_v3l_wg_per_cu(const mfm_launch_v3 *L);
 extern "C" hipError_t mfm_launch_channel_kernel_v3(const void *kfn, const mfm_launch_v3 *L, uint32_t lds_bytes, uint32_t grid,
                                                    hipStream_t stream);
 
@@ -178,6 +179,7 @@ struct mfm_engine {
     uint32_t v_layout = 0, v_t_per = 0, v_t_pitch = 0; /* mfm_launch_v3::layout: chunk rows for decimations % 32 != 0 */
     /* layout 3, long filters (mfm_kernel_v3l.hip): plain rows; v_rs = row stride, v_plane = bytes of one byte plane */
     uint32_t v_plane = 0, v_ng = 0, v_nstage_p = 0, v_sta_bytes = 0, v_rb = 1;
+    uint32_t v_shift = 0, v_copy_pitch = 0; /* decimations 1, 2, 4: 8 / D shifted copies of the image, this many bytes apart */
     uint32_t v_nslices = 0; /* channel slices of the second-generation launches: of 64 channels, or of 128 (v_rb = 2) */
     uint32_t v_kq = 0, v_nh = 0, v_kperm[4] = { 0, 0, 0, 0 }; /* the instance's k-step count, k-steps with a high-byte tap plane,
                                                                  and the order the k-steps are laid out in (mfm_launch_v3::kperm) */
@@ -285,7 +287,7 @@ namespace {
 void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
 {
     V.decim = e->cfg.decimation;
-    V.x_last4 = (e->cap_in - 4u) & ~3u;
+    V.x_last4 = e->v_shift ? e->cap_in - 1u : (e->cap_in - 4u) & ~3u;
     V.kq = e->m_ks;
     V.rs = e->v_rs;
     V.sp_pitch = e->v_sp_pitch;
@@ -319,6 +321,10 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
         V.ng = e->v_ng;
         V.rb = e->v_rb;
         V.nstage_p = e->v_nstage_p;
+        V.shift = e->v_shift;
+        if (e->v_shift) {
+            V.sp_pitch = e->v_copy_pitch;
+        }
     }
     V.nslices = e->v_nslices;
     V.nrb = e->m_nrb;
@@ -342,6 +348,9 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
             /* a staging chunk stays 4 samples there - an 8-byte load */
             V.nstage4 = e->v_nstage4;
             V.x_last4 = (2u * e->cap_in - 4u) & ~3u;
+            if (e->v_shift) {
+                V.x_last4 = 2u * e->cap_in - 1u; /* one-sample loads */
+            }
         }
     }
 }
@@ -976,7 +985,11 @@ static int commit_locked(struct mfm_engine *e)
      *      two signed bytes. ---- */
     std::vector<uint32_t> afrag;
     std::vector<int32_t> krow;
-    const uint32_t row_bytes_p = (2u * D + 15u) & ~15u;
+    /* decimations 1, 2, 4 (etc/multifm_file.json: 1): rows shorter than a fragment - the long-filter kernel keeps 8 / D shifted
+     * copies of the image instead of padding them (mfm_kernel_v3l.hip, SHIFT); the window is then the unpadded 2 T elements */
+    const bool shift_geo = (1u == D || 2u == D || 4u == D) && T <= 512u && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_FORCE_DOT2)) &&
+                           ![&] { for (const Channel &c : e->chans) { if (c.want_iq) { return true; } } return false; }();
+    const uint32_t row_bytes_p = shift_geo ? 2u * D : (2u * D + 15u) & ~15u;
     const uint32_t k_elems = ((T - 1u) / D) * row_bytes_p + 2u * ((T - 1u) % D) + 2u; /* element index of the last tap + 1 */
     e->use_mfma = 8u * D >= 3u * row_bytes_p && k_elems <= 64u * MFM_MFMA_KQ_STREAM_MAX &&
                   !(e->cfg.flags & MFM_F_FORCE_DOT2);
@@ -1062,6 +1075,8 @@ static int commit_locked(struct mfm_engine *e)
     /* ---- second-generation matrix kernel: 64-output tiles, four sub-planes per byte plane (mfm_kernel.h) ---- */
     e->use_v3 = false;
     e->v_layout = 0;
+    e->v_shift = 0;
+    e->v_rb = 1;
     if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && e->m_ks <= 4u && D % 8u == 0u && (2u * D) % 64u != 0u) {
         /* decimations that are multiples of 8 but not of 32 (40: etc/multifm.json, etc/multifm_1ch.json): the chunk-row
          * layout (mfm_kernel.h).  t_per = chunks of four outputs; slots: one per four staged rows, plus the window's reach */
@@ -1141,6 +1156,80 @@ static int commit_locked(struct mfm_engine *e)
         e->m_kq_used = 6u;
     }
 
+    if (shift_geo && e->use_mfma) {
+        /* ---- decimations 1, 2, 4 on the long-filter kernel's shifted copies (mfm_kernel_v3l.hip, SHIFT): whole-tile images of
+         *      8 / D copies, one row block per wave; the first generation's geometry above does not apply to rows this short ---- */
+        const uint32_t kq_inst = e->m_kq_used <= 4u ? 4u : e->m_kq_used <= 8u ? 8u : 16u;
+        uint32_t hi_mask = 0;
+        for (const Channel &ch : e->chans) {
+            for (uint32_t i = 0; i < T; i++) {
+                for (int32_t w : { (int32_t)ch.cre[i], (int32_t)ch.cim[i], -(int32_t)ch.cim[i] }) {
+                    const int32_t wl = (int8_t)(w & 0xff);
+                    if (((w - wl) >> 8) != 0) {
+                        hi_mask |= 1u << ((2u * i) / 64u);
+                    }
+                }
+            }
+        }
+        const uint32_t nc = 8u / D;
+        const uint32_t img_samples = 63u * D + T;                       /* what the tile's 64 windows cover */
+        const uint32_t read_bytes = 2u * D * 63u + 64u * kq_inst + 16u; /* ... and what the instance's fragment reads touch */
+        /* bytes between two copies: at least the copy, and 2 D (mod 16) sixteen-byte units - the sixteen columns of a fragment read
+         * (copy n % nc, offset 16 (n / nc)) then fall into sixteen different groups of four LDS banks */
+        uint32_t cp16 = (std::max(2u * img_samples, read_bytes) + 15u) / 16u;
+        while (cp16 % 16u != (2u * D) % 16u) {
+            cp16++;
+        }
+        const uint32_t plane = nc * cp16 * 16u;
+        const uint32_t aux = 8u * 8u * MFM_V3L_TP * 4u + 512u + 2048u;
+        const uint32_t lds = 4u * plane + 2048u + 2048u + aux;
+        mfm_launch_v3 probe{};
+        probe.layout = 3u;
+        probe.shift = 1u;
+        probe.kq = kq_inst;
+        probe.kq_used = e->m_kq_used;
+        probe.nh = (uint32_t)__builtin_popcount(hi_mask);
+        probe.ng = 4u;
+        probe.rb = 1u;
+        probe.nstage4 = img_samples;
+        const void *fn = nullptr;
+        if (img_samples <= 4u * 512u && lds <= 160u * 1024u && mfm_select_channel_kernel_v3(&probe, 0, &fn) == hipSuccess) {
+            e->use_v3 = true;
+            e->v_layout = 3u;
+            e->v_shift = 1u;
+            e->v_copy_pitch = cp16 * 16u;
+            e->v_rs = 2u * D;
+            e->v_plane = plane;
+            e->v_sp_pitch = 0;
+            e->v_ng = 4u;
+            e->v_rb = 1u;
+            e->v_nstage4 = img_samples;
+            e->v_nstage_p = T;
+            e->v_sta_bytes = 2048u;
+            e->v_lds_bytes = lds;
+            e->v_wg_per_cu = 1u; /* (per input format at launch time: mfm_v3l_wg_per_cu) */
+            e->v_kq = kq_inst;
+            e->v_nh = probe.nh;
+            uint8_t order[16] = { 0 };
+            uint32_t at = 0;
+            for (uint32_t k = 0; k < e->m_kq_used; k++) {
+                if ((hi_mask >> k) & 1u) {
+                    order[at++] = (uint8_t)k;
+                }
+            }
+            for (uint32_t k = 0; k < kq_inst; k++) {
+                if (!((hi_mask >> k) & 1u)) {
+                    order[at++] = (uint8_t)k;
+                }
+            }
+            for (int w = 0; w < 4; w++) {
+                e->v_kperm[w] = (uint32_t)order[4 * w] | ((uint32_t)order[4 * w + 1] << 8) | ((uint32_t)order[4 * w + 2] << 16) |
+                                ((uint32_t)order[4 * w + 3] << 24);
+            }
+        } else {
+            e->use_mfma = false; /* the v_dot2 kernel */
+        }
+    }
     if (e->use_mfma && !e->use_v3 && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_STREAM_TAPS)) && e->m_ks >= 8u &&
         e->m_ks <= MFM_V3L_KQ_MAX && !e->any_iq) {
         /* ---- filters of 129..512 taps on the second-generation structure (layout 3, mfm_kernel_v3l.hip): the first
@@ -1352,7 +1441,9 @@ static int commit_locked(struct mfm_engine *e)
         for (uint32_t rb = 0; rb < e->m_nrb; rb++) {
             for (uint32_t j = 0; j < e->v_kq; j++) {
                 const uint32_t src = (e->v_kperm[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-                memcpy(&af3[((size_t)rb * e->v_kq + j) * step_dw], &afrag[((size_t)rb * e->m_ks + src) * step_dw], step_dw * 4u);
+                if (src < e->m_ks) { /* (a step past the laid-out ones holds zero taps) */
+                    memcpy(&af3[((size_t)rb * e->v_kq + j) * step_dw], &afrag[((size_t)rb * e->m_ks + src) * step_dw], step_dw * 4u);
+                }
             }
         }
         afrag.swap(af3);
@@ -1733,7 +1824,9 @@ int launch_locked(mfm_engine *e)
             V.ntiles = (n_new + MFM_V3_OT - 1u) / MFM_V3_OT;
             /* chunks of consecutive tiles, `rounds` per workgroup slot and slice, lengths equal to within one tile
              * (a chunk pays one extra column group) */
-            const uint32_t slots = 256u * e->v_wg_per_cu;
+            /* (the long-filter kernel's small 8-bit instances are built for two workgroups per CU, the others for one) */
+            const uint32_t wg_per_cu = (3u == e->v_layout && 2u * e->v_lds_bytes <= 160u * 1024u) ? mfm_v3l_wg_per_cu(&V) : e->v_wg_per_cu;
+            const uint32_t slots = 256u * wg_per_cu;
             const uint32_t per_slice = std::max(1u, slots / V.nslices);
             /* one chunk per slot: shorter chunks (3..10 tiles, several rounds) were 2-6 % slower on MI355X */
             V.nchunks = std::min(V.ntiles, per_slice);

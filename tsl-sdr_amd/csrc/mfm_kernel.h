@@ -158,7 +158,7 @@ struct mfm_launch_mfma {
  * the surplus k-steps hold zero taps, the surplus planes zeros) */
 static inline uint32_t mfm_v3l_built_kq(uint32_t kq_used)
 {
-    return kq_used <= 6u ? 6u : kq_used <= 8u ? 8u : kq_used <= 12u ? kq_used : kq_used <= 14u ? 14u : 16u;
+    return kq_used <= 4u ? 4u : kq_used <= 6u ? 6u : kq_used <= 8u ? 8u : kq_used <= 12u ? kq_used : kq_used <= 14u ? 14u : 16u;
 }
 static inline uint32_t mfm_v3l_built_nh(uint32_t kq, uint32_t nh)
 {
@@ -241,6 +241,10 @@ struct mfm_launch_v3 {
                              blocks' taps fit 128 registers (no or few high-byte planes: configs[4]'s filter) */
     uint32_t nstage_p;    /* 4-sample chunks of the one-group image in front of a chunk's first tile (its column 0 is the
                              output in front of the chunk, recomputed) */
+    uint32_t shift;       /* 1: decimation 1, 2 or 4 - the image is kept 8 / D times, copy c shifted by 2 D c plane bytes and sp_pitch
+                             bytes behind copy c - 1, so that every column's window starts 16-byte aligned in one of the copies
+                             (mfm_kernel_v3l.hip, SHIFT); row_bytes = rs = 2 D, no padding; a staging chunk is one sample
+                             (nstage4 / nstage_p count samples); kq is 4, 8 or 16 */
     uint32_t tp_off;      /* LDS byte offset of the transposition areas: [8 waves][8 * rb channels][72] dwords, then the fold
                              constants (512 * rb bytes) and the exact-rotator tables (2048 * rb bytes) */
     uint32_t *tail_dst;

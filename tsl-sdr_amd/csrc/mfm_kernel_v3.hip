@@ -1165,7 +1165,7 @@ extern "C" hipError_t mfm_disc_test_v3(const int *s_re, const int *s_im, int *pc
  */
 /* layout 3 (long filters): the instances live in mfm_kernel_v3l.hip, one translation unit per k-step count */
 #define MFM3L_IMPORT(KQ_) extern "C" const void *mfm_v3l_instance_kq##KQ_(const mfm_launch_v3 *L, uint32_t nch);
-MFM3L_IMPORT(6) MFM3L_IMPORT(8) MFM3L_IMPORT(9) MFM3L_IMPORT(10) MFM3L_IMPORT(11) MFM3L_IMPORT(12) MFM3L_IMPORT(14) MFM3L_IMPORT(16)
+MFM3L_IMPORT(4) MFM3L_IMPORT(6) MFM3L_IMPORT(8) MFM3L_IMPORT(9) MFM3L_IMPORT(10) MFM3L_IMPORT(11) MFM3L_IMPORT(12) MFM3L_IMPORT(14) MFM3L_IMPORT(16)
 #undef MFM3L_IMPORT
 
 extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int dbg_iq, const void **kfn_out)
@@ -1180,6 +1180,7 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
             return hipErrorInvalidValue;
         }
         switch (L->kq) {
+        case 4: *kfn_out = mfm_v3l_instance_kq4(L, nch4); break;
         case 6: *kfn_out = mfm_v3l_instance_kq6(L, nch4); break;
         case 8: *kfn_out = mfm_v3l_instance_kq8(L, nch4); break;
         case 9: *kfn_out = mfm_v3l_instance_kq9(L, nch4); break;

@@ -82,8 +82,20 @@ static __device__ __forceinline__ void mfm3l_wait_fragments(int younger, mfm_v4i
  * all zero are neither held (four registers each) nor multiplied (two matrix instructions each), and the matrix phase is
  * straight-line code: run-time tests of a mask between the matrix instructions cost the compiler's lane-mask arithmetic
  * and a full LDS wait per k-step (first measurement of this file, profiles/r05_long_filters.txt). */
-template <int KQ, int NH, int NG, int NCH, bool IN8, int RB>
-__global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_launch_v3 L)
+/* SHIFT: decimations 1, 2, 4 (etc/multifm_file.json channelises without decimating) - a row of 2 D plane bytes is shorter than
+ * the 16 bytes a B fragment reads, and the window of output o starts at plane byte 2 D o, aligned to 16 bytes only for every
+ * (8 / D)-th output.  The image is kept 8 / D times, copy c shifted by 2 D c bytes (copy_c[j] = plane[j + 2 D c]), so that
+ * column n = (8 / D) a + c reads copy c at the aligned offset 16 a: every fragment read is again one aligned ds_read_b128,
+ * "lane register + group offset".  The image of a tile is a few hundred bytes per copy; the taps are the unpadded window. */
+/* waves per SIMD an instance is built for: four (two workgroups per CU) where the taps are few - the four-k-step shifted-copies
+ * form on 8-bit input (128 taps at decimation 1: etc/multifm_file.json is a cs8 capture) - else two */
+constexpr int mfm3l_waves_per_simd(int KQ, int NH, int RB, bool SHIFT, bool IN8)
+{
+    return (SHIFT && IN8 && KQ == 4 && RB == 1 && NH <= 2) ? 4 : 2; /* (the int16 forms would spill at 128 registers) */
+}
+
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SHIFT = false>
+__global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8)) void mfm_channel_kernel_v3l(const mfm_launch_v3 L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     static_assert(NG == 1 || NG == 2 || NG == 4, "an image is a tile, half or a quarter of one");
@@ -92,8 +104,10 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     constexpr uint32_t OPI = 16u * (uint32_t)NG; /* outputs per image */
     static_assert(NH >= 0 && NH <= KQ, "planes held");
     /* two k-steps ahead where the taps take 112 registers or more and the fragments are pairs */
-    constexpr int PF = (4 * RB * (KQ + NH) >= 112 && !IN8) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
-    using chunk_t = typename std::conditional<IN8, uint2, uint4>::type;
+    /* (and with four waves per SIMD, which have each other to hide an LDS round trip and 128 registers each) */
+    constexpr int PF = ((4 * RB * (KQ + NH) >= 112 && !IN8) || mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8) == 4) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
+    struct one_sample { uint32_t x; };
+    using chunk_t = typename std::conditional<SHIFT, one_sample, typename std::conditional<IN8, uint2, uint4>::type>::type;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
     uint16_t *sta16_s = reinterpret_cast<uint16_t *>(smem + L.sta_off);
 #pragma unroll
-    for (int j = 0; j < NCH; j++) {
+    for (int j = 0; j < NCH && !SHIFT; j++) {
         const uint32_t s0 = (tid + (uint32_t)j * MFM3_NT) * 4u;
         const uint32_t r0 = s0 / D, c0 = s0 % D;
         if (split_rows) {
@@ -133,12 +147,58 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
     for (int kq = 0; kq < KQ; kq++) {
         const uint32_t step = (L.kperm[kq >> 2] >> (8 * (kq & 3))) & 0xffu; /* the kq-th k-step multiplied is this one of the window */
         const uint32_t e = 64u * step + 16u * kg;
-        boff[kq] = (n + e / row_bytes) * rs + e % row_bytes;
+        if constexpr (SHIFT) {
+            /* column n = nc * a + c (nc = 8 / D copies): copy c, aligned offset 16 a; L.sp_pitch = bytes between two copies */
+            const uint32_t nc = 8u / D;
+            boff[kq] = (n % nc) * L.sp_pitch + 16u * (n / nc) + e;
+        } else {
+            boff[kq] = (n + e / row_bytes) * rs + e % row_bytes;
+        }
     }
 
     /* sample index (from L.x) of the first sample of the image that starts at output `out` of this launch */
     auto image_start = [&](int out) -> int { return (int)L.hist + out * (int)D; };
+    /* SHIFT: a thread-chunk is ONE sample (the image of a tile is a few hundred of them): its two plane bytes go to every copy */
+    auto stage_load1 = [&](int s_first, int j) -> uint32_t {
+        int gs = s_first + (int)(tid + (uint32_t)j * MFM3_NT);
+        gs = gs < 0 ? 0 : gs;
+        gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
+        if constexpr (IN8) {
+            return (uint32_t)reinterpret_cast<const uint16_t *>(L.x)[gs];
+        } else {
+            return L.x[gs];
+        }
+    };
+    auto stage_store1 = [&](uint32_t buf, int j, uint32_t v, uint32_t nsamp) {
+        const uint32_t p = tid + (uint32_t)j * MFM3_NT; /* sample index within the image */
+        if (p >= nsamp) {
+            return;
+        }
+        uint32_t hi, lo = 0;
+        if constexpr (IN8) {
+            hi = (v ^ L.in8_xor) & 0xffffu;
+        } else {
+            hi = __builtin_amdgcn_perm(v, v, 0x0c0c0301u);           /* (I_hi, Q_hi) */
+            lo = __builtin_amdgcn_perm(v, v, 0x0c0c0200u) ^ 0x8080u; /* (I_lo, Q_lo) - 128 */
+        }
+        uint8_t *img = smem + buf * buf_pitch;
+        const uint32_t nc = 8u / D;
+        for (uint32_t c = 0; c < nc; c++) {
+            const int off = 2 * (int)p - (int)(2u * D * c); /* copy_c[j] = plane[j + 2 D c] */
+            if (off >= 0) {
+                *reinterpret_cast<uint16_t *>(img + c * L.sp_pitch + (uint32_t)off) = (uint16_t)hi;
+                if (!IN8) {
+                    *reinterpret_cast<uint16_t *>(img + plane_pitch + c * L.sp_pitch + (uint32_t)off) = (uint16_t)lo;
+                }
+            }
+        }
+    };
     auto stage_load = [&](int s_first, int j) -> chunk_t {
+        if constexpr (SHIFT) {
+            chunk_t r{};
+            r.x = stage_load1(s_first, j);
+            return r;
+        } else {
         /* 4 samples of an image.  Only a readable address is needed: samples past n_avail feed only outputs >= n_new (never
          * stored) or zero-padded taps; an image never starts in front of the buffer (the output in front of a launch has
          * its first row there: L.hist). */
@@ -150,8 +210,13 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
         } else {
             return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
         }
+        }
     };
     auto stage_store = [&](uint32_t buf, int j, const chunk_t &v, uint32_t nchunk) {
+        if constexpr (SHIFT) {
+            stage_store1(buf, j, v.x, nchunk);
+            return;
+        } else {
         if (tid + (uint32_t)j * MFM3_NT >= nchunk) {
             return;
         }
@@ -191,6 +256,7 @@ __global__ __launch_bounds__(MFM3_NT, 2) void mfm_channel_kernel_v3l(const mfm_l
                     *reinterpret_cast<uint16_t *>(p + plane_pitch) = (uint16_t)l[m];
                 }
             }
+        }
         }
     };
 
@@ -695,10 +761,27 @@ static const void *mfm3l_instance_fmt(const mfm_launch_v3 *L, uint32_t nch)
 template <int KQ, int NH>
 static const void *mfm3l_instance_geo(const mfm_launch_v3 *L, uint32_t nch)
 {
+    /* decimations 1, 2, 4 on shifted copies of the image: whole-tile images, one row block per wave, k-step counts 4, 8, 16 */
+    if constexpr (KQ == 4 || KQ == 8 || KQ == 16) {
+        if (L->shift) {
+            if (L->ng != 4u || L->rb != 1u || mfm_v3l_built_nch(nch) != 4u) {
+                return nullptr;
+            }
+            return L->in8 ? reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, 4, 4, true, 1, true>)
+                          : reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, 4, 4, false, 1, true>);
+        }
+    }
+    if constexpr (KQ == 4) {
+        return nullptr; /* (the other layouts of this file start at five k-steps) */
+    } else {
+    if (L->shift) {
+        return nullptr;
+    }
     if (L->rb == 2u) {
         return L->ng == 1u ? mfm3l_instance_fmt<KQ, NH, 1, 2>(L, nch) : nullptr;
     }
     return L->ng == 4u ? mfm3l_instance_fmt<KQ, NH, 4, 1>(L, nch) : L->ng == 2u ? mfm3l_instance_fmt<KQ, NH, 2, 1>(L, nch) : nullptr;
+    }
 }
 
 /* the instance for a launch description (geometry fields only, all fixed at commit): L->kq k-steps (a built count), the
@@ -715,11 +798,22 @@ static const void *mfm3l_instance(const mfm_launch_v3 *L, uint32_t nch)
     }
 }
 
+#if MFM3L_ONLY_KQ == 0 || MFM3L_ONLY_KQ == 4
+/* workgroups per CU the instance a launch description selects is built for */
+extern "C" uint32_t mfm_v3l_wg_per_cu(const mfm_launch_v3 *L)
+{
+    return (L->shift && L->in8 && L->kq == 4u && L->rb == 1u && mfm_v3l_built_nh(4u, L->nh) <= 2u) ? 2u : 1u;
+}
+#endif
+
 #define MFM3L_EXPORT(KQ_)                                                                  \
     extern "C" const void *mfm_v3l_instance_kq##KQ_(const mfm_launch_v3 *L, uint32_t nch)  \
     {                                                                                      \
         return mfm3l_instance<KQ_>(L, nch);                                                \
     }
+#if MFM3L_ONLY_KQ == 0 || MFM3L_ONLY_KQ == 4
+MFM3L_EXPORT(4)
+#endif
 #if MFM3L_ONLY_KQ == 0 || MFM3L_ONLY_KQ == 6
 MFM3L_EXPORT(6)
 #endif
