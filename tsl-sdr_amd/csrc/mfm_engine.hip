@@ -1271,7 +1271,7 @@ static int commit_locked(struct mfm_engine *e)
                 continue;
             }
             /* the instance's count of chunks (a surplus chunk is loaded and not stored); 16-bit offsets where no chunk straddles rows */
-            const uint32_t sta = mfm_v3l_built_nch(nch) * ((D % 4u) != 0u ? 2048u : 1024u);
+            const uint32_t sta = mfm_v3l_built_nch(nch) * ((D % 4u) != 0u ? 1536u : 1024u); /* 16-bit offsets (+ a byte per chunk: rows split) */
             const uint32_t aux = 8u * 8u * rbw * MFM_V3L_TP * 4u + 512u * rbw + 2048u * rbw;
             const uint32_t lds = 4u * plane + 2048u + sta + aux;
             if (lds > 160u * 1024u) {

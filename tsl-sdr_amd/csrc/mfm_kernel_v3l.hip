@@ -126,17 +126,17 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
     /* staging: this thread owns the 4-sample chunks q = tid + j * 512 of every image; where they go never changes:
      * samples 4q .. 4q + 3 of the image sit in row (4q) / D, two plane bytes per sample; bits 16..18: how many of the four
      * still belong to that row (fewer than 4 only when D is not a multiple of 4) */
-    /* (a table of 16-bit offsets where no chunk straddles rows: LDS is what limits the image size at large decimations) */
-    uint32_t *sta_s = reinterpret_cast<uint32_t *>(smem + L.sta_off);
+    /* (16-bit offsets - LDS is what limits the image size at large decimations -, the in-row counts behind them as bytes: only
+     * decimations that are not multiples of 4 read those) */
     uint16_t *sta16_s = reinterpret_cast<uint16_t *>(smem + L.sta_off);
+    uint8_t *sta_in_row_s = smem + L.sta_off + NCH * MFM3_NT * 2u;
 #pragma unroll
     for (int j = 0; j < NCH && !SHIFT; j++) {
         const uint32_t s0 = (tid + (uint32_t)j * MFM3_NT) * 4u;
         const uint32_t r0 = s0 / D, c0 = s0 % D;
+        sta16_s[j * MFM3_NT + tid] = (uint16_t)(r0 * rs + 2u * c0);
         if (split_rows) {
-            sta_s[j * MFM3_NT + tid] = ((r0 * rs + 2u * c0) & 0xffffu) | (min(4u, D - c0) << 16);
-        } else {
-            sta16_s[j * MFM3_NT + tid] = (uint16_t)(r0 * rs + 2u * c0);
+            sta_in_row_s[j * MFM3_NT + tid] = (uint8_t)min(4u, D - c0);
         }
     }
 
@@ -220,9 +220,8 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         if (tid + (uint32_t)j * MFM3_NT >= nchunk) {
             return;
         }
-        const uint32_t st = split_rows ? sta_s[j * MFM3_NT + tid] : (uint32_t)sta16_s[j * MFM3_NT + tid];
-        uint8_t *base = smem + buf * buf_pitch + (st & 0xffffu); /* own slot: no barrier needed */
-        const uint32_t in_row = st >> 16, hop = rs - 2u * D;
+        uint8_t *base = smem + buf * buf_pitch + (uint32_t)sta16_s[j * MFM3_NT + tid]; /* own slot: no barrier needed */
+        const uint32_t in_row = split_rows ? (uint32_t)sta_in_row_s[j * MFM3_NT + tid] : 4u, hop = rs - 2u * D;
         if constexpr (IN8) {
             const uint32_t m = L.in8_xor; /* 0x80808080: unsigned bytes -> int8 */
             const uint2 hi = make_uint2(v.x ^ m, v.y ^ m);
@@ -596,17 +595,16 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                                  w[0] = f[0];
                                  w[MFM_V3L_TP] = f[1];
                              });
-                if (h + 1u == NSUB) {
+                if (RB == 1 && h + 1u == NSUB) {
                     /* rotator entries of this tile, four consecutive ones per channel: requested behind the tile's last matrix
                      * phase, needed behind the staging stores and the barrier.  (In front of it - a matrix phase more to
-                     * arrive - measured 1 % slower: profiles/r05_long_filters.txt) */
+                     * arrive - measured 1 % slower: profiles/r05_long_filters.txt.)  With two row blocks per wave the sixteen
+                     * registers are not there across the staging stores - the compiler parked them in scratch, which waits for
+                     * the loads on the spot - so those instances ask at the top of the epilogue. */
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < RB; r++) {
-#pragma unroll
-                        for (int c = 0; c < 2; c++) {
-                            rva[r][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + kb8[r][c]);
-                        }
+                    for (int c = 0; c < 2; c++) {
+                        rva[0][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[0][c]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -625,6 +623,15 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         if (rb_valid) {
             static_assert(MFM3_ROT4, "the long-filter kernel is written for 4-byte rotator entries");
             const uint32_t n_left = L.n_new - first_out; /* >= 1 */
+            if (RB > 1) {
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        rva[r][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[r][c]));
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < RB; r++) {
                 uint32_t q[4][2];
