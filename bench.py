@@ -276,11 +276,24 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
 
 
 def library_sha16(pkg):
-    """first 16 hex digits of the SHA-256 of libmultifm_hip.so: ties instruction counts in profiles/ to the build they belong to"""
+    """first 16 hex digits of the SHA-256 over the kernel sources the library is built from (tsl-sdr_amd/csrc/*, the Makefile) and
+    the compiler's version line: ties the instruction counts in profiles/ to the code they belong to.  (Not the .so's own hash: the
+    fat binary embeds the build directory, the same sources built elsewhere hash differently - tried.)"""
+    import glob
     import hashlib
-    path = os.path.join(ROOT, "tsl-sdr_amd", "libmultifm_hip.so")
+    import subprocess
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "tsl-sdr_amd")
     try:
-        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+        for f in sorted(glob.glob(os.path.join(base, "csrc", "*")) + [os.path.join(base, "Makefile")]):
+            if os.path.isfile(f):
+                h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+        try:
+            ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=30).stdout.splitlines()[0]
+        except Exception:
+            ver = "?"
+        h.update(ver.encode())
+        return h.hexdigest()[:16]
     except OSError:
         return None
 
@@ -453,6 +466,9 @@ def north_star_shape(pkg, torch, block, steps=12, settle_s=0.3):
                               "at_measured_3944_tops": bytes_alg / (issued / (MFMA_I8_MEASURED_TOPS * 1e12)) / 1e9 / HBM_PEAK_GBPS},
                "clocks": cyc}
         out["frac_of_bound"] = {k: frac / v for k, v in out["bound_frac"].items()}
+        # the same issue model as the headline's (matrix + other vector instructions against this run's shader cycles)
+        out["instance"] = instance_name(pkg, st, False)
+        out["issue_model"] = issue_model(out["instance"], st, cyc, frac, library_sha16(pkg))
         return out
     except Exception as e:  # a side line must never take the headline down
         return {"error": repr(e)}
@@ -1276,6 +1292,7 @@ def main():
                          # what holds the kernel below the HBM roof (SQ counters in profiles/)
                          "binding": "simd_issue" if mfma else "valu_dot2",
                          "ceiling_frac": ceiling["ceiling_frac"] if ceiling else None, "issue_model": ceiling,
+                         "instance": instance_name(pkg, st1, in8), "library_sha16": library_sha16(pkg),
                          # the kernel's own clocks for the timed launches, and one sysfs sample taken while they ran
                          "clocks": cycles, "board_sample": smi},
             "verified": verified["verified"], "verification": verified,
