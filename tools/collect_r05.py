@@ -312,8 +312,67 @@ for s in ("cfg5", "d25", "d100", "d120", "t512", "t256"):
     if s in pmc_rows:
         vals[s + "_lane"] = f"{pmc_rows[s]['lane']:.1f}"
         vals[s + "_busy"] = f"{pmc_rows[s]['busy']:.2f}"
+# ---- block-size series, host-fed figures, the link, latency (from the driver-flags line) --------------------------------------
+bs = head.get("block_series", {}).get("series", [])
+st = ["| block | mode | launches | us per block | input GSamp/s | of the HBM roof |", "|---|---|---|---|---|---|"]
+names = {"coalesced": "backlog gathered into launches of up to 2^26 samples, two streams", "per_block": "every block its own launch, two streams",
+         "coalesced_one_stream": "gathered, one stream", "per_block_one_stream": "every block its own launch, one stream"}
+for row in bs:
+    for mode in ("coalesced", "coalesced_one_stream", "per_block", "per_block_one_stream"):
+        m = row.get(mode)
+        if isinstance(m, dict) and "frac" in m:
+            st.append(f"| 2^{row['block_samples'].bit_length() - 1} x {row['blocks']} | {names[mode]} | {m['launches']} | {m['us_per_block']:.2f} | "
+                      f"{m['input_msamp_per_s'] / 1e3:.1f} | **{m['frac']:.3f}** |")
+ee = head.get("end_to_end", {})
+st += ["", f"Host-fed (`end_to_end`: {ee.get('path')}; PCIe both ways inside the figure).  `pool_arena` modes: the buffers are frames of ONE "
+       "page-locked pool in address order, as `host/mfm_receiver.c` gets them from its frame pool, and runs of neighbours go to the device as one "
+       "strided copy command (`mfm_group_push_pinned_run`):", "",
+       "| mode | buffers | copy commands | launches | us per buffer | input GSamp/s | H2D GB/s | D2H GB/s |", "|---|---|---|---|---|---|---|---|"]
+for mode, m in ee.items():
+    if isinstance(m, dict) and "input_msamp_per_s" in m:
+        st.append(f"| {mode} | {m.get('buffers', ee.get('buffers'))} | {m.get('copy_commands', '-')} | {m['launches']} | {m['us_per_buffer']:.2f} | "
+                  f"{m['input_msamp_per_s'] / 1e3:.2f} | {m['h2d_GBps']:.1f} | {m['d2h_GBps']:.1f} |")
+lk = ee.get("link")
+if lk:
+    st += ["", "The link by itself (`end_to_end.link`: `mfm_link_probe[_runs]` - page-locked host memory, H2D with the D2H of a third of the bytes "
+           "running against it, as the path has it):", "", "| pieces | H2D GB/s | D2H GB/s | H2D alone |", "|---|---|---|---|"]
+    for k, lab in (("pieces_512KiB", "512 KiB per copy command (one RTL-SDR sample_buf)"), ("pieces_512KiB_runs_of_16_strided", "runs of 16 x 512 KiB as one strided command"),
+                   ("pieces_64MiB", "64 MiB per command")):
+        if k in lk:
+            st.append(f"| {lab} | {lk[k]['h2d_GBps']:.1f} | {lk[k]['d2h_GBps']:.1f} | {lk[k].get('h2d_alone_GBps', nan):.1f} |")
+    st.append("")
+    st.append("end_to_end over link: " + ", ".join(f"{k[len('end_to_end_'):]} {v:.2f}" for k, v in lk.items() if k.startswith("end_to_end_")))
+lat = ee.get("latency")
+if lat:
+    st += ["", "Latency at a live feed's rate (`end_to_end.latency`: from `deliver` of a 131 072-sample buffer to its PCM fetched on the host, "
+           "buffers arriving at the sample rate's pace):", "", "| launch policy | feed | median ms | max ms | buffer period ms |", "|---|---|---|---|---|"]
+    for pol, feeds in lat.items():
+        for feed, m in feeds.items():
+            st.append(f"| {pol} | {feed} | {m['latency_ms_median']:.3f} | {m['latency_ms_max']:.3f} | {m['buffer_period_ms']:.1f} |")
+cba = cb.get("all_cores") if cb else None
+if cba:
+    st += ["", f"CPU baseline on all cores (`cpu_baseline.all_cores`): {cba['value']:.0f} MSamp/s x channels on {cba['cores']} threads, {cba['channels']} channels."]
+series_text = "\n".join(st)
+open(os.path.join(P, "r05_block_series.md"), "w").write(series_text + "\n")
+
+# the exchange table of DESIGN.md section 7
+blk_mb = head["config"]["block_samples"] * 4 / 1e6
+xt = ["| channels per GPU | kernel per block | needed per peer (int16 / 8-bit) | broadcast (≈ 153 GB/s per GPU) | all-gather on 7 links (≈ 940 GB/s at N = 8) |",
+      "|---|---|---|---|---|"]
+for key, lab in (("driverflags", "64"), ("c128", "128 (configs[2]: 1024 on 8 GPUs)"), ("c256", "256"), ("c1024", "1024")):
+    if key not in lines:
+        continue
+    k = lines[key]["roofline"]["kernel_ms"]
+    need = blk_mb / k  # MB per ms = GB/s
+    fmt = lambda have, n: "hidden" if n <= have else f"{n / have:.1f} x short"
+    xt.append(f"| {lab} | {k:.3f} ms | {need:.0f} / {need / 2:.0f} GB/s | {fmt(153.0, need)} | {fmt(940.0, need)} (8-bit: {fmt(940.0, need / 2)}) |")
+xt_text = "\n".join(xt)
+
 for path in (os.path.join(P, "README.md"), os.path.join(R, "DESIGN.md")):
     s = open(path).read()
+    s = re.sub(r"<!-- r05x:begin -->.*?<!-- r05x:end -->", lambda m: "<!-- r05x:begin -->\n" + xt_text + "\n<!-- r05x:end -->", s, flags=re.S)
+    s = re.sub(r"<!-- r05s:begin -->.*?<!-- r05s:end -->", lambda m: "<!-- r05s:begin -->\n" + series_text + "\n<!-- r05s:end -->", s, flags=re.S)
+    open(path, "w").write(s)
     if "<!-- r05:begin -->" not in s:
         print("no r05 markers in", path)
         continue
