@@ -277,20 +277,19 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
 
 def library_sha16(pkg):
     """first 16 hex digits of the SHA-256 over the kernel sources the library is built from (tsl-sdr_amd/csrc/*, the Makefile) and
-    the compiler's version line: ties the instruction counts in profiles/ to the code they belong to.  (Not the .so's own hash: the
+    the ROCm release: ties the instruction counts in profiles/ to the code they belong to.  (Not the .so's own hash: the
     fat binary embeds the build directory, the same sources built elsewhere hash differently - tried.)"""
     import glob
     import hashlib
-    import subprocess
     h = hashlib.sha256()
     base = os.path.join(ROOT, "tsl-sdr_amd")
     try:
         for f in sorted(glob.glob(os.path.join(base, "csrc", "*")) + [os.path.join(base, "Makefile")]):
             if os.path.isfile(f):
                 h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
-        try:
-            ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=30).stdout.splitlines()[0]
-        except Exception:
+        try:   # (a file, not `hipcc --version`: no child process is started from a process that has touched the GPU)
+            ver = open("/opt/rocm/.info/version").read().strip()
+        except OSError:
             ver = "?"
         h.update(ver.encode())
         return h.hexdigest()[:16]

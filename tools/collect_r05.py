@@ -44,7 +44,7 @@ with open(os.path.join(P, "r05_bench_lines.jsonl"), "w") as fo:
         d = dict(d)
         d["_run"] = k
         fo.write(json.dumps(d) + "\n")
-lib_sha = lines["driverflags_first_call" if final else "driverflags"]["roofline"]["library_sha16"]  # (sources + compiler: bench.py library_sha16())
+lib_sha = head["roofline"]["library_sha16"]  # (kernel sources + ROCm release: bench.py library_sha16(); both calls ran the same tree)
 what = collections.OrderedDict([
     ("driverflags", "cfg2 (64 ch, D = 96, 128 taps), driver's flags"), ("default", "cfg2, defaults (300 steps)"),
     ("grid64", "cfg2 geometry, every channel on the 12.5 kHz raster"), ("mfma1", "cfg2, first-generation kernel"),
