@@ -30,6 +30,12 @@ def case(pkg, ora, rng, long_only=False):
         # matrix kernel over their staging-chunk counts, tile forms and tap-plane masks
         decim = int(rng.choice([int(rng.randint(8, 461)), 4 * int(rng.randint(2, 116)), 8 * int(rng.randint(1, 58)), 96, 400]))
         ntaps = max(decim, int(rng.choice([int(rng.randint(129, 513)), 129, 160, 256, 257, 400, 512])))
+    small = (not long_only) and rng.rand() < 0.12
+    if small:
+        # decimations 1 .. 7: 1, 2, 4 run the shifted-copies form of the long-filter kernel (etc/multifm_file.json channelises
+        # without decimating), the others the first generation or v_dot2
+        decim = int(rng.choice([1, 1, 2, 4, 4, 3, 5, 6, 7]))
+        ntaps = int(rng.choice([128, 128, 64, 65, 200, 256, 512, 16, decim + int(rng.randint(0, 300))]))
     nch = int(rng.choice([1, 2, 5, 8, 9, 16, 33, 64, 65, 130, int(rng.randint(1, 300))]))
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     if long_only and rng.rand() < 0.25:
@@ -49,6 +55,9 @@ def case(pkg, ora, rng, long_only=False):
     if long_only:
         kernel, want_iq = "auto", bool(rng.rand() < 0.15)
     n = int(rng.randint(ntaps, 400000))
+    if small:
+        # bounded oracle work: n / D outputs x taps x channels
+        n = int(rng.randint(ntaps, max(ntaps + 1, min(400000, int(2.0e9 * decim / (ntaps * nch))))))
     if rng.rand() < 0.5:
         iq = pkg.synth.random_iq(n, seed=int(rng.randint(1 << 30)))
     else:
@@ -101,6 +110,12 @@ def case8(pkg, ora, rng, long_only=False):
         decim = int(rng.choice([4 * int(rng.randint(2, 116)), 8 * int(rng.randint(1, 58)), 96, 400, 25, 100, int(rng.randint(8, 461))]))
         ntaps = max(decim, int(rng.choice([int(rng.randint(257, 513)), 300, 400, 512, 256, 256])))
     nch = int(rng.choice([1, 3, 8, 9, 16, 64, 65, 130]))
+    limit = 300000
+    if (not long_only) and rng.rand() < 0.12:
+        # decimations 1, 2, 4 on 8-bit captures (etc/multifm_file.json is one): the shifted-copies form reading bytes
+        decim = int(rng.choice([1, 1, 2, 4]))
+        ntaps = int(rng.choice([128, 128, 64, 200, 256, 512]))
+        limit = max(4 * ntaps, min(300000, int(2.0e9 * decim / (ntaps * nch))))
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     offs = rng.randint(-fs // 2, fs // 2, size=nch)
     offs[: min(nch, 4)] = [0, 25000, -37500, 3125][: min(nch, 4)]
@@ -125,8 +140,8 @@ def case8(pkg, ora, rng, long_only=False):
     incr = np.stack([eng.get_channel(c)[2] for c in range(nch)])
     main_fmt = int(rng.choice([1, 2, 3, 3]))
     total, iq, got, seq = 0, [], [], []
-    while total < 300000:
-        m = int(rng.randint(1, max_block + 1))
+    while total < limit:
+        m = int(rng.randint(1, min(max_block, limit) + 1))
         fmt = main_fmt if rng.rand() < 0.9 else int(rng.randint(0, 4))
         if fmt == 0:
             blk = rng.randint(-32768, 32768, size=(m, 2)).astype(np.int16)
