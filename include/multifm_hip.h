@@ -727,6 +727,13 @@ int mfm_hosttwin_atan_table_ok(void); /* 1 if the generated table matches the pi
  * kernels carry three renderings of it (scalar, packed, four at a time), and tests run the hard cases of its division
  * through each (tools/div_proof.c).  Host arrays in and out; not a compute path. */
 int mfm_devtest_discriminate(int variant, const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *pcm_out, int device);
+/* What v_rcp_f32 returns on `device` for all 2^23 binary32 significands, as a hash (+ how many reciprocals are one ulp low /
+ * correctly rounded / one ulp high / anything else), and optionally the discriminator's division against the IEEE quotient
+ * on 2^28 significand pairs.  mfm_engine_commit() compares the hash with MFM_RCP_TABLE_HASH_GFX950 - the table the
+ * division's correctness proof (tools/div_proof.c) enumerated - once per device, and falls back to the sweep when it
+ * differs: a device with another reciprocal table is accepted only if not one quotient is off. */
+#define MFM_RCP_TABLE_HASH_GFX950 0x0ull /* (read off an MI355X: tests/test_gpu_parity.py checks it there) */
+int mfm_devtest_rcp_table(int device, uint64_t *hash, uint64_t counts[4], uint64_t *sweep_bad, uint64_t *sweep_tried);
 /* the device's table-driven BCH(31,21) decode (syndrome bytes -> 1024-entry flip table), on the host */
 int mfm_hosttwin_bch3121_decode(uint32_t *word);
 

@@ -993,3 +993,21 @@ def test_discriminator_division_hard_cases_on_the_device(pkg, ora, tmp_path, var
     ora.lib().mfmo_discriminate_batch(s_re.ctypes.data_as(i32p), s_im.ctypes.data_as(i32p), s_re.size, want.ctypes.data_as(i16p), 0)
     bad = np.flatnonzero(got != want)
     assert bad.size == 0, (bad.size, s_re[bad[:4]], s_im[bad[:4]], got[bad[:4]], want[bad[:4]])
+
+
+@pytest.mark.gpu
+def test_reciprocal_table_is_the_one_the_division_proof_enumerated(pkg):
+    """the one-residual-step division is correct for gfx950's v_rcp_f32 (tools/div_proof.c on the table
+    tools/rcp_check.hip read off an MI355X).  mfm_devtest_rcp_table hashes what v_rcp_f32 returns for all 2^23 significands on
+    THIS device: it must be the table the header names (commit() checks the same and falls back to a 2^28-quotient sweep
+    against the IEEE division otherwise), with the proof's shares - 89 % correctly rounded, 9 % one ulp low, 2 % high - and
+    the sweep itself must find nothing."""
+    lib = pkg.load_library()
+    h, bad, tried = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    counts = (C.c_uint64 * 4)()
+    assert lib.mfm_devtest_rcp_table(0, C.byref(h), counts, C.byref(bad), C.byref(tried)) == 0, lib.mfm_last_error()
+    low, exact, high, other = (int(c) for c in counts)
+    assert low + exact + high + other == 1 << 23 and other == 0, (low, exact, high, other)
+    assert 0.87 < exact / (1 << 23) < 0.91 and 0.07 < low / (1 << 23) < 0.11 and 0.01 < high / (1 << 23) < 0.03, (low, exact, high)
+    assert bad.value == 0 and tried.value == 1 << 28, (bad.value, tried.value)
+    assert h.value == pkg.binding.MFM_RCP_TABLE_HASH_GFX950, hex(h.value)

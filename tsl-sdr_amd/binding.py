@@ -25,12 +25,13 @@ MFM_F_STREAM_TAPS = 0x80
 MFM_F_GATHER = 0x100
 MFM_F_OVERLAP = 0x200
 MFM_F_V3L_ONE_ROW_BLOCK = 0x400
+MFM_RCP_TABLE_HASH_GFX950 = 0x0  # include/multifm_hip.h
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
 ABI_SYMBOLS = [
     "mfm_engine_input_bytes", "mfm_engine_input_bytes_cfg", "mfm_engine_flush", "mfm_engine_replay", "mfm_group_flush",
-    "mfm_engine_last_launch_input", "mfm_engine_seek", "mfm_devtest_discriminate",
+    "mfm_engine_last_launch_input", "mfm_engine_seek", "mfm_devtest_discriminate", "mfm_devtest_rcp_table",
     "mfm_host_alloc", "mfm_host_free", "mfm_engine_push_pinned", "mfm_engine_copy_done", "mfm_engine_copy_wait",
     "mfm_group_push_pinned", "mfm_group_copy_done", "mfm_group_copy_wait", "mfm_group_replay_pinned",
     "mfm_engine_create", "mfm_engine_destroy", "mfm_engine_add_channel",
@@ -251,6 +252,7 @@ def load_library():
     lib.mfm_hosttwin_discriminate_batch.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, i16p]
     lib.mfm_hosttwin_discriminate_batch.restype = None
     lib.mfm_devtest_discriminate.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, i16p, C.c_int]
+    lib.mfm_devtest_rcp_table.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.mfm_hosttwin_r14.argtypes = [C.c_int32]
     lib.mfm_hosttwin_r14.restype = C.c_int16
     lib.mfm_hosttwin_pcm_range.argtypes = [C.c_uint32, C.c_uint32, i16p]

@@ -419,6 +419,96 @@ int raise_lds_limit(int device, const void *fn, uint32_t lds)
  * discriminator and compares with the host twin's IEEE division: a device that answers differently is refused at
  * commit instead of producing PCM that is one LSB off once in 10^7 samples.
  */
+/* What v_rcp_f32 returns for every binary32 significand, as one number: the difference (in ulps) between the device's
+ * reciprocal of 2^23 + i and the correctly rounded one, hashed with i; the counts of -1 / 0 / +1 / anything else beside it.
+ * tools/div_proof.c's enumeration holds for the table this hash stands for (MFM_RCP_TABLE_HASH_GFX950, read off an MI355X
+ * by tools/rcp_check.hip: 89 % correctly rounded, 9 % one ulp low, 2 % one ulp high). */
+__global__ void mfm_rcp_table_kernel(unsigned long long *acc)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float b = (float)((1u << 23) + i);
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float rn = __fdiv_rn(1.0f, b);
+    const int32_t d = (int32_t)__float_as_uint(r) - (int32_t)__float_as_uint(rn);
+    unsigned long long h = (unsigned long long)(uint32_t)(d + 8) * ((unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
+    for (int o = 32; o > 0; o >>= 1) {
+        h += __shfl_down(h, o);
+    }
+    const unsigned long long lo = __ballot(d == -1), eq = __ballot(d == 0), hi = __ballot(d == 1);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&acc[0], h);
+        atomicAdd(&acc[1], (unsigned long long)__popcll(lo));
+        atomicAdd(&acc[2], (unsigned long long)__popcll(eq));
+        atomicAdd(&acc[3], (unsigned long long)__popcll(hi));
+        atomicAdd(&acc[4], 64ull - (unsigned long long)(__popcll(lo) + __popcll(eq) + __popcll(hi)));
+    }
+}
+
+/* the discriminator's division against the IEEE quotient on pseudo-random significand pairs and on the divisors next to a
+ * power of two (the classical hard ones): the net under a device whose reciprocal table is not the one of the proof */
+__global__ void mfm_div_sweep_kernel(uint32_t seed, uint32_t per_thread, unsigned long long *bad)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = ((uint64_t)seed << 32) ^ ((uint64_t)t * 0xD1B54A32D192ED03ull + 0x9E3779B97F4A7C15ull);
+    uint32_t wrong = 0;
+    for (uint32_t k = 0; k < per_thread; k++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        uint32_t A = (1u << 23) | ((uint32_t)x & 0x7fffffu), B = (1u << 23) | ((uint32_t)(x >> 32) & 0x7fffffu);
+        if ((k & 3u) == 3u) {
+            const uint32_t near = (uint32_t)(x >> 55) & 0xffu; /* divisors within 256 of 2^24 and of 2^23 */
+            B = (k & 4u) ? (1u << 24) - 1u - near : (1u << 23) + near;
+        }
+        const float b = (float)B;
+        const float a = A <= B ? (float)A : 0.5f * (float)A;
+        wrong += mfm_div_unit(a, b) != __fdiv_rn(a, b) ? 1u : 0u;
+    }
+    if (wrong) {
+        atomicAdd(bad, (unsigned long long)wrong);
+    }
+}
+
+int rcp_table_read(int device, uint64_t out[5])
+{
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 5 * sizeof(unsigned long long)));
+    int rc = MFM_OK;
+    if (hipMemset(d, 0, 5 * sizeof(unsigned long long)) != hipSuccess) {
+        rc = fail(MFM_E_DEVICE, "hipMemset failed");
+    } else {
+        hipLaunchKernelGGL(mfm_rcp_table_kernel, dim3((1u << 23) / 256u), dim3(256), 0, nullptr, d);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(MFM_E_DEVICE, "the reciprocal-table kernel failed on device %d", device);
+        }
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int div_sweep(int device, uint64_t *bad, uint64_t *tried)
+{
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
+    int rc = MFM_OK;
+    const uint32_t blocks = 4096, threads = 256, per_thread = 256; /* 2^28 quotients, a few ms */
+    if (hipMemset(d, 0, sizeof(unsigned long long)) != hipSuccess) {
+        rc = fail(MFM_E_DEVICE, "hipMemset failed");
+    } else {
+        hipLaunchKernelGGL(mfm_div_sweep_kernel, dim3(blocks), dim3(threads), 0, nullptr, 0x5eed5eedu, per_thread, d);
+        unsigned long long h = 0;
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(MFM_E_DEVICE, "the division sweep failed on device %d", device);
+        }
+        *bad = h;
+        *tried = (uint64_t)blocks * threads * per_thread;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int division_selftest(int device, int variant)
 {
     static std::mutex mu;
@@ -451,9 +541,35 @@ int division_selftest(int device, int variant)
             }
         }
     }
+    if (rc == MFM_OK) {
+        /* once per device: is v_rcp_f32's table the one tools/div_proof.c enumerated?  If it is not (another stepping, other
+         * microcode), the three quotients above are no proof: 2^28 quotients against the IEEE division decide, and a
+         * single wrong one refuses the device. */
+        static std::map<int, int> table_done;
+        auto td = table_done.find(device);
+        if (td == table_done.end()) {
+            uint64_t t[5] = { 0, 0, 0, 0, 0 };
+            int trc = rcp_table_read(device, t);
+            if (trc == MFM_OK && t[0] != MFM_RCP_TABLE_HASH_GFX950) {
+                uint64_t bad = 0, tried = 0;
+                trc = div_sweep(device, &bad, &tried);
+                if (trc == MFM_OK && bad != 0) {
+                    trc = fail(MFM_E_DEVICE, "device %d: v_rcp_f32 is not gfx950's table (hash %016llx, %llu / %llu / %llu one ulp low / exact / "
+                                             "high) and %llu of %llu quotients differ from the IEEE division", device,
+                               (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2], (unsigned long long)t[3],
+                               (unsigned long long)bad, (unsigned long long)tried);
+                }
+            }
+            table_done[device] = trc;
+            rc = trc;
+        } else if (td->second != MFM_OK) {
+            rc = fail(td->second, "the reciprocal-table check failed on device %d before", device);
+        }
+    }
     done[std::make_pair(device, variant)] = rc;
     return rc;
 }
+
 
 /* which instance runs blocks of each input format; its LDS limit is raised here, once (commit, on the engine's device) */
 int select_kernels(mfm_engine *e)
@@ -2856,6 +2972,27 @@ static float g_atan_tbl[257];
 static float2 g_atan_lut[256];
 static bool g_atan_ok = false;
 static void atan_tbl_once(void);
+
+int mfm_devtest_rcp_table(int device, uint64_t *hash, uint64_t counts[4], uint64_t *sweep_bad, uint64_t *sweep_tried)
+{
+    if (!hash || !counts) {
+        return fail(MFM_E_INVAL, "bad argument");
+    }
+    uint64_t t[5];
+    int rc = rcp_table_read(device, t);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    *hash = t[0];
+    counts[0] = t[1];
+    counts[1] = t[2];
+    counts[2] = t[3];
+    counts[3] = t[4];
+    if (sweep_bad && sweep_tried) {
+        rc = div_sweep(device, sweep_bad, sweep_tried);
+    }
+    return rc;
+}
 
 /* the discriminator as the kernels of variant 0 / 1 / 2 compute it, on the device, for caller-supplied products */
 int mfm_devtest_discriminate(int variant, const int32_t *s_re, const int32_t *s_im, size_t n, int16_t *pcm_out, int device)
