@@ -276,7 +276,8 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
 
 
 def library_sha16(pkg):
-    """first 16 hex digits of the SHA-256 over the kernel sources the library is built from (tsl-sdr_amd/csrc/*, the Makefile) and
+    """first 16 hex digits of the SHA-256 over the channel kernels' sources (tsl-sdr_amd/csrc/mfm_kernel*, mfm_v3_device.h,
+    mfm_numerics.h, the Makefile - not the engine: which instance ran is in instance_name()) and
     the ROCm release: ties the instruction counts in profiles/ to the code they belong to.  (Not the .so's own hash: the
     fat binary embeds the build directory, the same sources built elsewhere hash differently - tried.)"""
     import glob
@@ -284,7 +285,9 @@ def library_sha16(pkg):
     h = hashlib.sha256()
     base = os.path.join(ROOT, "tsl-sdr_amd")
     try:
-        for f in sorted(glob.glob(os.path.join(base, "csrc", "*")) + [os.path.join(base, "Makefile")]):
+        kernel_files = [f for f in glob.glob(os.path.join(base, "csrc", "*"))
+                        if os.path.basename(f).startswith("mfm_kernel") or os.path.basename(f) in ("mfm_v3_device.h", "mfm_numerics.h")]
+        for f in sorted(kernel_files + [os.path.join(base, "Makefile")]):
             if os.path.isfile(f):
                 h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
         try:   # (a file, not `hipcc --version`: no child process is started from a process that has touched the GPU)

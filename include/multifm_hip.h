@@ -732,7 +732,7 @@ int mfm_devtest_discriminate(int variant, const int32_t *s_re, const int32_t *s_
  * on 2^28 significand pairs.  mfm_engine_commit() compares the hash with MFM_RCP_TABLE_HASH_GFX950 - the table the
  * division's correctness proof (tools/div_proof.c) enumerated - once per device, and falls back to the sweep when it
  * differs: a device with another reciprocal table is accepted only if not one quotient is off. */
-#define MFM_RCP_TABLE_HASH_GFX950 0x0ull /* (read off an MI355X: tests/test_gpu_parity.py checks it there) */
+#define MFM_RCP_TABLE_HASH_GFX950 0x706d94bc005bcc1aull /* (read off an MI355X: tests/test_gpu_parity.py checks it there) */
 int mfm_devtest_rcp_table(int device, uint64_t *hash, uint64_t counts[4], uint64_t *sweep_bad, uint64_t *sweep_tried);
 /* the device's table-driven BCH(31,21) decode (syndrome bytes -> 1024-entry flip table), on the host */
 int mfm_hosttwin_bch3121_decode(uint32_t *word);

@@ -25,7 +25,7 @@ MFM_F_STREAM_TAPS = 0x80
 MFM_F_GATHER = 0x100
 MFM_F_OVERLAP = 0x200
 MFM_F_V3L_ONE_ROW_BLOCK = 0x400
-MFM_RCP_TABLE_HASH_GFX950 = 0x0  # include/multifm_hip.h
+MFM_RCP_TABLE_HASH_GFX950 = 0x706D94BC005BCC1A  # include/multifm_hip.h
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
 # every symbol include/multifm_hip.h declares (tests check the library exports each one)
