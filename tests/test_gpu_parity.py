@@ -1002,6 +1002,7 @@ def test_reciprocal_table_is_the_one_the_division_proof_enumerated(pkg):
     THIS device: it must be the table the header names (commit() checks the same and falls back to a 2^28-quotient sweep
     against the IEEE division otherwise), with the proof's shares - 89 % correctly rounded, 9 % one ulp low, 2 % high - and
     the sweep itself must find nothing."""
+    import ctypes as C
     lib = pkg.load_library()
     h, bad, tried = C.c_uint64(), C.c_uint64(), C.c_uint64()
     counts = (C.c_uint64 * 4)()
