@@ -1063,9 +1063,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
                         w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
 #if MFM3_NONTEMPORAL & 2
-                        typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
-                        mfm_v2u wv = { w.x, w.y };
-                        __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]));
+                        mfm3_store_pcm4(L.pcm, voff[c], w.x, w.y);
 #else
                         *reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]) = w;
 #endif

@@ -34,7 +34,7 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM3_NONTEMPORAL
 #define MFM3_NONTEMPORAL 2 /* bit 1: the PCM stores carry the non-temporal hint - the 8-byte stores of a tile leave L2 as whole
                               lines instead of being written back piecemeal (WRITE_SIZE 1.23 x the PCM bytes without it,
-                              0.98 x with it) and stop pushing the rotator tables out; bit 0 (A/B builds): the image loads
+                              0.98 x with it) - and, since round 5, system scope (mfm3_store_pcm4); bit 0 (A/B builds): the image loads
                               too - wrong, the slices of a chunk share the image through L2 (fetch + 40 %, 4 % slower) */
 #endif
 #ifndef MFM3_SP
@@ -164,6 +164,18 @@ static __device__ __forceinline__ uint32_t mfm3_sign_flip(uint32_t f, uint32_t s
     return q;
 }
 
+/* A lane's four PCM samples of one channel (8 bytes; the 16 lanes of a row write one 128-byte line between them): a
+ * system-scope non-temporal store.  With the hint alone (`nt`) the lines still live in L2 for a while and the PCM stream -
+ * 5.3 x the input's bytes at 1024 channels - pushes the rotator tables out between two uses; written through at system scope
+ * WRITE_SIZE is the PCM bytes to the byte (1 398 145 KB per 2^26-sample block at 1024 channels) and the tables' re-fetches drop
+ * by a fifth: L2-miss traffic 1.27 -> 1.155 x algorithmic, time unchanged (profiles/r05_store_policy.txt). */
+static __device__ __forceinline__ void mfm3_store_pcm4(void *base, uint32_t byte_off, uint32_t w0, uint32_t w1)
+{
+    typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
+    const mfm_v2u wv = { w0, w1 };
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1 nt" ::"v"(byte_off), "v"(wv), "s"(base) : "memory");
+}
+
 static __device__ __forceinline__ uint32_t mfm3_opaque(uint32_t v)
 {
     asm volatile("" : "+v"(v));
@@ -256,7 +268,6 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         z[i] = __builtin_fmaf(__builtin_fmaf(-mx[i], z[i], mn[i]), r1, z[i]);
 #endif
     }
-    typedef const __attribute__((address_space(3))) float *lds_fp;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
@@ -280,6 +291,7 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
 #else
         const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x4A000000u);
 #endif
+        typedef const __attribute__((address_space(3))) float *lds_fp;
         lds_fp p = (lds_fp)(uintptr_t)addr;
         t0[i] = p[0];
         dt[i] = p[256];
