@@ -520,7 +520,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     if (!mfm3_decode_item(L, item, &chunk, &slice)) {
         return;
     }
-    const uint64_t stamp_t0 = L.cyc ? __builtin_amdgcn_s_memtime() : 0ull, stamp_r0 = L.cyc ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const uint32_t stamp_t0 = mfm3_stamp_lo(L.cyc ? __builtin_amdgcn_s_memtime() : 0ull), stamp_r0 = mfm3_stamp_lo(L.cyc ? __builtin_amdgcn_s_memrealtime() : 0ull);
     /* chunk j = tiles [j * ntiles / nchunks, (j + 1) * ntiles / nchunks): lengths differ by at most one tile */
     uint32_t tile = (uint32_t)(((uint64_t)chunk * L.ntiles) / L.nchunks);
     uint32_t tend = (uint32_t)(((uint64_t)(chunk + 1u) * L.ntiles) / L.nchunks);

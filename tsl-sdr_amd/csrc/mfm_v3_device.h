@@ -318,13 +318,22 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
 #endif
 }
 
+/* low word of a clock stamp, pinned to ONE scalar register (left alone the compiler keeps the 64-bit pair alive to the end) */
+static __device__ __forceinline__ uint32_t mfm3_stamp_lo(uint64_t t)
+{
+    uint32_t lo = (uint32_t)t;
+    asm volatile("" : "+s"(lo));
+    return lo;
+}
+
 /* the workgroup's duration in shader-clock ticks and in 100 MHz reference ticks, folded into the launch's maximum
- * (mfm_launch_v3::cyc); t0 / r0: the stamps taken at the workgroup's start */
-static __device__ __forceinline__ void mfm3_stamp_end(const mfm_launch_v3 &L, uint64_t t0, uint64_t r0)
+ * (mfm_launch_v3::cyc); t0 / r0: the low words of the stamps taken at the workgroup's start (a launch is shorter than 2^32
+ * ticks of either clock; two SGPRs across the kernel instead of four - the 128-register instances parked four in a VGPR lane) */
+static __device__ __forceinline__ void mfm3_stamp_end(const mfm_launch_v3 &L, uint32_t t0, uint32_t r0)
 {
     if (L.cyc != nullptr && threadIdx.x == 0) {
-        const uint64_t tag = (uint64_t)(L.cyc_tag & 0xffffffu) << 40, mask = (1ull << 40) - 1ull;
-        const uint64_t dt = (__builtin_amdgcn_s_memtime() - t0) & mask, dr = (__builtin_amdgcn_s_memrealtime() - r0) & mask;
+        const uint64_t tag = (uint64_t)(L.cyc_tag & 0xffffffu) << 40;
+        const uint64_t dt = (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - t0), dr = (uint32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - r0);
         atomicMax(L.cyc, (unsigned long long)(tag | dt));
         atomicMax(L.cyc + 1, (unsigned long long)(tag | dr));
     }
