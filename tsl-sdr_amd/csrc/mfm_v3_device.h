@@ -179,7 +179,7 @@ static __device__ __forceinline__ void mfm3_store_pcm4(void *base, uint32_t byte
 #if MFM3_PCM_SYSTEM_SCOPE
     asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1 nt" ::"v"(byte_off), "v"(wv), "s"(base) : "memory");
 #else
-    asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(byte_off), "v"(wv), "s"(base) : "memory"); /* (A/B builds: rounds 4's policy) */
+    __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u *>(reinterpret_cast<uint8_t *>(base) + byte_off));
 #endif
 }
 
