@@ -1380,10 +1380,11 @@ static int commit_locked(struct mfm_engine *e)
                 continue;
             }
             const uint32_t opi = 16u * ng;
-            const uint32_t plane = (opi + std::max(reach, reach_read)) * rs_l;
+            const uint32_t plane_used = (opi + std::max(reach, reach_read)) * rs_l;
+            const uint32_t plane = mfm_v3l_plane_pitch(rbw); /* a constant: the low plane's reads are "high plane + immediate" */
             const uint32_t nstage4 = ((opi + reach) * D + 3u) / 4u;
             const uint32_t nch = (nstage4 + 511u) / 512u;
-            if (nch > MFM_V3_CH_MAX || plane >= 65536u || kq_inst > e->m_ks) {
+            if (nch > MFM_V3_CH_MAX || plane_used > plane || kq_inst > e->m_ks) {
                 continue;
             }
             /* the instance's count of chunks (a surplus chunk is loaded and not stored); 16-bit offsets where no chunk straddles rows */

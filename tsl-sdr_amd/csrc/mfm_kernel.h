@@ -166,6 +166,14 @@ static inline uint32_t mfm_v3l_built_nh(uint32_t kq, uint32_t nh)
     return b < kq ? b : kq;
 }
 /* ... and the staging chunks per thread */
+/* bytes between the two byte planes of an image of the long-filter kernel (not the shifted-copies form): a constant of the
+ * row-block count, so that a fragment's low-plane read is the high-plane read's address + an instruction immediate (half
+ * the address arithmetic of the matrix phase); the engine takes geometries whose planes fit and lays the buffers out at twice
+ * this pitch */
+static inline uint32_t mfm_v3l_plane_pitch(uint32_t rb)
+{
+    return rb == 2u ? 24576u : 31744u;
+}
 static inline uint32_t mfm_v3l_built_nch(uint32_t nch)
 {
     return nch <= 4u ? 4u : 8u;

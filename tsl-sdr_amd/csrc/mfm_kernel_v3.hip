@@ -1174,7 +1174,9 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
         const uint32_t nch4 = (L->nstage4 + MFM3_NT - 1) / MFM3_NT;
         if (dbg_iq || nch4 < 1 || nch4 > MFM_V3_CH_MAX || (L->ng != 1u && L->ng != 2u && L->ng != 4u) || (L->rb != 1u && L->rb != 2u) ||
             L->kq_used > L->kq || L->nh > L->kq ||
-            L->kq != mfm_v3l_built_kq(L->kq) || (L->in8 != 0u && L->in8 != 7u && L->in8 != 14u)) {
+            L->kq != mfm_v3l_built_kq(L->kq) || (L->in8 != 0u && L->in8 != 7u && L->in8 != 14u) ||
+            /* (a description with the LDS layout filled in: the plane pitch the instances' immediates assume) */
+            (!L->shift && L->plane_pitch != 0u && L->plane_pitch != mfm_v3l_plane_pitch(L->rb))) {
             return hipErrorInvalidValue;
         }
         switch (L->kq) {

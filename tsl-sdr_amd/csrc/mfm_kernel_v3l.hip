@@ -345,10 +345,15 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
             asm volatile("v_add_u32 %0, %1, %2" : "=v"(at) : "s"(gbase), "v"(boff[st % KQ]));
             asm volatile("ds_read_b128 %0, %1" : "=v"(bh[st % SLOTS]) : "v"(at) : "memory");
             if constexpr (!IN8) {
-                const uint32_t gbase_l = gbase + plane_pitch;
-                uint32_t at_l;
-                asm volatile("v_add_u32 %0, %1, %2" : "=v"(at_l) : "s"(gbase_l), "v"(boff[st % KQ]));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bl[st % SLOTS]) : "v"(at_l) : "memory");
+                if constexpr (SHIFT) {
+                    const uint32_t gbase_l = gbase + plane_pitch;
+                    uint32_t at_l;
+                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(at_l) : "s"(gbase_l), "v"(boff[st % KQ]));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bl[st % SLOTS]) : "v"(at_l) : "memory");
+                } else {
+                    /* the low plane lies a constant behind the high one (mfm_v3l_plane_pitch): the same address register */
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[st % SLOTS]) : "v"(at), "n"(RB == 2 ? 24576 : 31744) : "memory");
+                }
             }
         };
 #pragma unroll
