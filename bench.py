@@ -275,6 +275,14 @@ def flex_chain(pkg, torch, fs, decim, taps, offs, gains, block, iters=12):
             "ms_per_block": total, "value": block * len(offs) / total / 1e3, "unit": "MSamp/s x channels"}
 
 
+def sparse_timing(steps):
+    """HIP event pairs on one launch in four (True) or on every launch (False; BENCH_EVENTS=all).  An event pair is two
+    command-processor packets between two kernels: on every launch of the driver's 20-step run they cost 2 % of `value`
+    (profiles/r05_step_overheads.txt: ms_per_step 0.1183 against 0.1160 over four alternating runs each), so the events stay
+    sparse and EVERY launch is timed by the kernel's own 100 MHz stamps instead (`roofline.clocks.kernel_ms_by_stamps`)."""
+    return os.environ.get("BENCH_EVENTS", "sparse") != "all"
+
+
 def library_sha16(pkg):
     """first 16 hex digits of the SHA-256 over the channel kernels' sources (tsl-sdr_amd/csrc/mfm_kernel*, mfm_v3_device.h,
     mfm_numerics.h, the Makefile - not the engine: which instance ran is in instance_name()) and
@@ -371,6 +379,9 @@ def launch_clocks(eng, n):
     sh, ref = sh[ok].astype(np.float64), ref[ok].astype(np.float64)
     return {"launches": int(ok.sum()), "shader_ticks_median": float(np.median(sh)), "ref_ticks_100mhz_median": float(np.median(ref)),
             "kernel_ms_by_ref_ticks": float(np.median(ref)) / 1e5,
+            # every launch of the timed region, first workgroup's start to last workgroup's end (no dispatch latency in it)
+            "kernel_ms_by_stamps": {"launches": int(ok.sum()), "mean": float(np.mean(ref)) / 1e5, "min": float(np.min(ref)) / 1e5,
+                                    "median": float(np.median(ref)) / 1e5, "max": float(np.max(ref)) / 1e5},
             "sclk_mhz_effective": float(np.median(sh / ref)) * 100.0,
             "source": "s_memtime / s_memrealtime stamped by the kernel's workgroups, this run"}
 
@@ -913,7 +924,7 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
     b = pkg.binding
     S = len(devices)
     g = b.Group(fs, decim, block, devices=tuple(devices),
-                flags=b.MFM_F_DEVICE_ONLY | b.MFM_F_TIMING | (b.MFM_F_TIMING_SPARSE if steps >= 64 else 0) |
+                flags=b.MFM_F_DEVICE_ONLY | b.MFM_F_TIMING | (b.MFM_F_TIMING_SPARSE if sparse_timing(steps) else 0) |
                 (b.MFM_F_GROUP_SHARED_DEVICE if shared else 0),
                 exchange=b.MFM_X_RCCL_ALLGATHER if S > 1 else b.MFM_X_AUTO)
     for o, gn in zip(offs, gains):
@@ -1108,7 +1119,7 @@ def main():
     eng = pkg.Engine(fs, decim, block, device=local_rank,
                      # one launch in four carries the event pair; runs of fewer than 64 steps time every launch (the driver's 20)
                      flags=pkg.binding.MFM_F_DEVICE_ONLY | pkg.binding.MFM_F_TIMING |
-                     (pkg.binding.MFM_F_TIMING_SPARSE if args.steps >= 64 else 0) |
+                     (pkg.binding.MFM_F_TIMING_SPARSE if sparse_timing(args.steps) else 0) |
                      (pkg.binding.MFM_F_OVERLAP if args.overlap else 0) |
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
                      (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0) |

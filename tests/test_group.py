@@ -317,7 +317,10 @@ def test_bench_line_carries_the_group_path_and_the_north_star_shape():
     assert ns["channels"] == 1024 and ns["kernel_variant"] == 2 and 0.0 < ns["roofline"]["frac"] < ns["bound_frac"]["at_nominal_5000_tops"] < 1.0, ns
     clk = line["roofline"]["clocks"]
     assert clk and clk["launches"] == 20 and 500.0 < clk["sclk_mhz_effective"] < 3000.0, clk
-    assert line["roofline"]["timed_launches"] == 20  # fewer than 64 steps: every launch carries the event pair
+    # one launch in four carries the HIP event pair (on every launch the packets cost 2 % of `value`); every launch is timed by the
+    # kernel's own 100 MHz stamps
+    assert line["roofline"]["timed_launches"] == 5 and clk["kernel_ms_by_stamps"]["launches"] == 20
+    assert 0.0 < clk["kernel_ms_by_stamps"]["min"] <= clk["kernel_ms_by_stamps"]["median"] <= clk["kernel_ms_by_stamps"]["max"] < 10.0
 
 
 @pytest.mark.gpu

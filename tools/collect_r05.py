@@ -252,7 +252,9 @@ gen = [f"Generated by `tools/collect_r05.py` from `gpurun_out/r05e` (`tools/prof
        + f"; kernel sources sha256[:16] `{lib_sha}`.  Edit the script, not this text.", ""]
 gen.append(f"* Headline (`r05_bench_n1.json`, the driver's command `python bench.py --gpus 1 --steps 20 --warmup 5`): "
            f"**{head['value'] / 1e6:.1f} M MSamp/s x channels**, `ms_per_step` {head['ms_per_step']:.4f}, kernel {hr['kernel_ms']:.4f} ms "
-           f"(HIP events on {hr.get('timed_launches')} of {hr.get('launches')} timed launches - every one), `roofline.frac` **{hr['frac']:.3f}**, "
+           f"(HIP events on {hr.get('timed_launches')} of {hr.get('launches')} timed launches; all {((hr.get('clocks') or {}).get('kernel_ms_by_stamps') or {}).get('launches', '?')} by the kernel's "
+           f"own stamps: mean {((hr.get('clocks') or {}).get('kernel_ms_by_stamps') or {}).get('mean', nan):.4f} ms, min {((hr.get('clocks') or {}).get('kernel_ms_by_stamps') or {}).get('min', nan):.4f}, "
+           f"max {((hr.get('clocks') or {}).get('kernel_ms_by_stamps') or {}).get('max', nan):.4f}, first workgroup's start to last workgroup's end), `roofline.frac` **{hr['frac']:.3f}**, "
            f"`verified` {head.get('verified')}.")
 clk = hr.get("clocks") or {}
 bs = hr.get("board_sample") or {}
