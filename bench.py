@@ -966,9 +966,11 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
     eng0 = g.shard_engine(0)
     cycles = launch_clocks(eng0, min(steps, 1024))
     sampler = BoardSampler(0)   # behind the timed region, while the same steps keep running (see main())
-    for k in range(max(steps, 16)):
+    k = 0
+    while k < 16 or (sampler.thread.is_alive() and k < 4000):
         step()
-        if k == 2:
+        k += 1
+        if k == 3:
             sampler.start()
     g.sync()
     smi = sampler.result()
@@ -1263,9 +1265,13 @@ def main():
     smi = None
     if os.environ.get("BENCH_NO_BOARD_SAMPLE") != "1":
         sampler = BoardSampler(local_rank) if rank == 0 else None
-        for k in range(max(args.steps, 16)):
+        k = 0
+        # the workload keeps running for as long as the read takes (2-4 ms: a reading taken after the queue has drained shows the
+        # idle clock)
+        while k < 16 or (sampler is not None and sampler.thread.is_alive() and k < 4000):
             step()
-            if sampler and k == 2:
+            k += 1
+            if sampler and k == 3:
                 sampler.start()
         fence()
         if sampler:
