@@ -1049,8 +1049,27 @@ def idle_rank(args):
     dist.destroy_process_group()
 
 
+def start_watchdog(args):
+    """N > 1 only: a run that does not finish (a collective that never completes on hardware this code has not met) ends with
+    a message and a non-zero exit instead of sitting there until the driver's limit.  BENCH_WATCHDOG_S, default 900."""
+    if args.gpus <= 1:
+        return
+    import threading
+    limit = float(os.environ.get("BENCH_WATCHDOG_S", "900"))
+
+    def fire():
+        sys.stderr.write(f"bench.py: no result after {limit:.0f} s with --gpus {args.gpus} (rank {os.environ.get('RANK', '0')}): giving up\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+
+
 def main():
     args = parse()
+    start_watchdog(args)
     group = args.exchange == "group" and (args.gpus > 1 or args.group_shards > 0)
     if group:
         world = int(os.environ.get("WORLD_SIZE", "1"))
