@@ -240,7 +240,7 @@ def test_tsl_names_of_the_compat_tree(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run(_link_with_host(exe, [obj]), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    env = dict(os.environ)  # (tools/sanitize_cpu.sh: the host library is then the ASan build and wants its runtime preloaded)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1]) == {"bad": 0}, r.stdout + r.stderr
 
@@ -284,7 +284,7 @@ def test_reference_driver_and_rtl_sdr_front_end_compile_and_link_unchanged(tmp_p
     r = subprocess.run(_link_with_host(exe, objs, "-L" + str(fake_dir), "-l:librtlsdr.so.0", "-Wl,-rpath," + str(fake_dir)),
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "FAKE_RTLSDR_FILE")}
+    env = {k: v for k, v in os.environ.items() if k not in ("FAKE_RTLSDR_FILE",)}
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 1 and "usage:" in r.stderr and "NO-DEVS-FOUND" in r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60, env=dict(env, FAKE_RTLSDR_FILE="/dev/null"))
@@ -305,7 +305,7 @@ def test_rtl_sdr_front_end_without_the_library_and_usage_listing(tmp_path):
     (multifm/multifm.c:132-135); with the library (the test double) the usage text lists the devices (:57-77)."""
     cj = tmp_path / "c.json"
     cj.write_text(json.dumps({"device": {"type": "rtlsdr", "deviceIndex": 0}, "sampleRateHz": 1200000, "centerFreqHz": 152000000}))
-    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "LD_LIBRARY_PATH", "FAKE_RTLSDR_FILE")}
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "FAKE_RTLSDR_FILE")}
     r = subprocess.run([MULTIFM, str(cj)], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode != 0 and "RTLSDR-NOT-SUPPORTED" in r.stderr, r.stderr
     fake_dir = tmp_path / "fakelib"

@@ -7,10 +7,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g"
 cd "$ROOT/tsl-sdr_amd/host"
-for f in mfm_tsl mfm_config mfm_receiver mfm_file_if mfm_pager_pocsag mfm_pager_flex; do
+for f in mfm_tsl mfm_config mfm_receiver mfm_file_if mfm_rtl_sdr_if mfm_pager_pocsag mfm_pager_flex; do
   gcc -std=gnu11 $SAN -fPIC -D_GNU_SOURCE -I. -I../../include -c -o $T/$f.o $f.c
 done
-gcc -shared $SAN -o $T/libmfm_host.so $T/*.o -L.. -lmultifm_hip -Wl,-rpath,$ROOT/tsl-sdr_amd -lpthread -lm
+gcc -shared $SAN -o $T/libmfm_host.so $T/*.o -L.. -lmultifm_hip -Wl,-rpath,$ROOT/tsl-sdr_amd -lpthread -lm -ldl
 cd "$ROOT/oracle"
 gcc -std=gnu11 $SAN -march=x86-64-v3 -ffp-contract=off -fwrapv -fPIC -D_GNU_SOURCE -shared -o $T/liboracle.so \
     mfm_oracle.c pocsag_oracle.c f32_oracle.c flex_oracle.c -lm -lpthread
