@@ -353,6 +353,73 @@ def test_pushes_out_of_page_locked_memory_with_copy_tickets(pkg, ora, coalesce):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("coalesce,max_run", [(0, 4), (300000, 16), (300000, 64)])
+def test_runs_of_neighbouring_pool_frames_as_one_copy_command(pkg, ora, coalesce, max_run):
+    """mfm_engine_push_pinned_run (round 5): frames of ONE page-locked arena that lie `stride` bytes apart - a sample_buf header
+    between the data of two frames, as in host/mfm_receiver.c's pool - go to the device as one strided copy command and are
+    accepted as one block.  `accepted` may be smaller than offered (the buffer being filled is full, or the gathering policy
+    wants a launch in between): the rest is offered again.  int16 and byte frames, frames reused (overwritten) as soon as their
+    ticket is through; the PCM stream against the oracle."""
+    import ctypes
+    b = pkg.binding
+    lib = pkg.load_library()
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=10)
+    nfr, spf, hdr = 96, 4096, 48                       # frames of 4096 samples with a 48-byte header in front of each
+    stride = hdr + spf * 4
+    arena = lib.mfm_host_alloc(nfr * stride)
+    assert arena
+    eng = pkg.Engine(fs, decim, spf * max_run, device=0, coalesce_samples=coalesce)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    rng = np.random.RandomState(11)
+    iq, parts, qparts = [], [], []
+    tickets = [0] * nfr
+    commands = offered = 0
+    for rnd in range(3):
+        fmt = b.MFM_IN_CS16 if rnd != 1 else b.MFM_IN_RTLSDR_U8
+        per = spf if fmt == b.MFM_IN_CS16 else 2 * spf     # a frame of bytes holds twice the samples
+        # the front end fills every frame of the pool (after its last copy is through) ...
+        for f in range(nfr):
+            assert lib.mfm_engine_copy_wait(eng.h, tickets[f]) == 0
+            if fmt == b.MFM_IN_CS16:
+                blk = rng.randint(-20000, 20000, size=(per, 2)).astype(np.int16)
+                iq.append(blk)
+            else:
+                blk = rng.randint(0, 256, size=(per, 2)).astype(np.uint8)
+                iq.append(ora.unpack_bytes(blk, fmt).reshape(-1, 2))
+            ctypes.memset(arena + f * stride, 0xa5, stride)
+            ctypes.memmove(arena + f * stride + hdr, blk.ctypes.data, blk.nbytes)
+        # ... and the submit thread sends them in runs
+        f = 0
+        while f < nfr:
+            want_n = min(int(rng.randint(1, max_run + 1)), nfr - f)
+            t, took = ctypes.c_uint64(), ctypes.c_size_t()
+            rc = lib.mfm_engine_push_pinned_run(eng.h, arena + f * stride + hdr, stride, per, want_n, fmt, ctypes.byref(t), ctypes.byref(took))
+            if rc == b.MFM_E_BUSY:
+                _drain(eng, parts, qparts)
+                continue
+            assert rc == 0, lib.mfm_last_error()
+            assert 1 <= took.value <= want_n
+            for k in range(took.value):
+                tickets[f + k] = t.value
+            f += took.value
+            commands += 1
+            offered += want_n
+    _finish(eng, parts, qparts)
+    if coalesce:
+        assert commands < 3 * nfr                      # fewer commands than frames: runs were taken
+    else:
+        assert commands == 3 * nfr                     # without gathering every frame is a launch of its own: one is accepted at a time
+    eng.close()
+    lib.mfm_host_free(arena)
+    iq = np.concatenate(iq)
+    cre, cim, incr = _tables(ora, taps, offs, fs, decim, gains)
+    want, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
+    got = np.concatenate([p[1] for p in parts], axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("geoms,kernel", [(((48, 64), (56, 64)), "auto"), (((25, 128), (30, 128), (12, 40)), "mfma1"),
                                           (((96, 128), (96, 100), (32, 32)), "auto")])
 def test_two_engines_sharing_a_kernel_instance_keep_their_lds(pkg, ora, geoms, kernel):

@@ -1012,3 +1012,35 @@ def test_reciprocal_table_is_the_one_the_division_proof_enumerated(pkg):
     assert 0.87 < exact / (1 << 23) < 0.91 and 0.07 < low / (1 << 23) < 0.11 and 0.01 < high / (1 << 23) < 0.03, (low, exact, high)
     assert bad.value == 0 and tried.value == 1 << 28, (bad.value, tried.value)
     assert h.value == pkg.binding.MFM_RCP_TABLE_HASH_GFX950, hex(h.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nch", [256, 130, 70])
+def test_long_filter_row_block_forms_give_the_same_bits(pkg, ora, nch):
+    """mfm_kernel_v3l.hip at configs[4]'s geometry (decimation 400, 512 taps): more than 64 channels run two row blocks per wave
+    (128-channel slices, quarter-tile images) unless MFM_F_V3L_ONE_ROW_BLOCK asks for the other form; both, and the first
+    generation, against the oracle - int16 blocks of ragged lengths and RTL-SDR bytes."""
+    b = pkg.binding
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg5_airspy", nr_channels=nch)
+    n = decim * 900 + len(taps) + 17
+    iq = pkg.synth.random_iq(n, seed=nch)
+    seen = set()
+    for flags in (0, b.MFM_F_V3L_ONE_ROW_BLOCK, b.MFM_F_FORCE_MFMA_V1):
+        eng = _mk_engine(pkg, fs, decim, taps, offs, gains=gains, max_block=1 << 17, flags=flags)
+        st = eng.stats()
+        eng.close()
+        assert st["kernel_variant"] == (1 if flags == b.MFM_F_FORCE_MFMA_V1 else 2) and st["taps_resident"] == 1, st
+        seen.add((st["kernel_variant"], st["lds_bytes"]))
+        for block in (1 << 17, 50001):
+            eng = _mk_engine(pkg, fs, decim, taps, offs, gains=gains, max_block=block, flags=flags)
+            cre, cim, incr = _oracle_tables(eng, len(offs))
+            pcm, _ = eng.run(iq, block)
+            eng.close()
+            ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
+            assert pcm.shape == ref.shape and np.array_equal(pcm, ref), (flags, block, int((pcm != ref).sum()) if pcm.shape == ref.shape else pcm.shape)
+        # the byte form of the same kernels
+        raw = np.random.RandomState(nch).randint(0, 256, size=(n, 2)).astype(np.uint8)
+        if flags != b.MFM_F_FORCE_MFMA_V1:
+            got, want, st8 = _ingest_8bit(pkg, ora, fs, decim, taps, offs, [(raw[:70001], 3), (raw[70001:], 3)], 1 << 19, flags=flags)
+            assert st8["kernel_variant"] == 2 and st8["launches_8bit"] > 0 and got.shape == want.shape and np.array_equal(got, want)
+    assert len(seen) == 3, seen                       # three different kernels ran (the two long-filter forms differ in their LDS)
