@@ -503,3 +503,33 @@ def test_engines_driven_from_their_own_threads(pkg, ora):
         cre, cim, incr = (np.stack([t[i] for t in tabs]) for i in range(3))
         ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=4)
         assert pcm.shape == ref.shape and np.array_equal(pcm, ref), shapes[k]
+
+
+def test_link_probe_and_input_room(pkg):
+    """mfm_link_probe / mfm_link_probe_runs (what bench.py's end_to_end.link reports): positive rates for the command shapes the
+    host uses; mfm_engine_input_room: what the buffer being filled still takes goes down by what was pushed and comes back
+    with the launch."""
+    import ctypes
+    lib = pkg.load_library()
+    h2d, d2h = ctypes.c_double(), ctypes.c_double()
+    assert lib.mfm_link_probe(0, 512 << 10, 64 << 20, 1.0 / 3.0, ctypes.byref(h2d), ctypes.byref(d2h)) == 0, lib.mfm_last_error()
+    assert 1.0 < h2d.value < 200.0 and 0.3 < d2h.value < 200.0, (h2d.value, d2h.value)
+    one = h2d.value
+    assert lib.mfm_link_probe_runs(0, 512 << 10, 48, 16, 64 << 20, 1.0 / 3.0, ctypes.byref(h2d), ctypes.byref(d2h)) == 0, lib.mfm_last_error()
+    assert h2d.value > 0.8 * one, (one, h2d.value)        # runs of 16 frames per command are not slower than one frame per command
+    assert lib.mfm_link_probe(0, 0, 1 << 20, 0.0, ctypes.byref(h2d), ctypes.byref(d2h)) != 0
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg2_64ch", nr_channels=4)
+    eng = pkg.Engine(fs, decim, 1 << 14, device=0, coalesce_samples=1 << 16)
+    for o, g in zip(offs, gains):
+        eng.add_channel(int(o), taps, float(g))
+    eng.commit()
+    room0 = lib.mfm_engine_input_room(eng.h)
+    assert room0 >= (1 << 16)
+    assert eng.push(np.zeros(2 * 5000, np.int16)) == 0
+    r1 = lib.mfm_engine_input_room(eng.h)
+    assert room0 - 5000 <= r1 <= room0                    # gathered, or launched at once (the device was idle): then only the carried tail is there
+    eng.sync()
+    while eng.fetch() is not None:
+        pass
+    assert lib.mfm_engine_input_room(eng.h) >= room0 - 5000
+    eng.close()
