@@ -280,7 +280,7 @@ def sparse_timing(steps):
     command-processor packets between two kernels: on every launch of the driver's 20-step run they cost 2 % of `value`
     (profiles/r05_step_overheads.txt: ms_per_step 0.1183 against 0.1160 over four alternating runs each), so the events stay
     sparse and EVERY launch is timed by the kernel's own 100 MHz stamps instead (`roofline.clocks.kernel_ms_by_stamps`)."""
-    return os.environ.get("BENCH_EVENTS", "sparse") != "all"
+    return steps >= 8 and os.environ.get("BENCH_EVENTS", "sparse") != "all"   # (a handful of steps: every launch, or none would be timed)
 
 
 def library_sha16(pkg):
