@@ -3,6 +3,7 @@ the sample_buf pool and refcount contract, and - on the GPU - the multifm-shaped
 file_if input (BASELINE configs[0])."""
 import ctypes as C
 import json
+import re
 import os
 import subprocess
 
@@ -170,6 +171,66 @@ def test_receiver_threads_are_race_free_under_tsan(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["delivered"] == 9 and res["dropped"] == 32 and res["pushed"] == 9 and res["pool_back"] == 1
+
+
+@pytest.mark.parametrize("ending", ["reader_returns", "sigint"])
+def test_rtl_sdr_front_end_threads_are_race_free_under_tsan(tmp_path, ending):
+    """The whole driver (host/multifm_main.c: configuration, front-end table, signal handling, cleanup order) with the RTL-SDR
+    front end (host/mfm_rtl_sdr_if.c) on the device double, built with -fsanitize=thread: librtlsdr's reader thread (the test
+    double replays a capture through the async callback) delivers into the receiver's ring while the submit and drain threads
+    run; both endings of multifm/rtl_sdr_if.c - the read returns by itself, or SIGINT -> rtlsdr_cancel_async from the main
+    thread while the callback is active.  ThreadSanitizer must have nothing to report."""
+    import signal
+    import time
+    host = os.path.join(ROOT, "tsl-sdr_amd", "host")
+    exe = tmp_path / "multifm_tsan"
+    srcs = [os.path.join(host, f) for f in ("mfm_tsl.c", "mfm_config.c", "mfm_receiver.c", "mfm_file_if.c", "mfm_rtl_sdr_if.c",
+                                            "multifm_main.c")]
+    srcs.append(os.path.join(ROOT, "tests", "hoststub", "stub_group.c"))
+    r = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-D_GNU_SOURCE", "-I" + host,
+                        "-I" + os.path.join(ROOT, "include"), "-o", str(exe)] + srcs + ["-lpthread", "-lm", "-ldl"],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stderr
+    fake_dir = tmp_path / "fakelib"
+    _build_fake_rtlsdr(fake_dir)
+    n = 16 * 32 * 512 // 2 * 6 + 1234          # six transfers and a bit
+    cap = tmp_path / "rtl.u8"
+    cap.write_bytes(np.random.RandomState(3).randint(0, 256, size=2 * n).astype(np.uint8).tobytes())
+    outs = []
+    cfg = {"device": {"type": "rtlsdr", "deviceIndex": 0, "dBGainLNA": 20.0}, "sampleRateHz": 1200000, "centerFreqHz": 152000000,
+           "nrSampBufs": 8, "decimationFactor": 25, "lpfTaps": [0.01] * 50, "channels": []}
+    for i, f in enumerate((-320000, 125000, 0)):
+        o = tmp_path / f"ch{i}.pcm"
+        o.write_bytes(b"")
+        cfg["channels"].append({"outFifo": str(o), "chanCenterFreq": 152000000 + f})
+        outs.append(o)
+    cj = tmp_path / "cfg.json"
+    cj.write_text(json.dumps(cfg))
+    log = tmp_path / "rtl.log"
+    env = dict({k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}, LD_LIBRARY_PATH=str(fake_dir), FAKE_RTLSDR_FILE=str(cap),
+               FAKE_RTLSDR_LOG=str(log), TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    if ending == "reader_returns":
+        r = subprocess.run([str(exe), str(cj)], capture_output=True, text=True, timeout=180, env=dict(env, FAKE_RTLSDR_EOF_RETURNS="1"))
+        err, rc = r.stderr, r.returncode
+    else:
+        p = subprocess.Popen([str(exe), str(cj)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        deadline = time.time() + 120
+        while time.time() < deadline and p.poll() is None and not (log.exists() and "read_async" in log.read_text()):
+            time.sleep(0.05)
+        time.sleep(0.3)                        # the callback is delivering (the capture is replayed again and again)
+        assert p.poll() is None, p.stderr.read()[-3000:]
+        p.send_signal(signal.SIGINT)
+        _, err = p.communicate(timeout=120)
+        rc = p.returncode
+    assert "ThreadSanitizer" not in err, err[-4000:]
+    assert rc == 0, (rc, err[-3000:])
+    # (the device double takes the blocks and gives nothing back: no PCM is written; what counts is what the threads did)
+    m = re.search(r"INGEST-SUMMARY (\d+) sample buffers delivered, (\d+) submitted", err)
+    assert m and int(m.group(1)) == int(m.group(2)) >= 6, err[-2000:]
+    names = [ln.split()[0] for ln in log.read_text().splitlines()]
+    assert names[-1] == "close" and ("cancel_async" in names) == (ending == "sigint"), names
 
 
 REF_FILE_IF = "/root/reference/multifm/file_if.c"

@@ -99,7 +99,8 @@ typedef aresult_t (*receiver_cleanup_func_t)(struct receiver *rx);
 typedef aresult_t (*receiver_rx_thread_func_t)(struct receiver *rx);
 
 struct receiver {
-    bool muted;
+    _Atomic bool muted; /* set by the main thread (receiver_set_mute, receiver_cleanup), read by the front end's callback: plain
+                           `rx->muted` in a front end's source (multifm/rtl_sdr_if.c:94) is then an atomic load */
     struct list_entry demod_threads;
     size_t nr_demod_threads;
     _Atomic size_t nr_samp_buf_alloc_fails; /* written by the front end, read by whoever reports */
