@@ -173,8 +173,8 @@ def test_receiver_threads_are_race_free_under_tsan(tmp_path):
     assert res["delivered"] == 9 and res["dropped"] == 32 and res["pushed"] == 9 and res["pool_back"] == 1
 
 
-@pytest.mark.parametrize("ending", ["reader_returns", "sigint"])
-def test_rtl_sdr_front_end_threads_are_race_free_under_tsan(tmp_path, ending):
+@pytest.mark.parametrize("ending", ["reader_returns", "sigint", "file_eof"])
+def test_driver_and_front_end_threads_are_race_free_under_tsan(tmp_path, ending):
     """The whole driver (host/multifm_main.c: configuration, front-end table, signal handling, cleanup order) with the RTL-SDR
     front end (host/mfm_rtl_sdr_if.c) on the device double, built with -fsanitize=thread: librtlsdr's reader thread (the test
     double replays a capture through the async callback) delivers into the receiver's ring while the submit and drain threads
@@ -206,11 +206,22 @@ def test_rtl_sdr_front_end_threads_are_race_free_under_tsan(tmp_path, ending):
         o.write_bytes(b"")
         cfg["channels"].append({"outFifo": str(o), "chanCenterFreq": 152000000 + f})
         outs.append(o)
+    if ending == "file_eof":
+        # (the same driver on the file front end, 3 000 buffers of 4 096 samples: the reader outruns the device double's consumer)
+        big = tmp_path / "cap.cs8"
+        big.write_bytes(np.random.RandomState(4).randint(0, 256, size=2 * (4096 * 3000 + 77)).astype(np.uint8).tobytes())
+        cfg["device"] = {"type": "file", "filename": str(big), "fileFormat": "cs8"}
     cj = tmp_path / "cfg.json"
     cj.write_text(json.dumps(cfg))
     log = tmp_path / "rtl.log"
     env = dict({k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}, LD_LIBRARY_PATH=str(fake_dir), FAKE_RTLSDR_FILE=str(cap),
                FAKE_RTLSDR_LOG=str(log), TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    if ending == "file_eof":
+        r = subprocess.run([str(exe), str(cj)], capture_output=True, text=True, timeout=300, env=env)
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+        m = re.search(r"INGEST-SUMMARY (\d+) sample buffers delivered, (\d+) submitted", r.stderr)
+        assert r.returncode == 0 and m and int(m.group(1)) == int(m.group(2)) == 3001, (r.returncode, r.stderr[-2000:])
+        return
     if ending == "reader_returns":
         r = subprocess.run([str(exe), str(cj)], capture_output=True, text=True, timeout=180, env=dict(env, FAKE_RTLSDR_EOF_RETURNS="1"))
         err, rc = r.stderr, r.returncode
