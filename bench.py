@@ -314,12 +314,25 @@ def instance_name(pkg, st, in8):
                                                                 st["tap_hi_mask"], st["outputs_per_tile"], "_in8" if in8 else "")
 
 
-def gpu_sysfs_sample(local_rank=0):
+def device_pci_address(device_index=0):
+    """'dddd:bb:dd.f' of a HIP device as sysfs spells it, or None (torch is plumbing here: it asks the runtime)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+
+
+def gpu_sysfs_sample(local_rank=0, pci_address=None, sysfs="/sys"):
     """One sample of the board's shader clock and power from sysfs (what rocm-smi prints, without starting a process inside the
-    timed region): {sclk_mhz, power_w, source} or None where the files are not there or not readable."""
+    timed region): {sclk_mhz, power_w, source} or None where the files are not there or not readable.  The card is the one at
+    `pci_address` (a box shows the hwmon files of every GPU of its node, usable or not: "the local_rank-th card" read an idle
+    neighbour on such a box - round 5); without an address, or without a match, the local_rank-th card and `matched` false."""
     import glob
     cards = []
-    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+    numbered = [d for d in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")) if os.path.basename(os.path.dirname(d))[4:].isdigit()]
+    for dev in sorted(numbered, key=lambda d: int(os.path.basename(os.path.dirname(d))[4:])):
         try:
             if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
                 continue
@@ -327,10 +340,11 @@ def gpu_sysfs_sample(local_rank=0):
             continue
         hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
         if hw:
-            cards.append(hw[0])
+            cards.append((os.path.basename(os.path.realpath(dev)).lower(), hw[0]))
     if not cards:
         return None
-    hw = cards[min(local_rank, len(cards) - 1)]
+    by_addr = [h for a, h in cards if pci_address and a == pci_address.lower()]
+    hw = by_addr[0] if by_addr else cards[min(local_rank, len(cards) - 1)][1]
 
     def rd(name):
         try:
@@ -339,9 +353,12 @@ def gpu_sysfs_sample(local_rank=0):
             return None
     sclk = rd("freq1_input")
     power = rd("power1_average") or rd("power1_input")
+    cap = rd("power1_cap")
     if sclk is None and power is None:
         return None
-    return {"sclk_mhz": sclk / 1e6 if sclk else None, "power_w": power / 1e6 if power else None, "source": hw}
+    return {"sclk_mhz": sclk / 1e6 if sclk else None, "power_w": power / 1e6 if power else None,
+            "power_cap_w": cap / 1e6 if cap else None, "source": hw, "pci_address": pci_address, "matched": bool(by_addr),
+            "cards_visible": len(cards)}
 
 
 class BoardSampler:
@@ -353,11 +370,12 @@ class BoardSampler:
         import threading
         self.out, self.t_rel = None, None
         self.local_rank = local_rank
+        self.pci_address = device_pci_address(local_rank)   # (asked here, on the caller's thread, not inside the sample)
         self.thread = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         t0 = time.perf_counter()
-        self.out = gpu_sysfs_sample(self.local_rank)
+        self.out = gpu_sysfs_sample(self.local_rank, self.pci_address)
         if self.out is not None:
             self.out["read_ms"] = (time.perf_counter() - t0) * 1e3
 
