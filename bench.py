@@ -314,6 +314,9 @@ def instance_name(pkg, st, in8):
                                                                 st["tap_hi_mask"], st["outputs_per_tile"], "_in8" if in8 else "")
 
 
+BOARD_SAMPLE_AFTER_S = float(os.environ.get("BENCH_BOARD_SAMPLE_AFTER_S", "0.6"))
+
+
 def device_pci_address(device_index=0):
     """'dddd:bb:dd.f' of a HIP device as sysfs spells it, or None (torch is plumbing here: it asks the runtime)."""
     try:
@@ -357,7 +360,7 @@ def gpu_sysfs_sample(local_rank=0, pci_address=None, sysfs="/sys"):
     if sclk is None and power is None:
         return None
     return {"sclk_mhz": sclk / 1e6 if sclk else None, "power_w": power / 1e6 if power else None,
-            "power_cap_w": cap / 1e6 if cap else None, "source": hw, "pci_address": pci_address, "matched": bool(by_addr),
+            "power_cap_w": cap / 1e6 if cap else None, "power_of_cap": (power / cap) if (power and cap) else None, "source": hw, "pci_address": pci_address, "matched": bool(by_addr),
             "cards_visible": len(cards)}
 
 
@@ -983,15 +986,6 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
     st1 = [g.stats(s) for s in range(g.nr_shards)]
     eng0 = g.shard_engine(0)
     cycles = launch_clocks(eng0, min(steps, 1024))
-    sampler = BoardSampler(0)   # behind the timed region, while the same steps keep running (see main())
-    k = 0
-    while k < 16 or (sampler.thread.is_alive() and k < 4000):
-        step()
-        k += 1
-        if k == 3:
-            sampler.start()
-    g.sync()
-    smi = sampler.result()
     uses, nblk, moved = g.exchange_info()
     shards = []
     for s in range(g.nr_shards):
@@ -1007,6 +1001,18 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
     n_last = eng0.last_output_device()[2]
     verified = verify_last_block(pkg, eng0, fs, decim, taps, list(offs)[lo0:lo0 + n0], list(gains)[lo0:lo0 + n0],
                                  g.stats(0)["outputs"] - n_last)
+    sampler = BoardSampler(0)   # behind the timed region and the self-check, while the same steps run again (see main())
+    k, started, t_load = 0, False, time.perf_counter()
+    while k < 16 or ((not started or sampler.thread.is_alive()) and k < 40000):
+        step()
+        k += 1
+        if k % 64 == 0:
+            g.sync()
+        if not started and time.perf_counter() - t_load >= BOARD_SAMPLE_AFTER_S:
+            sampler.start()
+            started = True
+    g.sync()
+    smi = sampler.result()
     out = {"dt": dt, "shards": shards, "exchange": {"uses_rccl": bool(uses), "blocks": int(nblk), "bytes_to_other_devices": int(moved),
                                                     "mode": "scatter + all-gather (MFM_X_RCCL_ALLGATHER)" if S > 1 else "none (one device)"},
            "verified": verified, "clocks": cycles, "board_sample": smi, "st1": st1[0]}
@@ -1295,6 +1301,12 @@ def main():
     if rank == 0 and st1["kernel_variant"] == 2 and world == 1:
         ceiling = issue_model(instance_name(pkg, st1, in8), st1, cycles, achieved / HBM_PEAK_GBPS, library_sha16(pkg))
 
+    # (the self-check first: it reads what the LAST TIMED launch left in HBM)
+    verified = None
+    if rank == 0:
+        n_last = eng.last_output_device()[2]
+        verified = verify_last_block(pkg, eng, fs, decim, taps, offs, gains, eng.stats()["outputs"] - n_last)
+
     # One sysfs sample of the board's clock and power, taken while the same steps keep running right BEHIND the timed region: a
     # hwmon read is a message to the SMU that holds the submission up for ~1.5 ms - inside a 2.4 ms timed region it cost a
     # third of `value` (tools/r05/step_overheads.sh: ms_per_step 0.121 -> 0.180).  The clock the timed launches really ran
@@ -1302,24 +1314,30 @@ def main():
     smi = None
     if os.environ.get("BENCH_NO_BOARD_SAMPLE") != "1":
         sampler = BoardSampler(local_rank) if rank == 0 else None
-        k = 0
-        # the workload keeps running for as long as the read takes (2-4 ms: a reading taken after the queue has drained shows the
-        # idle clock)
-        while k < 16 or (sampler is not None and sampler.thread.is_alive() and k < 4000):
+        # The read starts only after BOARD_SAMPLE_AFTER_S of back-to-back steps - the host work between the timed region and
+        # this loop (the self-check: tenths of a second) lets the board's power reading, a moving average over a few hundred ms,
+        # fall to a transitional value (854 W read 0.4 ms into the resumed load; 1375-1387 W sustained:
+        # profiles/r05_power_trace.txt) - and the workload keeps running for as long as the read takes (2-4 ms: a reading taken
+        # after the queue has drained shows the idle clock).  Step counts come from the timed region's own step time, which is
+        # the same number on every rank (max over ranks): with N > 1 a step is a collective.
+        step_s = max(dt / max(1, args.steps), 1e-6)
+        n_pre = int(min(20000, max(16, BOARD_SAMPLE_AFTER_S / step_s)))
+        n_post = int(min(4000, max(16, 0.03 / step_s)))
+        for _ in range(n_pre):
             step()
-            k += 1
-            if sampler and k == 3:
-                sampler.start()
+        torch.cuda.synchronize()
+        eng.sync()   # the device has now run n_pre steps back to back (the host submits faster than it executes) ...
+        for _ in range(16):
+            step()   # ... and is kept busy while the read starts
+        if sampler:
+            sampler.start()
+        for _ in range(n_post):
+            step()
         fence()
         if sampler:
             smi = sampler.result()
             if smi is not None:
-                smi["when"] = "during further steps of the same workload queued right behind the timed region"
-
-    verified = None
-    if rank == 0:
-        n_last = eng.last_output_device()[2]
-        verified = verify_last_block(pkg, eng, fs, decim, taps, offs, gains, eng.stats()["outputs"] - n_last)
+                smi["when"] = "after %.1f s of further back-to-back steps of the same workload behind the timed region" % BOARD_SAMPLE_AFTER_S
 
     if rank == 0:
         line = {
