@@ -258,9 +258,12 @@ gen.append(f"* Headline (`r05_bench_n1.json`, the driver's command `python bench
            f"`verified` {head.get('verified')}.")
 clk = hr.get("clocks") or {}
 bs = hr.get("board_sample") or {}
+bs_note = "" if bs.get("matched") else (" (that sample predates the matching of the card to the device's PCI address and the wait for a sustained load: "
+                                          "it is the first AMD card of that box, read right after the host's pause - a matched, sustained reading is in "
+                                          "`r05b_summary.txt`: 1944 MHz, 1384 W of the 1400 W cap)")
 gen.append(f"* Clock and power of the same run: the kernel's own stamps (`roofline.clocks`: s_memtime / s_memrealtime of the first and last workgroup) give "
            f"{clk.get('shader_ticks_median', nan):.0f} shader cycles in {clk.get('kernel_ms_by_ref_ticks', nan):.4f} ms = **{clk.get('sclk_mhz_effective', nan):.0f} MHz** "
-           f"inside the timed launches; the board's sysfs reading right behind the timed region: {bs.get('sclk_mhz')} MHz, {bs.get('power_w')} W.")
+           f"inside the timed launches; the board's sysfs reading right behind the timed region: {bs.get('sclk_mhz')} MHz, {bs.get('power_w')} W{bs_note}.")
 im = hr.get("issue_model")
 if im and im.get("simd_busy_fraction"):
     gen.append(f"* Issue model in the line (`roofline.issue_model`): {im['mfma_insts_per_launch']:.4g} matrix + {im['other_valu_insts_per_launch']:.4g} other vector "
