@@ -1013,6 +1013,8 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
             started = True
     g.sync()
     smi = sampler.result()
+    if smi is not None:
+        smi["when"] = "after %.1f s of further back-to-back steps of the same workload behind the timed region" % BOARD_SAMPLE_AFTER_S
     out = {"dt": dt, "shards": shards, "exchange": {"uses_rccl": bool(uses), "blocks": int(nblk), "bytes_to_other_devices": int(moved),
                                                     "mode": "scatter + all-gather (MFM_X_RCCL_ALLGATHER)" if S > 1 else "none (one device)"},
            "verified": verified, "clocks": cycles, "board_sample": smi, "st1": st1[0]}
