@@ -364,6 +364,17 @@ def gpu_sysfs_sample(local_rank=0, pci_address=None, sysfs="/sys"):
             "cards_visible": len(cards)}
 
 
+def energy_figures(smi, ms_per_step, channels, outputs_per_launch):
+    """What a step costs in energy, from the sustained board sample: PPT x step time.  At the board's power cap this - not issue
+    slots - is what sets the step time (profiles/r05_exp_issue_vs_power.txt, r05_power_trace.txt)."""
+    if not smi or not smi.get("power_w") or not smi.get("matched"):
+        return None
+    j = smi["power_w"] * ms_per_step * 1e-3
+    return {"joule_per_step": j, "nJ_per_channel_output": j * 1e9 / max(1.0, channels * outputs_per_launch),
+            "power_w": smi["power_w"], "power_of_cap": smi.get("power_of_cap"),
+            "basis": "board_sample.power_w (PPT of the run's own card, 0.6 s into sustained load) x ms_per_step"}
+
+
 class BoardSampler:
     """One gpu_sysfs_sample() taken WHILE the timed steps run, on a thread of its own: a hwmon read is a message to the SMU and
     takes a millisecond or two - on the submitting thread it would sit in the middle of a 2.4 ms timed region (first try of this
@@ -1370,7 +1381,8 @@ def main():
                          "ceiling_frac": ceiling["ceiling_frac"] if ceiling else None, "issue_model": ceiling,
                          "instance": instance_name(pkg, st1, in8), "library_sha16": library_sha16(pkg),
                          # the kernel's own clocks for the timed launches, and one sysfs sample taken while they ran
-                         "clocks": cycles, "board_sample": smi},
+                         "clocks": cycles, "board_sample": smi,
+                         "energy": energy_figures(smi, dt / args.steps * 1e3, len(offs), outs)},
             "verified": verified["verified"], "verification": verified,
             "rotators": {"exact_channels": st1["rot_exact_channels"], "channels": len(offs)},
             "protocol": {"settle_seconds": args.settle_seconds, "settle_steps": settle_steps + 8,

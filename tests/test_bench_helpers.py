@@ -41,3 +41,11 @@ def test_board_sample_reads_the_card_at_the_devices_pci_address(tmp_path):
     s = b.gpu_sysfs_sample(0, "0000:ff:00.0", sysfs=str(tmp_path))
     assert not s["matched"] and s["sclk_mhz"] == 96
     assert b.gpu_sysfs_sample(0, "0000:65:00.0", sysfs=str(tmp_path / "nothing")) is None
+
+
+def test_energy_figures_need_a_matched_sample():
+    b = _bench()
+    assert b.energy_figures(None, 0.117, 64, 699050) is None
+    assert b.energy_figures({"power_w": 1380.0, "matched": False}, 0.117, 64, 699050) is None
+    e = b.energy_figures({"power_w": 1380.0, "matched": True, "power_of_cap": 0.986}, 0.117, 64, 699050.0)
+    assert abs(e["joule_per_step"] - 0.16146) < 1e-4 and abs(e["nJ_per_channel_output"] - 3.609) < 0.01
