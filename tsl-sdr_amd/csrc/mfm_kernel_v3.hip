@@ -54,7 +54,7 @@
 #define MFM3_SH0(d, a) "v_lshrrev_b32_sdwa %[" #d "], 14, %[" #a "] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
 #define MFM3_SH1(d, a) "v_lshrrev_b32_sdwa %[" #d "], 14, %[" #a "] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
-template <bool HAS_PREV, bool HAS_NEXT, int LO, int O2, int O3, int N0, int N1>
+template <bool HAS_PREV, bool HAS_NEXT, int LO, int O2, int O3, int N0, int N1, bool REUSE = false>
 static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, const mfm_v4i &al0, const mfm_v4i &al1,
                                                       const mfm_v4i &al2, const mfm_v4i &al3, const mfm_v4i &ah1,
                                                       const mfm_v4i &ah2, mfm_v4i &b0h, mfm_v4i &b0l, mfm_v4i &b1h,
@@ -110,7 +110,47 @@ static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, 
     }
     /* second half: k-steps 2, 3; the next group's k-step 0 goes into b1 (free since MFMA 6), its k-step 1 into b2 (free
      * behind MFMA 10) */
-    if (HAS_PREV && HAS_NEXT) {
+    if (REUSE && HAS_PREV && HAS_NEXT) {
+        /* The Toeplitz overlap (MFM3_TOEPLITZ): at D = 96, T = 128 the windows of consecutive outputs overlap by 64 plane bytes =
+         * one k-step, so the next column group's k-step 0 IS this group's k-step 3 - the same LDS bytes, already in b0 when
+         * this block ends: only the next group's k-step 1 is requested (into b2), and the caller hands (b0, b2, b1) on.  Two
+         * requests fewer in flight: the counted waits are 2 where the form above has 4. */
+        asm volatile(
+            "s_waitcnt lgkmcnt(2)\n\t"                                       /* b2 = k-step 2 (behind it: b0 = k-step 3) */
+            MFM3_MF(hh, ah2, b2h, "%[hh]")
+            MFM3_LA(t0, t0, l0) MFM3_LA(t1, t1, l1)
+            MFM3_MF(md, ah2, b2l, "%[md]")
+            MFM3_LA(t2, t2, l2) MFM3_LA(t3, t3, l3)
+            MFM3_MF(ll, al2, b2l, "%[ll]")
+            MFM3_MF(md, al2, b2h, "%[md]")
+            MFM3_RD(b2h, n1) MFM3_RD(b2l, n1l)
+            "s_waitcnt lgkmcnt(2)\n\t"                                       /* b0 = k-step 3 */
+            MFM3_MF(ll, al3, b0l, "%[ll]")
+            MFM3_SH0(t0, t0) MFM3_SH0(t2, t2)
+            MFM3_MF(md, al3, b0h, "%[md]")
+            MFM3_SH1(t0, t1) MFM3_SH1(t2, t3)
+            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3),
+              [b2h] "+v"(b2h), [b2l] "+v"(b2l)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0h] "v"(b0h), [b0l] "v"(b0l),
+              [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]), [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]),
+              [n1] "n"(N1), [n1l] "n"(N1 + LO)
+            : "memory");
+    } else if (REUSE && HAS_NEXT) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(2)\n\t"
+            MFM3_MF(hh, ah2, b2h, "%[hh]")
+            MFM3_MF(md, ah2, b2l, "%[md]")
+            MFM3_MF(ll, al2, b2l, "%[ll]")
+            MFM3_MF(md, al2, b2h, "%[md]")
+            MFM3_RD(b2h, n1) MFM3_RD(b2l, n1l)
+            "s_waitcnt lgkmcnt(2)\n\t"
+            MFM3_MF(ll, al3, b0l, "%[ll]")
+            MFM3_MF(md, al3, b0h, "%[md]")
+            : [hh] "+v"(hh), [md] "+v"(md), [ll] "+v"(ll), [b2h] "+v"(b2h), [b2l] "+v"(b2l)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0h] "v"(b0h), [b0l] "v"(b0l),
+              [n1] "n"(N1), [n1l] "n"(N1 + LO)
+            : "memory");
+    } else if (HAS_PREV && HAS_NEXT) {
         asm volatile(
             MFM3_RD(b1h, n0) MFM3_RD(b1l, n0l)
             "s_waitcnt lgkmcnt(4)\n\t"                                       /* b2 = k-step 2 */
@@ -188,7 +228,7 @@ static __device__ __forceinline__ void mfm3_group_d96(uint32_t lb, uint32_t ka, 
 #define MFM3_SHN0(d, a) "v_lshrrev_b32_sdwa %[" #d "], %[sh], %[" #a "] dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
 #define MFM3_SHN1(d, a) "v_lshrrev_b32_sdwa %[" #d "], %[sh], %[" #a "] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
 
-template <bool HAS_PREV, bool HAS_NEXT, int SH, int O2, int O3, int N0, int N1>
+template <bool HAS_PREV, bool HAS_NEXT, int SH, int O2, int O3, int N0, int N1, bool REUSE = false>
 static __device__ __forceinline__ void mfm3_group_d96_b8(uint32_t lb, uint32_t ka, const mfm_v4i &al0, const mfm_v4i &al1,
                                                          const mfm_v4i &al2, const mfm_v4i &al3, const mfm_v4i &ah1,
                                                          const mfm_v4i &ah2, mfm_v4i &b0, mfm_v4i &b1, mfm_v4i &b2,
@@ -207,7 +247,38 @@ static __device__ __forceinline__ void mfm3_group_d96_b8(uint32_t lb, uint32_t k
         : [hh] "=&v"(hh), [ll] "=&v"(ll), [b2] "=&v"(b2), [b0] "+v"(b0)
         : [lb] "v"(lb), [ka] "v"(ka), [al0] "v"(al0), [al1] "v"(al1), [ah1] "v"(ah1), [b1] "v"(b1), [o2] "n"(O2), [o3] "n"(O3)
         : "memory");
-    if (HAS_PREV && HAS_NEXT) {
+    if (REUSE && HAS_PREV && HAS_NEXT) {
+        /* the Toeplitz overlap (mfm3_group_d96): the next group's k-step 0 is this group's k-step 3, already in b0 - one request
+         * fewer in flight, the counted waits are 1 where the form below has 2; the caller hands (b0, b2, b1) on */
+        asm volatile(
+            MFM3_LA(t0, h0, l0)
+            "s_waitcnt lgkmcnt(1)\n\t"                                       /* b2 = k-step 2 */
+            MFM3_MF(hh, ah2, b2, "%[hh]")
+            MFM3_LA(t1, h1, l1) MFM3_LA(t2, h2, l2)
+            MFM3_MF(ll, al2, b2, "%[ll]")
+            MFM3_RD(b2, n1)                                                  /* the next group's k-step 1 */
+            MFM3_LA(t3, h3, l3)
+            "s_waitcnt lgkmcnt(1)\n\t"                                       /* b0 = k-step 3 */
+            MFM3_MF(ll, al3, b0, "%[ll]")
+            MFM3_SHN0(t0, t0) MFM3_SHN0(t2, t2)
+            MFM3_SHN1(t0, t1) MFM3_SHN1(t2, t3)
+            : [hh] "+v"(hh), [ll] "+v"(ll), [b2] "+v"(b2), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0] "v"(b0), [h0] "v"(accP[0][0]),
+              [h1] "v"(accP[0][1]), [h2] "v"(accP[0][2]), [h3] "v"(accP[0][3]), [l0] "v"(accP[2][0]), [l1] "v"(accP[2][1]),
+              [l2] "v"(accP[2][2]), [l3] "v"(accP[2][3]), [n1] "n"(N1), [sh] "n"(SH)
+            : "memory");
+    } else if (REUSE && HAS_NEXT) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(1)\n\t"
+            MFM3_MF(hh, ah2, b2, "%[hh]")
+            MFM3_MF(ll, al2, b2, "%[ll]")
+            MFM3_RD(b2, n1)
+            "s_waitcnt lgkmcnt(1)\n\t"
+            MFM3_MF(ll, al3, b0, "%[ll]")
+            : [hh] "+v"(hh), [ll] "+v"(ll), [b2] "+v"(b2)
+            : [lb] "v"(lb), [al2] "v"(al2), [al3] "v"(al3), [ah2] "v"(ah2), [b0] "v"(b0), [n1] "n"(N1)
+            : "memory");
+    } else if (HAS_PREV && HAS_NEXT) {
         asm volatile(
             MFM3_RD(b1, n0)                                                  /* the next group's k-step 0 */
             MFM3_LA(t0, h0, l0)
@@ -866,20 +937,41 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 mfm_v4i acc0[3], acc1[3];
                 uint32_t t[4];
                 const mfm_v4i none[3] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-                mfm3_group_d96<false, true, LO, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, none, acc0, t);
-                mfm3_group_d96<true, true, LO, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qh, ql, rh, rl, ph, pl, acc0, acc1, t);
-                f[0][0] = t[0];
-                f[0][1] = t[2];
-                mfm3_group_d96<true, true, LO, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rh, rl, ph, pl, qh, ql, acc1, acc0, t);
-                f[1][0] = t[0];
-                f[1][1] = t[2];
-                mfm3_group_d96<true, false, LO, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, acc0, acc1, t);
-                f[2][0] = t[0];
-                f[2][1] = t[2];
+                /* (decimation 96: the windows of consecutive outputs overlap by exactly one k-step; decimation 40 does not) */
+                constexpr bool TOEP = MFM3_TOEPLITZ != 0 && MFM3_OFS(0, 3) == MFM3_OFS(1, 0) && MFM3_OFS(1, 3) == MFM3_OFS(2, 0) &&
+                                      MFM3_OFS(2, 3) == MFM3_OFS(3, 0);
+                if constexpr (TOEP) {
+                    /* the next group's k-step 0 is this group's k-step 3 (same LDS bytes): p serves both, q and r alternate */
+                    mfm3_group_d96<false, true, LO, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1), true>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, none, acc0, t);
+                    mfm3_group_d96<true, true, LO, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1), true>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, rh, rl, qh, ql, acc0, acc1, t);
+                    f[0][0] = t[0];
+                    f[0][1] = t[2];
+                    mfm3_group_d96<true, true, LO, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1), true>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, acc1, acc0, t);
+                    f[1][0] = t[0];
+                    f[1][1] = t[2];
+                    mfm3_group_d96<true, false, LO, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, rh, rl, qh, ql, acc0, acc1, t);
+                    f[2][0] = t[0];
+                    f[2][1] = t[2];
+                } else {
+                    mfm3_group_d96<false, true, LO, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, none, acc0, t);
+                    mfm3_group_d96<true, true, LO, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qh, ql, rh, rl, ph, pl, acc0, acc1, t);
+                    f[0][0] = t[0];
+                    f[0][1] = t[2];
+                    mfm3_group_d96<true, true, LO, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rh, rl, ph, pl, qh, ql, acc1, acc0, t);
+                    f[1][0] = t[0];
+                    f[1][1] = t[2];
+                    mfm3_group_d96<true, false, LO, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], ph, pl, qh, ql, rh, rl, acc0, acc1, t);
+                    f[2][0] = t[0];
+                    f[2][1] = t[2];
+                }
                 /* rotator entries of this tile, four consecutive ones per channel: requested at the end of the matrix phase
                  * (its registers are all taken until here), needed behind the staging stores and the barrier */
                 __builtin_amdgcn_sched_barrier(0);
@@ -910,16 +1002,31 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                 mfm_v4i acc0[3], acc1[3];
                 uint32_t t[4];
                 const mfm_v4i none[3] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-                mfm3_group_d96_b8<false, true, IN8, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, none, acc0, t);
-                mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qb, rb2, pb, acc0, acc1, t);
-                f[0][0] = t[0];
-                f[0][1] = t[2];
-                mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rb2, pb, qb, acc1, acc0, t);
-                f[1][0] = t[0];
-                f[1][1] = t[2];
+                constexpr bool TOEP = MFM3_TOEPLITZ != 0 && MFM3_OFS(0, 3) == MFM3_OFS(1, 0) && MFM3_OFS(1, 3) == MFM3_OFS(2, 0) &&
+                                      MFM3_OFS(2, 3) == MFM3_OFS(3, 0);
+                if constexpr (TOEP) {
+                    mfm3_group_d96_b8<false, true, IN8, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1), true>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, none, acc0, t);
+                    mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1), true>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, rb2, qb, acc0, acc1, t);
+                    f[0][0] = t[0];
+                    f[0][1] = t[2];
+                    mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1), true>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, acc1, acc0, t);
+                    f[1][0] = t[0];
+                    f[1][1] = t[2];
+                } else {
+                    mfm3_group_d96_b8<false, true, IN8, MFM3_OFS(0, 2), MFM3_OFS(0, 3), MFM3_OFS(1, 0), MFM3_OFS(1, 1)>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, none, acc0, t);
+                    mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(1, 2), MFM3_OFS(1, 3), MFM3_OFS(2, 0), MFM3_OFS(2, 1)>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], qb, rb2, pb, acc0, acc1, t);
+                    f[0][0] = t[0];
+                    f[0][1] = t[2];
+                    mfm3_group_d96_b8<true, true, IN8, MFM3_OFS(2, 2), MFM3_OFS(2, 3), MFM3_OFS(3, 0), MFM3_OFS(3, 1)>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], rb2, pb, qb, acc1, acc0, t);
+                    f[1][0] = t[0];
+                    f[1][1] = t[2];
+                }
                 /* rotator entries of this tile: requested in front of the last column group instead of behind the matrix
                  * phase - a column group more time to arrive (the knock-out build without these loads was 8 us faster: what
                  * they cost is their own latency).  This form has the 16 registers for it; the int16 form spills with it
@@ -936,8 +1043,13 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                mfm3_group_d96_b8<true, false, IN8, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
-                    lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, acc0, acc1, t);
+                if constexpr (TOEP) {
+                    mfm3_group_d96_b8<true, false, IN8, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, rb2, qb, acc0, acc1, t);
+                } else {
+                    mfm3_group_d96_b8<true, false, IN8, MFM3_OFS(3, 2), MFM3_OFS(3, 3), 0, 0>(
+                        lb, ka, a_l[0], a_l[1], a_l[2], a_l[3], a_h[1], a_h[2], pb, qb, rb2, acc0, acc1, t);
+                }
                 f[2][0] = t[0];
                 f[2][1] = t[2];
                 settle();

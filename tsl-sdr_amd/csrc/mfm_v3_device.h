@@ -50,6 +50,10 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
 #ifndef MFM3_DIV_STEPS
 #define MFM3_DIV_STEPS 1 /* 2: A/B builds - the division with a second residual step, as in rounds 1-3 */
 #endif
+#ifndef MFM3_TOEPLITZ
+#define MFM3_TOEPLITZ 1 /* 0: A/B builds; 1: the int16 and the 8-bit D = 96 / 128-tap instance does not read a column group's k-step 0 again when it is the
+                           previous group's k-step 3 (6 of a tile's 32 B-fragment reads per wave and plane) */
+#endif
 #ifndef MFM3_LUT_MODE
 #define MFM3_LUT_MODE 1 /* the arctangent table in LDS: 1 {T, dT} pairs, one 8-byte read per output (banked over 64 dwords);
                          * 0 (rounds 2-3, A/B builds) T[256] then dT[256], one ds_read2st64_b32 (banked over 32): the table's
