@@ -26,6 +26,9 @@ done
 timeout 600 python bench.py --config cfg5_airspy --channels-per-gpu 256 --kernel v3l1 --steps 40 --warmup 5 $N > $O/bench_cfg5_v3l1.json 2> $O/bench_cfg5_v3l1.err
 timeout 600 python bench.py --config pocsag_rtlsdr --channels-per-gpu 64 --steps 60 --warmup 5 $N > $O/bench_pocsag_d25.json 2> $O/bench_pocsag_d25.err
 timeout 600 python bench.py --config multifm_1ch --channels-per-gpu 64 --steps 60 --warmup 5 $N > $O/bench_multifm_d40.json 2> $O/bench_multifm_d40.err
+# profiled runs: no 0.6 s of sustained load in front of the board sample (5 000 more dispatches per run in every trace and counter
+# file: the call's output went over gpurun's 64 MiB), and the per-dispatch traces of the counter passes are not kept
+export BENCH_BOARD_SAMPLE_AFTER_S=0
 # rocprofv3 kernel trace of the headline command (same flags the driver uses) and of the 1024-channel shape
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -o k -- python3 bench.py --gpus 1 --steps 20 --warmup 5 $N > $O/kstats.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats1024 -o k -- python3 bench.py --config cfg3_1024ch --channels-per-gpu 1024 --steps 20 --warmup 3 --settle-seconds 0.3 $N > $O/kstats1024.log 2>&1
@@ -38,6 +41,7 @@ pmc() { # tag, bench flags...
   timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $O/${tag}_p3 -o p -- $P > $O/${tag}_p3.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_fetch -o f -- $P > $O/${tag}_fetch.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_write -o w -- $P > $O/${tag}_write.log 2>&1
+  find $O/${tag}_p1 $O/${tag}_p2 $O/${tag}_p3 $O/${tag}_fetch $O/${tag}_write -name "*kernel_trace.csv" -delete 2>/dev/null
 }
 pmc head
 pmc c1024 --config cfg3_1024ch --channels-per-gpu 1024
@@ -45,8 +49,9 @@ pmc cfg5 --config cfg5_airspy --channels-per-gpu 256
 pmc d25 --config pocsag_rtlsdr_256taps --channels-per-gpu 64
 pmc d100 --config pocsag_airspy --channels-per-gpu 64
 pmc d120 --config multifm_airspy --channels-per-gpu 64
+unset BENCH_BOARD_SAMPLE_AFTER_S
 # what the line's own instrumentation costs, the link, host-fed end to end
 bash tools/r05/step_overheads.sh > $O/step_overheads.txt 2>&1
 timeout 300 python3 tools/r05/link_probe.py > $O/link_probe.txt 2>&1
 nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
-ls $O | head -80
+du -sh $O; ls $O | wc -l
