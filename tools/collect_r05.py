@@ -263,7 +263,7 @@ bs_note = "" if bs.get("matched") else (" (that sample predates the matching of 
                                           "`r05b_summary.txt`: 1944 MHz, 1384 W of the 1400 W cap)")
 gen.append(f"* Clock and power of the same run: the kernel's own stamps (`roofline.clocks`: s_memtime / s_memrealtime of the first and last workgroup) give "
            f"{clk.get('shader_ticks_median', nan):.0f} shader cycles in {clk.get('kernel_ms_by_ref_ticks', nan):.4f} ms = **{clk.get('sclk_mhz_effective', nan):.0f} MHz** "
-           f"inside the timed launches; the board's sysfs reading right behind the timed region: {bs.get('sclk_mhz')} MHz, {bs.get('power_w')} W{bs_note}.")
+           f"inside the timed launches; the board's sysfs reading ({'the card at the device PCI address, ' + str(bs.get('when')) if bs.get('matched') else 'right behind the timed region'}): {bs.get('sclk_mhz')} MHz, {bs.get('power_w')} W" + (f" of the {bs.get('power_cap_w'):.0f} W cap" if bs.get('power_cap_w') else "") + f"{bs_note}.")
 im = hr.get("issue_model")
 if im and im.get("simd_busy_fraction"):
     gen.append(f"* Issue model in the line (`roofline.issue_model`): {im['mfma_insts_per_launch']:.4g} matrix + {im['other_valu_insts_per_launch']:.4g} other vector "
