@@ -49,8 +49,9 @@ def parse():
     # state as the defaults.
     ap.add_argument("--settle-seconds", type=float, default=0.75)
     ap.add_argument("--channels-per-gpu", type=int, default=None,
-                    help="default 64 at N = 1 (BASELINE configs[1]), 128 at N > 1 (configs[2]: 1024 channels on 8 GPUs)")
-    ap.add_argument("--kernel", choices=["auto", "mfma1", "mfma1s", "dot2", "v3l1"], default="auto",
+                    help="default 64 at every N: BASELINE configs[1] per GPU, the same per-GPU work as N grows (weak scaling); "
+                             "--gpus 8 --channels-per-gpu 128 is configs[2] (1024 channels on 8 GPUs)")
+    ap.add_argument("--kernel", choices=["auto", "mfma1", "mfma1s", "dot2", "v3l1", "slice64", "slice128"], default="auto",
                     help="mfma1 / dot2 = the first-generation matrix kernel / the v_dot2 kernel through the "
                          "MFM_F_FORCE_* flags (A/B timing)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
@@ -1008,10 +1009,23 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
                        "kernel_variant": st1[s]["kernel_variant"], "k_steps": st1[s]["k_steps"], "tap_hi_mask": st1[s]["tap_hi_mask"],
                        "rot_exact_channels": st1[s]["rot_exact_channels"], "pending_blocks": st1[s]["pending_blocks"],
                        "submits": int(st1[s]["submits"] - st0[s]["submits"])})
-    lo0, n0, _ = g.shard_info(0)
-    n_last = eng0.last_output_device()[2]
-    verified = verify_last_block(pkg, eng0, fs, decim, taps, list(offs)[lo0:lo0 + n0], list(gains)[lo0:lo0 + n0],
-                                 g.stats(0)["outputs"] - n_last)
+    # every shard's last block against the oracle, on the input THAT shard's launch read: a wrong scatter or all-gather offset
+    # corrupts the input of the non-root shards only
+    per_shard = []
+    for s in range(g.nr_shards):
+        lo_s, n_s, _ = g.shard_info(s)
+        eng_s = g.shard_engine(s)
+        n_last = eng_s.last_output_device()[2]
+        v = verify_last_block(pkg, eng_s, fs, decim, taps, list(offs)[lo_s:lo_s + n_s], list(gains)[lo_s:lo_s + n_s],
+                              g.stats(s)["outputs"] - n_last)
+        v["shard"] = s
+        per_shard.append(v)
+    verified = dict(per_shard[0])
+    verified["verified"] = all(v["verified"] for v in per_shard)
+    verified["shards_verified"] = [bool(v["verified"]) for v in per_shard]
+    if not verified["verified"]:
+        verified["failed_shards"] = [v for v in per_shard if not v["verified"]]
+    detail = [g.exchange_detail(s) for s in range(g.nr_shards)]
     sampler = BoardSampler(0)   # behind the timed region and the self-check, while the same steps run again (see main())
     k, started, t_load = 0, False, time.perf_counter()
     while k < 16 or ((not started or sampler.thread.is_alive()) and k < 40000):
@@ -1026,8 +1040,15 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
     smi = sampler.result()
     if smi is not None:
         smi["when"] = "after %.1f s of further back-to-back steps of the same workload behind the timed region" % BOARD_SAMPLE_AFTER_S
+    try:
+        rccl_file = b.rccl_library() if uses else None
+    except Exception as exc:   # (a group that exchanges has loaded it: this cannot fail there)
+        rccl_file = "unavailable: %s" % exc
     out = {"dt": dt, "shards": shards, "exchange": {"uses_rccl": bool(uses), "blocks": int(nblk), "bytes_to_other_devices": int(moved),
-                                                    "mode": "scatter + all-gather (MFM_X_RCCL_ALLGATHER)" if S > 1 else "none (one device)"},
+                                                    "mode": "scatter + all-gather (MFM_X_RCCL_ALLGATHER)" if S > 1 else "none (one device)",
+                                                    "rccl_library": rccl_file,
+                                                    "rccl_ranks": detail[0]["rccl_ranks"] if uses else 0,
+                                                    "per_shard": detail},
            "verified": verified, "clocks": cycles, "board_sample": smi, "st1": st1[0]}
     g.close()
     return out
@@ -1036,7 +1057,7 @@ def group_run(pkg, args, devices, shared, fs, decim, taps, offs, gains, block, s
 def group_main(args, pkg, devices, shared, world_for_line):
     """`--exchange group`: the whole line from one process."""
     S = len(devices)
-    cpg = args.channels_per_gpu or (64 if S == 1 else 128)
+    cpg = args.channels_per_gpu or 64   # the same per-GPU work at every N (weak scaling): BENCH's 64 channels per GPU
     total_ch = cpg * S
     fs, decim, taps, offs, gains = pkg.synth.plan(args.config, nr_channels=total_ch)
     block = 1 << args.block_log2
@@ -1051,6 +1072,15 @@ def group_main(args, pkg, devices, shared, world_for_line):
     msamp = args.steps * block / dt / 1e6
     kname = {0: "mfm_channel_kernel", 1: "mfm_channel_kernel_mfma", 2: "mfm_channel_kernel_v3"}[sh0["kernel_variant"]]
     need = 4.0 * block / (k_ms * 1e-3) / 1e9 if S > 1 else 0.0
+    single = None
+    if S > 1:
+        # the same per-GPU shape on ONE device of the same node, same run, same protocol: what "N x one GPU" means for this line
+        fs1, decim1, taps1, offs1, gains1 = pkg.synth.plan(args.config, nr_channels=cpg)
+        r1 = group_run(pkg, args, devices[:1], False, fs1, decim1, taps1, offs1, gains1, block, args.steps, args.warmup, args.settle_seconds)
+        v1 = args.steps * block / r1["dt"] / 1e6 * cpg
+        single = {"value": v1, "unit": "MSamp/s x channels", "channels": cpg, "ms_per_step": r1["dt"] / args.steps * 1e3,
+                  "kernel_ms": r1["shards"][0]["kernel_ms"], "verified": r1["verified"]["verified"], "device": devices[0],
+                  "what": "a one-device group at the same channels_per_gpu, same blocks, same step count, in this run"}
     line = {
         "metric": "input IQ MSamp/s x channels demodulated", "value": msamp * total_ch, "unit": "MSamp/s x channels",
         "n_gpus": world_for_line, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -1069,6 +1099,8 @@ def group_main(args, pkg, devices, shared, world_for_line):
         "verified": r["verified"]["verified"], "verification": r["verified"],
         "group": {"shards": r["shards"], "exchange_info": r["exchange"],
                   "needed_GBps_per_peer": need, "api": "mfm_group_acquire_input + mfm_group_submit (include/multifm_hip.h)"},
+        "single_gpu_same_shape": single,
+        "scaling_efficiency": (msamp * total_ch) / (S * single["value"]) if single else None,
         "protocol": {"settle_seconds": args.settle_seconds, "warmup_steps": args.warmup, "timed_steps": args.steps},
     }
     return line
@@ -1162,7 +1194,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    cpg = args.channels_per_gpu or (64 if world == 1 else 128)
+    cpg = args.channels_per_gpu or 64
     total_ch = cpg * world
     fs, decim, taps, all_offs, all_gains = pkg.synth.plan(args.config, nr_channels=total_ch)
     lo, hi = pkg.dist.shard_range(total_ch, rank, world)
@@ -1182,7 +1214,9 @@ def main():
                      (pkg.binding.MFM_F_FORCE_DOT2 if args.kernel == "dot2" else 0) |
                      (pkg.binding.MFM_F_FORCE_MFMA_V1 if args.kernel == "mfma1" else 0) |
                      (pkg.binding.MFM_F_STREAM_TAPS if args.kernel == "mfma1s" else 0) |
-                     (pkg.binding.MFM_F_V3L_ONE_ROW_BLOCK if args.kernel == "v3l1" else 0),
+                     (pkg.binding.MFM_F_V3L_ONE_ROW_BLOCK if args.kernel == "v3l1" else 0) |
+                     (pkg.binding.MFM_F_SLICE_64 if args.kernel == "slice64" else 0) |
+                     (pkg.binding.MFM_F_SLICE_128 if args.kernel == "slice128" else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))

@@ -91,6 +91,11 @@ extern "C" {
 #define MFM_F_V3L_ONE_ROW_BLOCK 0x400u /* long filters on the second generation (mfm_kernel_v3l.hip): one row block (8 channels) per
                                   wave - slices of 64 channels - also where two would fit (slices of 128: the default for more
                                   than 64 channels when two row blocks' taps fit 128 registers); same bits; parity tests, A/B timing */
+#define MFM_F_SLICE_128 0x800u  /* 128-tap filters (filter/direct_fir.c:363-384 at multifm's 2.4 MS/s -> 25 kS/s geometry) on slices of
+                                  128 channels - two row blocks per wave share every B fragment and every staged image
+                                  (mfm_kernel_v3l.hip) - whatever the channel count; the default takes them from the channel count
+                                  at which they measured faster than slices of 64.  Same bits; parity tests, A/B timing */
+#define MFM_F_SLICE_64 0x1000u  /* ... never: slices of 64 channels (mfm_kernel_v3.hip) at any channel count */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 
@@ -300,8 +305,9 @@ size_t mfm_engine_get_launch_ms(struct mfm_engine *e, float *dst, size_t cap);
 /* MFM_F_TIMING, second-generation kernels: the last launches' durations in the shader's own clocks, oldest first - the
  * longest workgroup's s_memtime (shader-clock ticks) and s_memrealtime (100 MHz reference ticks) difference, stamped by the
  * kernel itself.  shader / ref * 100 MHz is the clock the launch really ran at; shader ticks against the kernel's issue
- * cycles is how much of the launch the SIMDs were issuing (bench.py: roofline.issue_model).  Waits for the engine to drain.
- * 0 entries for launches that left no stamp; returns the number of entries written (0 without MFM_F_TIMING or on the other
+ * cycles is how much of the launch the SIMDs were issuing (bench.py: roofline.issue_model).  Waits for the launches issued so
+ * far and nothing else: samples that were accepted and not yet launched stay where they are (no flush - the call is read-only,
+ * also on a device group's shard engines).  At most the last 512 launches.  0 entries for launches that left no stamp; returns the number of entries written (0 without MFM_F_TIMING or on the other
  * kernels).  Either array may be NULL. */
 size_t mfm_engine_get_launch_cycles(struct mfm_engine *e, uint64_t *shader_ticks, uint64_t *ref_ticks, size_t cap);
 
@@ -409,6 +415,28 @@ int mfm_group_get_stats(struct mfm_group *g, uint32_t shard, struct mfm_stats *s
 /* whether blocks travel through RCCL, how many blocks were pushed through it and how many bytes it moved to
  * non-root devices */
 int mfm_group_exchange_info(struct mfm_group *g, int *uses_rccl, uint64_t *blocks, uint64_t *bytes_exchanged);
+/* One shard of the exchange, as measured: what a scaling figure needs to be read (is a step bound by the exchange of the block -
+ * multifm/receiver.c:89-95's fan-out, here over xGMI - or by the shard's kernel?).  With MFM_F_TIMING the group brackets the
+ * RCCL calls of one block in four with an event pair on every shard's exchange stream. */
+struct mfm_exchange_detail {
+    int32_t device;            /* HIP device of the shard */
+    int32_t rccl_ranks;        /* ncclCommCount of the shard's communicator; 0: the group does not exchange; -1: the library has no such call */
+    char pci_bus_id[32];       /* hipDeviceGetPCIBusId of the device */
+    uint64_t timed_exchanges;  /* exchanges whose duration is in exchange_ms */
+    double exchange_ms;        /* sum of their durations on this shard's exchange stream */
+    uint64_t timed_launches;   /* the shard engine's mfm_stats::timed_launches ... */
+    double kernel_ms;          /* ... and ::kernel_ms */
+    uint32_t bound;            /* MFM_BOUND_KERNEL / MFM_BOUND_EXCHANGE: the larger of the two means; MFM_BOUND_UNKNOWN without both */
+    uint32_t reserved0;
+};
+#define MFM_BOUND_UNKNOWN 0u
+#define MFM_BOUND_KERNEL 1u
+#define MFM_BOUND_EXCHANGE 2u
+int mfm_group_exchange_detail(struct mfm_group *g, uint32_t shard, struct mfm_exchange_detail *out);
+/* Which RCCL a device group of more than one GPU uses: loads it as mfm_group_commit() would - a librccl that is mapped into the
+ * process already (PyTorch brings its own), else the loader's search for the bare name (LD_LIBRARY_PATH, the cache), then
+ * $ROCM_PATH/lib/librccl.so and /opt/rocm/lib/librccl.so - and writes the file's path.  MFM_E_DEVICE when none can be loaded. */
+int mfm_group_rccl_library(char *path, size_t cap);
 
 /*
  * ---- PCM stage behind the FIFO -------------------------------------------

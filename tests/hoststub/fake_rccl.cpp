@@ -117,6 +117,11 @@ int ncclCommDestroy(void *c)
     delete static_cast<FakeComm *>(c);
     return 0;
 }
+int ncclCommCount(void *c, int *count)
+{
+    *count = static_cast<FakeComm *>(c)->size;
+    return 0;
+}
 int ncclGroupStart() { g_depth++; return 0; }
 int ncclGroupEnd() { return --g_depth ? 0 : flush(); }
 int ncclBroadcast(const void *s, void *d, size_t count, int dtype, int root, void *c, hipStream_t st)

@@ -11,6 +11,7 @@ void stub_set_busy(int busy);
 unsigned long stub_pushed(void);
 unsigned long stub_samples(void);
 unsigned long stub_busy_returns(void);
+unsigned long stub_order_errors(void);
 
 static aresult_t rx_func(struct receiver *rx) { (void)rx; return A_OK; }
 static aresult_t cleanup_func(struct receiver *rx) { (void)rx; return A_OK; }
@@ -50,6 +51,8 @@ int main(int argc, char **argv)
             continue;
         }
         memset(sb->data_buf, 0, spb * 4);
+        const uint32_t seq = delivered; /* the device double checks that buffers arrive once each, in order (stride / offset of runs) */
+        memcpy(sb->data_buf, &seq, sizeof(seq));
         sb->nr_samples = (uint32_t)spb;
         if (FAILED(receiver_sample_buf_deliver(&rx, sb))) {
             return 5;
@@ -70,6 +73,8 @@ int main(int argc, char **argv)
     if (pool_back) {
         sb->nr_samples = (uint32_t)spb;
         memset(sb->data_buf, 0, spb * 4);
+        const uint32_t seq = delivered;
+        memcpy(sb->data_buf, &seq, sizeof(seq));
         if (FAILED(receiver_sample_buf_deliver(&rx, sb)) || FAILED(receiver_drain(&rx))) {
             return 7;
         }
@@ -77,9 +82,9 @@ int main(int argc, char **argv)
     }
     printf("{\"delivered\": %u, \"dropped\": %u, \"alloc_fails\": %zu, \"pushed_while_stalled\": %lu, \"pushed\": %lu, "
            "\"samples\": %lu, \"busy_returns\": %lu, \"worst_deliver_ns_stalled\": %llu, \"worst_alloc_ns\": %llu, "
-           "\"pool_back\": %d}\n",
+           "\"pool_back\": %d, \"order_errors\": %lu}\n",
            delivered, dropped, alloc_fails_stalled, pushed_while_stalled, stub_pushed(), stub_samples(), stub_busy_returns(),
-           (unsigned long long)worst_deliver_stalled, (unsigned long long)worst_alloc_ns, pool_back);
+           (unsigned long long)worst_deliver_stalled, (unsigned long long)worst_alloc_ns, pool_back, stub_order_errors());
     if (FAILED(receiver_cleanup(&prx))) {
         return 8;
     }

@@ -13,12 +13,15 @@ struct mfm_group {
 };
 
 static _Atomic int g_busy;
-static _Atomic unsigned long g_pushed, g_samples, g_busy_returns;
+static _Atomic unsigned long g_pushed, g_samples, g_busy_returns, g_order_errors, g_next_seq;
 
 void stub_set_busy(int busy) { g_busy = busy; }
 unsigned long stub_pushed(void) { return g_pushed; }
 unsigned long stub_samples(void) { return g_samples; }
 unsigned long stub_busy_returns(void) { return g_busy_returns; }
+/* buffers whose first word was not the next sequence number (the test's front end numbers what it delivers): a wrong
+ * stride or offset in the receiver's run detection, a buffer pushed twice or out of order */
+unsigned long stub_order_errors(void) { return g_order_errors; }
 
 const char *mfm_last_error(void) { return "stub"; }
 const char *mfm_strerror(int e) { (void)e; return "stub"; }
@@ -52,6 +55,12 @@ int mfm_group_push(struct mfm_group *g, const void *data, size_t nr_samples, int
         g_busy_returns++;
         return MFM_E_BUSY;
     }
+    uint32_t seq = 0;
+    memcpy(&seq, data, sizeof(seq));
+    if (seq != (uint32_t)g_next_seq) {
+        g_order_errors++;
+    }
+    g_next_seq = seq + 1u;
     g_pushed++;
     g_samples += nr_samples;
     return MFM_OK;
@@ -71,7 +80,6 @@ int mfm_group_push_pinned_run(struct mfm_group *g, const void *first, size_t str
                               int format, uint64_t *ticket, size_t *accepted)
 {
     size_t k = count > 3 ? 3 : count;
-    (void)stride_bytes;
     if (accepted) {
         *accepted = 0;
     }
@@ -80,7 +88,7 @@ int mfm_group_push_pinned_run(struct mfm_group *g, const void *first, size_t str
         return MFM_E_BUSY;
     }
     for (size_t i = 0; i < k; i++) {
-        (void)mfm_group_push(g, first, nr_samples_each, format);
+        (void)mfm_group_push(g, (const uint8_t *)first + i * stride_bytes, nr_samples_each, format);
     }
     if (ticket) {
         *ticket = ++g_tickets;

@@ -25,6 +25,52 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.binding.ABI_SYMBOLS) == names
 
 
+def test_library_exports_nothing_but_the_declared_symbols(pkg):
+    """the kernels' launchers, instance selectors and tap helpers are shared between the library's objects only (a linker
+    version script generated from the header, tsl-sdr_amd/Makefile): `nm -D` lists exactly the header's names"""
+    import subprocess
+    so = os.path.join(ROOT, "tsl-sdr_amd", "libmultifm_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == _declared_functions()
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")
+
+
+def _fake_rccl(tmp_path, name="librccl.so"):
+    import subprocess
+    d = tmp_path / "private"
+    d.mkdir(exist_ok=True)
+    so = d / name
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", str(so), FAKE_RCCL], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return so
+
+
+def _rccl_probe(code, env):
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as ge\npkg = ge.load_package()\n" % ROOT + code],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    return r.stdout.strip().splitlines()[-1]
+
+
+def test_rccl_loader_prefers_a_mapped_library_then_the_search_path(pkg, tmp_path):
+    """mfm_group.hip load_rccl(): a librccl that the process has mapped already wins (PyTorch brings its own: a second copy in one
+    address space would carry its own device state); else the loader's search for the bare name.  Checked with the test double of
+    RCCL on a private path - no device involved: the library is only loaded and asked where it lives."""
+    so = _fake_rccl(tmp_path)
+    base = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "LD_PRELOAD")}
+    # 1. on no search path at all, but mapped by the process (ctypes) before the group asks
+    got = _rccl_probe("import ctypes; ctypes.CDLL(%r)\nprint(pkg.binding.rccl_library())" % str(so), dict(base, LD_LIBRARY_PATH=""))
+    assert os.path.realpath(got) == os.path.realpath(so)
+    # 2. first on LD_LIBRARY_PATH
+    got = _rccl_probe("print(pkg.binding.rccl_library())", dict(base, LD_LIBRARY_PATH=str(so.parent)))
+    assert os.path.realpath(got) == os.path.realpath(so)
+
+
 def test_error_codes_and_messages(pkg):
     lib = pkg.load_library()
     assert lib.mfm_strerror(0) == b"ok"
@@ -156,7 +202,9 @@ def test_hand_counted_lds_waits_cover_their_reads():
     assert (reads, viol, unv) == (2, 2, 0)
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("no llvm tools here")
-    long_objs = [(f"mfm_kernel_v3l_kq{k}.o", "mfm_channel_kernel_v3l<", 6 if k == 4 else 40) for k in (4, 6, 8, 9, 10, 11, 12, 14, 16)]
+    # (round 6: every instruction of a matrix phase of the long-filter kernel is inline asm in an order computed at compile time,
+    # mfm_v3l_plan.h - fragment reads, transposition and staging stores alike count on LGKM and are replayed here)
+    long_objs = [(f"mfm_kernel_v3l_kq{k}.o", "mfm_channel_kernel_v3l<", 8 if k == 4 else 30) for k in (4, 6, 8, 9, 10, 11, 12, 14, 16)]
     for obj, flt, least in [("mfm_kernel_mfma.o", "mfm_channel_kernel_mfma<", 100), ("mfm_kernel_v3.o", "mfm_channel_kernel_v3<", 60)] + long_objs:
         path = os.path.join(root, "tsl-sdr_amd", "build", obj)
         if not os.path.exists(path):
@@ -186,10 +234,11 @@ def test_long_filter_instances_do_not_spill_where_it_would_matter():
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         for ln in r.stdout.splitlines():
-            m = re.match(r"mfm_channel_kernel_v3l<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (true|false)>.*vgpr +(\d+).*scratch +(\d+)", ln)
+            m = re.match(r"mfm_channel_kernel_v3l<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (true|false), (true|false)>.*vgpr +(\d+).*scratch +(\d+)", ln)
             assert m, ln
             seen += 1
-            # one row block per wave: never; two: a few chunk set-up values at most
-            assert int(m.group(9)) <= (0 if int(m.group(6)) == 1 else 96), ln
-            assert int(m.group(8)) <= 256
+            # round 6: no instance uses scratch at all (every matrix phase is asm; the accumulators, fragments and staging
+            # registers of a phase are live across hundreds of statements the compiler cannot reorder)
+            assert int(m.group(10)) == 0, ln
+            assert int(m.group(9)) <= 256
     assert seen >= 300

@@ -28,8 +28,8 @@ def _mk_engine(pkg, fs, decim, taps, offs, gains=None, max_block=1 << 16, want_i
         eng.add_channel(int(o), taps, float(g), want_iq=want_iq)
     eng.commit()
     variant = eng.stats()["kernel_variant"]
-    if kernel == "auto" and decim == 25 and len(taps) <= 150 and not want_iq and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
-        assert variant == 2, "decimation 25 without filtered IQ: the second-generation kernel on padded rows applies"
+    if kernel == "auto" and decim == 25 and len(taps) <= 150 and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
+        assert variant == 2, "decimation 25, with or without filtered IQ: the second-generation kernel on padded rows applies"
     if kernel == "dot2":
         assert variant == 0
     elif decim % 8 == 0 and len(taps) <= 128 and np.abs(_all_taps(eng, len(offs))).max() <= 32639:
@@ -94,10 +94,11 @@ def test_reference_shaped_configs(pkg, ora, name, kernel):
         # decimation 25 is not a multiple of 8: LDS rows padded from 50 to 64 bytes, zero taps over the padding
         # (filter/direct_fir.c:328-417 has no restriction on the decimation; neither have the matrix kernels): the second
         # generation on its padded-row layout since round 4, the first generation when forced
-        eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=4096, kernel=kernel)
-        st = eng.stats()
-        eng.close()
-        assert st["kernel_variant"] == (2 if kernel == "auto" else 1)
+        for want_iq in (False, True):   # (True: the DBG_IQ instances of the padded-row layout, round 6)
+            eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=4096, kernel=kernel, want_iq=want_iq)
+            st = eng.stats()
+            eng.close()
+            assert st["kernel_variant"] == (2 if kernel == "auto" else 1)
     if name == "multifm_1ch" and kernel == "auto":
         # etc/multifm.json, etc/multifm_1ch.json: decimation 40 - a multiple of 8, not of 32: the second-generation
         # kernel on its chunk-row LDS layout
@@ -313,9 +314,10 @@ def test_long_filters_stream_their_taps_through_the_matrix_kernel(pkg, ora, ntap
     assert eng.stats()["kernel_variant"] == 1 and eng.stats()["taps_resident"] == 0
     eng.close()
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq, kernel="mfma1s")
-    # without the flag: the second generation's long-filter kernel, unless a channel wants its filtered IQ (not built there)
+    # without the flag: the second generation's long-filter kernel - since round 6 also when a channel wants its filtered IQ
+    # (signalDebugFile, multifm/demod.c:75-81: a run-time switch in that kernel's epilogue)
     eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=1 << 16, want_iq=want_iq)
-    assert eng.stats()["kernel_variant"] == (1 if want_iq else 2), eng.stats()
+    assert eng.stats()["kernel_variant"] == 2, eng.stats()
     eng.close()
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 16, gains=gains, want_iq=want_iq)
 

@@ -282,7 +282,7 @@ def test_bench_group_path_over_the_fake_transport(tmp_path, shards):
     library's RCCL scatter + all-gather of every block, one process).  No multi-GPU node here: the same call path with
     --group-shards S puts S shards on the one device (MFM_F_GROUP_SHARED_DEVICE) over the test double of the RCCL calls.  The
     line must carry the exchange's counters and every shard's statistics, the shards must have moved in lock step, and
-    the self-check (shard 0's last launch against the oracle) must hold."""
+    the self-check (EVERY shard's last launch against the oracle, on the input that shard's launch read) must hold."""
     so = tmp_path / "librccl.so"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
                         os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
@@ -299,6 +299,18 @@ def test_bench_group_path_over_the_fake_transport(tmp_path, shards):
     assert g["exchange_info"]["uses_rccl"] and g["exchange_info"]["bytes_to_other_devices"] >= 5 * (shards - 1) * (4 << 21)
     assert len({sh["launches"] for sh in g["shards"]}) == 1 and all(sh["launches"] == 5 and sh["kernel_variant"] == 2 for sh in g["shards"])
     assert len({sh["pending_blocks"] for sh in g["shards"]}) == 1  # (device-only: nothing is fetched; the shards stay in step)
+    # what makes an N > 1 line readable: which RCCL, how many ranks it reports, every shard's device,
+    # exchange time against kernel time, and the same per-GPU shape on one device of the same run
+    x = g["exchange_info"]
+    assert x["rccl_ranks"] == shards and os.path.realpath(x["rccl_library"]) == os.path.realpath(so), x
+    assert len(x["per_shard"]) == shards
+    for d in x["per_shard"]:
+        assert d["rccl_ranks"] == shards and d["pci"] and d["timed_exchanges"] >= 1 and d["exchange_ms"] > 0.0, d
+        assert d["kernel_ms"] and d["kernel_ms"] > 0.0 and d["bound"] in ("kernel", "exchange"), d
+    assert line["verification"]["shards_verified"] == [True] * shards   # EVERY shard's last launch against the oracle
+    one = line["single_gpu_same_shape"]
+    assert one["channels"] == 40 and one["value"] > 0 and one["verified"] is True, one
+    assert abs(line["scaling_efficiency"] - line["value"] / (shards * one["value"])) < 1e-9 and line["config"]["channels_per_gpu"] == 40
 
 
 @pytest.mark.gpu

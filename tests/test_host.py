@@ -142,6 +142,7 @@ def test_deliver_never_blocks_and_a_stalled_device_drops_at_the_pool(tmp_path):
     # 8 frames: the submit thread holds one (retrying its push), seven more wait in the ring; the other 32 reads are dropped
     assert res["delivered"] == 8 + 1 and res["dropped"] == 32 and res["alloc_fails"] == 32
     assert res["pushed_while_stalled"] == 0 and res["busy_returns"] > 0
+    assert res["order_errors"] == 0 and res["pushed"] == res["delivered"], res  # runs: every buffer once, in order, from its own address
     assert res["pushed"] == 9 and res["samples"] == 9 * 4096 and res["pool_back"] == 1
     # deliver() queues a pointer: microseconds even on a loaded CI host, never the 200-us retry period of the old loop
     assert res["worst_deliver_ns_stalled"] < 100_000, res

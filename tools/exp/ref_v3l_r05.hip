@@ -35,21 +35,42 @@
 #include "mfm_numerics.h"
 
 #include "mfm_v3_device.h"
-#include "mfm_v3l_plan.h"
-
-typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
 
 #ifndef MFM3L_ONLY_KQ
 #define MFM3L_ONLY_KQ 0 /* > 0: this translation unit holds the instances of that k-step count only (the Makefile compiles the
                            file once per count, side by side) */
 #endif
-#ifndef MFM3L_KNOCK
-#define MFM3L_KNOCK 0 /* TIMING-ONLY builds (wrong results), tools/exp/variant_l.sh: bit 2 = no barrier behind an image, bit 3 = no
-                         epilogue, bit 4 = no matrix phase (and with it no staging) */
-#endif
 #ifndef MFM3L_PF
 #define MFM3L_PF 4 /* k-steps of B fragments in flight ahead of the matrix instructions (2 where all 128 tap registers are in use) */
 #endif
+
+/* "at most `younger` LDS requests issued after the ones that fill h (and l) are still outstanding": the wait in front of the
+ * products of a B fragment that was requested by inline asm.  LDS returns in order and everything else that counts on
+ * lgkmcnt only adds to it, so the wait can be too long, never too short.  The operands tie the wait to the registers. */
+template <bool ONE_PLANE>
+static __device__ __forceinline__ void mfm3l_wait_fragments(int younger, mfm_v4i &h, mfm_v4i &l)
+{
+#define MFM3L_WAIT_CASE(N_)                                                    \
+    case N_:                                                                   \
+        if (ONE_PLANE) {                                                       \
+            asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(h)::"memory");    \
+        } else {                                                               \
+            asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(h), "+v"(l)::"memory"); \
+        }                                                                      \
+        break;
+    switch (younger) {
+        MFM3L_WAIT_CASE(1) MFM3L_WAIT_CASE(2) MFM3L_WAIT_CASE(3) MFM3L_WAIT_CASE(4) MFM3L_WAIT_CASE(5) MFM3L_WAIT_CASE(6)
+        MFM3L_WAIT_CASE(7) MFM3L_WAIT_CASE(8)
+    default:
+        if (ONE_PLANE) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h)::"memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h), "+v"(l)::"memory");
+        }
+        break;
+    }
+#undef MFM3L_WAIT_CASE
+}
 
 /* KQ: k-steps of 64 elements held in registers (6 .. 16: mfm_v3l_built_kq); NG: column groups per staged image (4: a tile, 2: half a tile);
  * NCH: 4-sample staging chunks a thread owns per image (a surplus chunk is loaded and not stored); IN8: the input is 8-bit
@@ -73,66 +94,18 @@ constexpr int mfm3l_waves_per_simd(int KQ, int NH, int RB, bool SHIFT, bool IN8)
     return (SHIFT && IN8 && KQ == 4 && RB == 1 && NH <= 2) ? 4 : 2; /* (the int16 forms would spill at 128 registers) */
 }
 
-/* ---- compile-time loops: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) ---- */
-template <typename F, int... Is>
-static __device__ __forceinline__ void mfm3l_for_seq(F &&f, std::integer_sequence<int, Is...>)
-{
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-static __device__ __forceinline__ void mfm3l_for(F &&f)
-{
-    mfm3l_for_seq(f, std::make_integer_sequence<int, N>{});
-}
-
-/* word K of a staging chunk (a template, so that the one-sample chunks of the shifted-copies form are never asked for a .y) */
-template <int K, typename T>
-static __device__ __forceinline__ uint32_t mfm3l_word(const T &c)
-{
-    if constexpr (K == 0) {
-        return c.x;
-    } else if constexpr (K == 1) {
-        return c.y;
-    } else if constexpr (K == 2) {
-        return c.z;
-    } else {
-        return c.w;
-    }
-}
-
-/* the schedule of one phase as a compile-time object (only ever used in constant expressions: nothing of it exists on the device) */
-template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool SHIFTRD, bool DB, bool PI, bool CO, int NST>
-struct mfm3l_plan_of {
-    static constexpr auto value = mfm3l_make_plan<KQ, NH, NGC, RB, IN8, PF, SHIFTRD, DB, PI, CO, NST>();
-};
-
-/* two accumulator sets (a column group's recombination in the gaps of the next group's matrix instructions) where the taps leave
- * the registers for them: 12 * RB more (8 * RB without a high tap plane) */
-constexpr bool mfm3l_two_acc_sets(int KQ, int NH, int RB, bool SHIFT, bool IN8)
-{
-    return mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8) == 2 && 4 * RB * (KQ + NH) <= 80;
-}
-
-/* SPLIT: the decimation is not a multiple of 4 - a 4-sample staging chunk can straddle two rows of the image and is stored sample
- * by sample, behind the matrix phase as in round 5 (such decimations are small: the image is a few hundred chunks) */
-template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SHIFT = false, bool SPLIT = false>
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SHIFT = false>
 __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8)) void mfm_channel_kernel_v3l(const mfm_launch_v3 L)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     static_assert(NG == 1 || NG == 2 || NG == 4, "an image is a tile, half or a quarter of one");
     static_assert(RB == 1 || RB == 2, "row blocks (of 16 rows = 8 channels) per wave");
-    constexpr int NSUB = 4 / NG;                     /* images per tile */
-    constexpr uint32_t OPI = 16u * (uint32_t)NG;     /* outputs per image */
+    constexpr uint32_t NSUB = 4u / (uint32_t)NG; /* images per tile */
+    constexpr uint32_t OPI = 16u * (uint32_t)NG; /* outputs per image */
     static_assert(NH >= 0 && NH <= KQ, "planes held");
     /* two k-steps ahead where the taps take 112 registers or more and the fragments are pairs */
     /* (and with four waves per SIMD, which have each other to hide an LDS round trip and 128 registers each) */
     constexpr int PF = ((4 * RB * (KQ + NH) >= 112 && !IN8) || mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8) == 4) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
-    constexpr int SLOTS = PF + 1;
-    /* SHADOW: the next image's staging stores sit in the gaps of this image's matrix instructions, and the image after next is
-     * requested from memory as soon as a chunk's registers are free (a whole phase to arrive) */
-    constexpr bool SHADOW = !SHIFT && !SPLIT;
-    constexpr bool DB = mfm3l_two_acc_sets(KQ, NH, RB, SHIFT, IN8);
-    constexpr int NACC = DB ? 2 : 1;
     struct one_sample { uint32_t x; };
     using chunk_t = typename std::conditional<SHIFT, one_sample, typename std::conditional<IN8, uint2, uint4>::type>::type;
 
@@ -142,12 +115,9 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
     const uint32_t kg = lane >> 4, n = lane & 15u;
     const uint32_t D = L.decim, row_bytes = L.row_bytes, rs = L.rs;
     const uint32_t plane_pitch = L.plane_pitch, buf_pitch = L.buf_pitch;
-    const bool split_rows = SPLIT;
+    const bool split_rows = L.split_rows != 0u;
     const uint32_t in8_sh = (uint32_t)__builtin_amdgcn_readfirstlane(L.in8);
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(smem + L.lut_off);
-    /* some channel of the set wants its filtered IQ (signalDebugFile, multifm/demod.c:75-81): a run-time switch here - a
-     * wave-uniform branch around a 16-byte store per channel and tile - where mfm_kernel_v3.hip has instances */
-    const bool want_iq = L.iq_dbg != nullptr;
 
     /* atan LUT, once per workgroup: {T[i], T[i+1]-T[i]} pairs as the engine holds them */
     static_assert(MFM3_NT == 512, "one table dword per thread");
@@ -160,19 +130,11 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
      * decimations that are not multiples of 4 read those) */
     uint16_t *sta16_s = reinterpret_cast<uint16_t *>(smem + L.sta_off);
     uint8_t *sta_in_row_s = smem + L.sta_off + NCH * MFM3_NT * 2u;
-    /* SHADOW: the offsets stay in registers, and a chunk past the image's last one is the last one again (the same bytes to the
-     * same place: no lane is ever masked off in the matrix phase) */
-    uint32_t sta_r[NCH];
 #pragma unroll
     for (int j = 0; j < NCH && !SHIFT; j++) {
-        uint32_t q = tid + (uint32_t)j * MFM3_NT;
-        if (SHADOW) {
-            q = q < L.nstage4 ? q : L.nstage4 - 1u;
-        }
-        const uint32_t s0 = q * 4u;
+        const uint32_t s0 = (tid + (uint32_t)j * MFM3_NT) * 4u;
         const uint32_t r0 = s0 / D, c0 = s0 % D;
-        sta_r[j] = r0 * rs + 2u * c0;
-        sta16_s[j * MFM3_NT + tid] = (uint16_t)sta_r[j];
+        sta16_s[j * MFM3_NT + tid] = (uint16_t)(r0 * rs + 2u * c0);
         if (split_rows) {
             sta_in_row_s[j * MFM3_NT + tid] = (uint8_t)min(4u, D - c0);
         }
@@ -180,14 +142,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
 
     /* B fragments: column n of the image's first column group, k-step kq, lane group kg reads 16 bytes at element
      * 64 kq + 16 kg of the window that starts at row n: row n + e / row_bytes, byte e % row_bytes */
-    /* (where the taps take 96 registers or more: two 16-bit offsets per register, taken apart by the address add's operand
-     * selection - an image plane is less than 32 KB) */
-    constexpr bool BPACK = 4 * RB * (KQ + NH) >= 96;
-    uint32_t boff[BPACK ? (KQ + 1) / 2 : KQ];
-#pragma unroll
-    for (int kq = 0; kq < (BPACK ? (KQ + 1) / 2 : KQ); kq++) {
-        boff[kq] = 0;
-    }
+    uint32_t boff[KQ];
 #pragma unroll
     for (int kq = 0; kq < KQ; kq++) {
         const uint32_t step = (L.kperm[kq >> 2] >> (8 * (kq & 3))) & 0xffu; /* the kq-th k-step multiplied is this one of the window */
@@ -195,25 +150,11 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         if constexpr (SHIFT) {
             /* column n = nc * a + c (nc = 8 / D copies): copy c, aligned offset 16 a; L.sp_pitch = bytes between two copies */
             const uint32_t nc = 8u / D;
-            const uint32_t o = (n % nc) * L.sp_pitch + 16u * (n / nc) + e;
-            boff[BPACK ? kq / 2 : kq] |= BPACK ? o << (16 * (kq & 1)) : o;
+            boff[kq] = (n % nc) * L.sp_pitch + 16u * (n / nc) + e;
         } else {
-            const uint32_t o = (n + e / row_bytes) * rs + e % row_bytes;
-            boff[BPACK ? kq / 2 : kq] |= BPACK ? o << (16 * (kq & 1)) : o;
+            boff[kq] = (n + e / row_bytes) * rs + e % row_bytes;
         }
     }
-    /* at = base + the lane's offset of k-step KQI */
-    auto frag_addr = [&](auto kq_tag, uint32_t &dst, uint32_t base) {
-        constexpr int KQI = decltype(kq_tag)::value;
-        (void)&boff; /* (named outside a dependent expression: the generic lambda captures it when it is defined) */
-        if constexpr (!BPACK) {
-            asm volatile("v_add_u32 %0, %1, %2" : "=v"(dst) : "s"(base), "v"(boff[KQI]));
-        } else if constexpr ((KQI & 1) == 0) {
-            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(dst) : "s"(base), "v"(boff[KQI / 2]));
-        } else {
-            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(dst) : "s"(base), "v"(boff[KQI / 2]));
-        }
-    };
 
     /* sample index (from L.x) of the first sample of the image that starts at output `out` of this launch */
     auto image_start = [&](int out) -> int { return (int)L.hist + out * (int)D; };
@@ -252,33 +193,23 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
             }
         }
     };
-    /* 4 samples of an image, chunk q of it.  Only a readable address is needed: samples past n_avail feed only outputs >= n_new
-     * (never stored) or zero-padded taps; an image never starts in front of the buffer (the output in front of a launch has
-     * its first row there: L.hist). */
-    auto stage_load_q = [&](int s_first, uint32_t q) -> chunk_t {
-        int gs = s_first + 4 * (int)q;
-        gs = gs < 0 ? 0 : gs;
-        gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
-        if constexpr (SHIFT) {
-            return chunk_t{};
-        } else if constexpr (IN8) {
-            return *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 1));
-        } else {
-            return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
-        }
-    };
-    /* chunk j of this thread in the matrix phase's numbering (a chunk past the image's last one is the last one again) */
-    auto chunk_of = [&](int j) -> uint32_t {
-        const uint32_t q = tid + (uint32_t)j * MFM3_NT;
-        return q < L.nstage4 ? q : L.nstage4 - 1u;
-    };
     auto stage_load = [&](int s_first, int j) -> chunk_t {
         if constexpr (SHIFT) {
             chunk_t r{};
             r.x = stage_load1(s_first, j);
             return r;
         } else {
-            return stage_load_q(s_first, tid + (uint32_t)j * MFM3_NT);
+        /* 4 samples of an image.  Only a readable address is needed: samples past n_avail feed only outputs >= n_new (never
+         * stored) or zero-padded taps; an image never starts in front of the buffer (the output in front of a launch has
+         * its first row there: L.hist). */
+        int gs = s_first + 4 * (int)(tid + (uint32_t)j * MFM3_NT);
+        gs = gs < 0 ? 0 : gs;
+        gs = gs > (int)L.x_last4 ? (int)L.x_last4 : gs;
+        if constexpr (IN8) {
+            return *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 1));
+        } else {
+            return *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.x) + ((uint32_t)gs << 2));
+        }
         }
     };
     auto stage_store = [&](uint32_t buf, int j, const chunk_t &v, uint32_t nchunk) {
@@ -354,7 +285,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
     uint32_t *tp_s = reinterpret_cast<uint32_t *>(aux) + wave * (8u * RB * MFM_V3L_TP);
     /* what this lane writes after a column group (row block r, channel 2 kg + c at + (8 r + c) * TP dwords, output 16 g + n
      * at + 16 g) and what it reads back for the epilogue (outputs 4n .. 4n + 3) */
-    const uint32_t tp_w_addr = (uint32_t)(uintptr_t)(tp_s + (2u * kg) * MFM_V3L_TP + n);
+    uint32_t *tp_w = tp_s + (2u * kg) * MFM_V3L_TP + n;
     const uint4 *tp_r = reinterpret_cast<const uint4 *>(tp_s + (2u * kg) * MFM_V3L_TP + 4u * n);
     uint8_t *per_wave = aux + 8u * 8u * RB * MFM_V3L_TP * 4u;
     uint2 *fold_s = reinterpret_cast<uint2 *>(per_wave) + (wave * 4u + kg) * (2u * RB);
@@ -394,244 +325,109 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         ch_ok[r][0] = ch_ok[r][1] = w_exact[r] = false;
     }
 
-    /* ---- registers of the matrix phases (mfm_v3l_plan.h has the schedule) ---- */
-    mfm_v4i acc[NACC][RB][3];           /* hh, md, ll of the column group in flight (and, DB, of the one before) */
-    mfm_v4i bh[SLOTS], bl[IN8 ? 1 : SLOTS]; /* B fragments, rotating */
-    uint32_t tq[RB][4], fq[RB][2];      /* recombined sums / packed filtered samples of the group being finished */
-    chunk_t pre[NCH];                   /* SHADOW: the image behind the one in the idle buffer, on its way from memory */
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int a = 0; a < NACC; a++) {
-                acc[a][r][k] = mfm_v4i{ 0, 0, 0, 0 };
-            }
-        }
-        tq[r][0] = tq[r][1] = tq[r][2] = tq[r][3] = fq[r][0] = fq[r][1] = 0;
-    }
-
-    /*
-     * One image's matrix phase: NGC column groups of (RB x 16) rows x 16 columns x 64 * KQ elements, four byte-plane products
-     * per k-step and row block (two with one sample plane), the B fragments used by every row block of the wave.  Everything in
-     * it is a single-instruction asm statement in the order of the plan: the compiler allocates the registers and nothing else.
-     *   MAIN: image H of the tile.  Its column groups' packed filtered samples (first Q14 rounding done; lane (kg, n) holds
-     *   channels 2 kg, 2 kg + 1 of column n) go to the wave's transposition area; with two accumulator sets the last group is
-     *   left to the next image of the tile (its recombination sits in that phase's gaps).  SHADOW: the chunks in `pre` go to
-     *   the idle buffer in the gaps, and as soon as a chunk is stored its successor (the image that starts at output n2_out) is
-     *   requested into the same registers.
-     *   FRONT: the one-group image in front of a chunk; the samples stay in fq.
-     */
-    auto phase = [&](auto ngc_tag, auto h_tag, auto main_tag, uint32_t lds_h, uint32_t lds_other, int n2_out) {
-        constexpr int NGC = decltype(ngc_tag)::value, H = decltype(h_tag)::value;
-        constexpr bool MAIN = decltype(main_tag)::value;
-        constexpr bool PDB = DB && MAIN;
-        constexpr bool PEND_IN = PDB && H > 0, CARRY_OUT = PDB && H + 1 < NSUB;
-        constexpr int P0 = PDB ? (H * NG) & 1 : 0;
-        constexpr int NST = (MAIN && SHADOW) ? NCH : 0;
-        using plan_t = mfm3l_plan_of<KQ, NH, NGC, RB, IN8, PF, SHIFT, PDB, PEND_IN, CARRY_OUT, NST>;
-        constexpr int NMF = mfm3l_nmf(KQ, NH, NGC, RB, IN8), NS = NGC * KQ;
-        constexpr int PL = RB == 2 ? 24576 : 31744; /* mfm_v3l_plane_pitch: the low plane lies a constant behind the high one */
-
+    /* One image's matrix phase: NGC column groups of (RB x 16) rows x 16 columns x 64 * KQ elements, four byte-plane products
+     * per k-step and row block (two with one sample plane), B fragments requested PF k-steps ahead across the groups and
+     * used by every row block of the wave.  sink(g, r, f) takes the packed filtered samples (first Q14 rounding done) of
+     * column group g, row block r: lane (kg, n) holds channels 2 kg, 2 kg + 1 of column n. */
+    auto matrix_phase = [&](auto ngc_tag, uint32_t lds_h, auto &&sink) {
+        constexpr int NGC = decltype(ngc_tag)::value;
+        constexpr int RPK = IN8 ? 1 : 2, SLOTS = PF + 1, NS = NGC * KQ;
+        static_assert(PF * RPK <= 8, "the wait helper counts up to eight younger requests");
+        mfm_v4i hh[RB], md[RB], ll[RB];
+        mfm_v4i bh[SLOTS], bl[SLOTS];
+        /* (the address arithmetic is inline asm as well: left to the compiler, "fragment offset + group offset (+ plane
+         * pitch)" is loop invariant and gets hoisted - a register per (column group, k-step, plane), which the instances
+         * with 128 tap registers do not have) */
         const uint32_t lds_u = (uint32_t)__builtin_amdgcn_readfirstlane(lds_h);
-        const uint32_t sto_u = (uint32_t)__builtin_amdgcn_readfirstlane(lds_other);
-        uint32_t at = 0, at_l = 0, sa = 0, s0 = 0, s1 = 0;
-        /* (named here so that every level of these nested generic lambdas captures them when it is defined) */
-#define MFM3L_CAPTURES (void)&bl, (void)&bh, (void)&acc, (void)&tq, (void)&fq, (void)&pre, (void)&a_h, (void)&a_l, (void)&krow, (void)&boff, (void)&sta_r; (void)&at, (void)&at_l, (void)&sa, (void)&s0, (void)&s1
-        MFM3L_CAPTURES;
-
-        auto filler = [&](auto idx_tag) {
-            MFM3L_CAPTURES;
-            constexpr int I = decltype(idx_tag)::value;
-            constexpr mfm3l_fl F = plan_t::value.fl[I];
-            if constexpr (F.kind == MFM3L_F_ADD || F.kind == MFM3L_F_ADDL) {
-                constexpr int ST = F.a;
-                const uint32_t gbase = lds_u + (uint32_t)(ST / KQ) * 16u * rs + (F.kind == MFM3L_F_ADDL ? plane_pitch : 0u);
-                if constexpr (F.kind == MFM3L_F_ADD) {
-                    frag_addr(std::integral_constant<int, ST % KQ>{}, at, gbase);
-                } else {
-                    frag_addr(std::integral_constant<int, ST % KQ>{}, at_l, gbase);
-                }
-            } else if constexpr (F.kind == MFM3L_F_RDH) {
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bh[F.a % SLOTS]) : "v"(at) : "memory");
-            } else if constexpr (F.kind == MFM3L_F_RDL) {
-                if constexpr (SHIFT) {
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(bl[IN8 ? 0 : F.a % SLOTS]) : "v"(at_l) : "memory");
-                } else {
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[IN8 ? 0 : F.a % SLOTS]) : "v"(at), "n"(PL) : "memory");
-                }
-            } else if constexpr (F.kind == MFM3L_F_LA) {
-                /* t = (x << 8) + y over the group's accumulators: (hh, md) then (t, ll); without a high tap plane (md, ll); one
-                 * sample plane: (hh, ll) */
-                constexpr int A = !PDB ? 0 : F.c == MFM3L_G_PEND ? (P0 + 1) & 1 : (P0 + F.c) & 1; /* which accumulator set */
-                constexpr int R = F.a, E = F.b, LV = F.d;
-                constexpr int NLA = mfm3l_la_levels(IN8, NH);
-                if constexpr (NLA == 2 && LV == 0) {
-                    asm volatile("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(tq[R][E]) : "v"(acc[A][R][0][E]), "v"(acc[A][R][1][E]));
-                } else if constexpr (NLA == 2) {
-                    asm volatile("v_lshl_add_u32 %0, %0, 8, %1" : "+v"(tq[R][E]) : "v"(acc[A][R][2][E]));
-                } else if constexpr (IN8) {
-                    asm volatile("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(tq[R][E]) : "v"(acc[A][R][0][E]), "v"(acc[A][R][2][E]));
-                } else {
-                    asm volatile("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(tq[R][E]) : "v"(acc[A][R][1][E]), "v"(acc[A][R][2][E]));
-                }
-            } else if constexpr (F.kind == MFM3L_F_SH0 || F.kind == MFM3L_F_SH1) {
-                /* bits 29:14 (8-bit input: the format's shift) of the biased sums as (re | im << 16) */
-                constexpr int A = !PDB ? 0 : F.c == MFM3L_G_PEND ? (P0 + 1) & 1 : (P0 + F.c) & 1; /* which accumulator set */
-                constexpr int R = F.a, C = F.b, E = 2 * F.b + (F.kind == MFM3L_F_SH1 ? 1 : 0);
-                constexpr bool DIRECT = mfm3l_la_levels(IN8, NH) == 0; /* one sample plane, no high tap plane: the sum is ll itself */
-                if constexpr (F.kind == MFM3L_F_SH0) {
-                    if constexpr (IN8 && DIRECT) {
-                        asm volatile("v_lshrrev_b32_sdwa %0, %2, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(fq[R][C]) : "v"(acc[A][R][2][E]), "s"(in8_sh));
-                    } else if constexpr (IN8) {
-                        asm volatile("v_lshrrev_b32_sdwa %0, %2, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(fq[R][C]) : "v"(tq[R][E]), "s"(in8_sh));
-                    } else {
-                        asm volatile("v_lshrrev_b32_sdwa %0, 14, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(fq[R][C]) : "v"(tq[R][E]));
-                    }
-                } else {
-                    if constexpr (IN8 && DIRECT) {
-                        asm volatile("v_lshrrev_b32_sdwa %0, %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(fq[R][C]) : "v"(acc[A][R][2][E]), "s"(in8_sh));
-                    } else if constexpr (IN8) {
-                        asm volatile("v_lshrrev_b32_sdwa %0, %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(fq[R][C]) : "v"(tq[R][E]), "s"(in8_sh));
-                    } else {
-                        asm volatile("v_lshrrev_b32_sdwa %0, 14, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(fq[R][C]) : "v"(tq[R][E]));
-                    }
-                }
-            } else if constexpr (F.kind == MFM3L_F_TPW) {
-                if constexpr (MAIN) {
-                    /* column group (H * NG + g) of the tile, row block R, channel 2 kg + C of it: [channel][output] */
-                    constexpr int POS = F.c == MFM3L_G_PEND ? H * NG - 1 : H * NG + F.c;
-                    static_assert(POS >= 0 && POS < 4, "a group left to the next image stays inside its tile");
-                    constexpr int OFF = (POS * 16 + (F.a * 8 + F.b) * (int)MFM_V3L_TP) * 4;
-                    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(tp_w_addr), "v"(fq[F.a][F.b]), "n"(OFF) : "memory");
-                }
-            } else if constexpr (F.kind == MFM3L_F_STG) {
-                constexpr int J = F.a, OP = F.b;
-                if constexpr (OP == 0) {
-                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(sa) : "s"(sto_u), "v"(sta_r[J]));
-                } else if constexpr (IN8) {
-                    if constexpr (OP == 1) {
-                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(s0) : "s"(L.in8_xor), "v"(mfm3l_word<0>(pre[J])));
-                    } else if constexpr (OP == 2) {
-                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(s1) : "s"(L.in8_xor), "v"(mfm3l_word<1>(pre[J])));
-                    } else {
-                        const mfm_v2u w = { s0, s1 };
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(sa), "v"(w) : "memory");
-                    }
-                } else {
-                    /* dword = [lo0 hi0 lo1 hi1]: the high bytes of four int16 into one dword, the low bytes (- 128) into another */
-                    if constexpr (OP == 1) {
-                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s0) : "v"(mfm3l_word<1>(pre[J])), "v"(mfm3l_word<0>(pre[J])), "s"(0x07050301u));
-                    } else if constexpr (OP == 2) {
-                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s1) : "v"(mfm3l_word<3>(pre[J])), "v"(mfm3l_word<2>(pre[J])), "s"(0x07050301u));
-                    } else if constexpr (OP == 3) {
-                        const mfm_v2u w = { s0, s1 };
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(sa), "v"(w) : "memory");
-                    } else if constexpr (OP == 4) {
-                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s0) : "v"(mfm3l_word<1>(pre[J])), "v"(mfm3l_word<0>(pre[J])), "s"(0x06040200u));
-                    } else if constexpr (OP == 5) {
-                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s1) : "v"(mfm3l_word<3>(pre[J])), "v"(mfm3l_word<2>(pre[J])), "s"(0x06040200u));
-                    } else if constexpr (OP == 6) {
-                        asm volatile("v_xor_b32 %0, 0x80808080, %0" : "+v"(s0));
-                    } else if constexpr (OP == 7) {
-                        asm volatile("v_xor_b32 %0, 0x80808080, %0" : "+v"(s1));
-                    } else {
-                        const mfm_v2u w = { s0, s1 };
-                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(w), "n"(PL) : "memory");
-                    }
-                }
-            } else if constexpr (F.kind == MFM3L_F_NOP16) {
-                /* matrix result -> vector instruction: 16 wait states cover a 16x16x64 matrix instruction */
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-            }
-        };
-        /* the successor of a stored chunk: the same registers, a whole phase to arrive */
-        auto reload = [&](auto m_tag) {
-            MFM3L_CAPTURES;
-            if constexpr (NST > 0) {
-                constexpr int M = decltype(m_tag)::value;
-                mfm3l_for<NST>([&](auto j_tag) {
-                    MFM3L_CAPTURES;
-                    constexpr int J = decltype(j_tag)::value;
-                    if constexpr (plan_t::value.stg_done[J] == M) {
-                        pre[J] = stage_load_q(image_start(n2_out), chunk_of(J));
-                    }
-                });
-            }
-        };
-
-        /* the first PF k-steps' fragments */
-        mfm3l_for<(PF < NS ? PF : NS)>([&](auto st_tag) {
-            MFM3L_CAPTURES;
-            constexpr int ST = decltype(st_tag)::value;
-            const uint32_t gbase = lds_u + (uint32_t)(ST / KQ) * 16u * rs;
-            frag_addr(std::integral_constant<int, ST % KQ>{}, at, gbase);
-            asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ST % SLOTS]) : "v"(at) : "memory");
+        auto request = [&](int st) { /* step st = column group st / KQ, k-step st % KQ */
+            const uint32_t gbase = lds_u + (uint32_t)(st / KQ) * 16u * rs;
+            uint32_t at;
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(at) : "s"(gbase), "v"(boff[st % KQ]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bh[st % SLOTS]) : "v"(at) : "memory");
             if constexpr (!IN8) {
                 if constexpr (SHIFT) {
                     const uint32_t gbase_l = gbase + plane_pitch;
-                    frag_addr(std::integral_constant<int, ST % KQ>{}, at_l, gbase_l);
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(bl[IN8 ? 0 : ST % SLOTS]) : "v"(at_l) : "memory");
+                    uint32_t at_l;
+                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(at_l) : "s"(gbase_l), "v"(boff[st % KQ]));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bl[st % SLOTS]) : "v"(at_l) : "memory");
                 } else {
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[IN8 ? 0 : ST % SLOTS]) : "v"(at), "n"(PL) : "memory");
+                    /* the low plane lies a constant behind the high one (mfm_v3l_plane_pitch): the same address register */
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[st % SLOTS]) : "v"(at), "n"(RB == 2 ? 24576 : 31744) : "memory");
                 }
             }
-        });
-        mfm3l_for<NMF>([&](auto m_tag) {
-            MFM3L_CAPTURES;
-            constexpr int M = decltype(m_tag)::value;
-            constexpr mfm3l_mf X = plan_t::value.mf[M];
-            constexpr int SL = X.step % SLOTS, A = PDB ? (P0 + X.g) & 1 : 0, R = X.r;
-            if constexpr (X.wait != 0xff) {
-                /* "at most `wait` LGKM operations issued behind this k-step's reads are still outstanding"; the operands tie
-                 * the wait to the registers */
-                if constexpr (IN8) {
-                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bh[SL]) : "n"(X.wait) : "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[SL]), "+v"(bl[IN8 ? 0 : SL]) : "n"(X.wait) : "memory");
-                }
-            }
-            /* the product: which tap plane, which sample plane, which accumulator */
-            constexpr int AC = X.prod == MFM3L_P_HH ? 0 : X.prod == MFM3L_P_LL ? 2 : 1;
-            constexpr bool TAP_H = X.prod == MFM3L_P_HH || X.prod == MFM3L_P_MDH;
-            constexpr bool SMP_H = IN8 || X.prod == MFM3L_P_HH || X.prod == MFM3L_P_MD;
-            const mfm_v4i &ta = TAP_H ? a_h[R][X.kq < NH ? X.kq : 0] : a_l[R][X.kq];
-            const mfm_v4i &sb = SMP_H ? bh[SL] : bl[IN8 ? 0 : SL];
-            if constexpr (X.init && AC == 2) {
-                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(acc[A][R][AC]) : "v"(ta), "v"(sb), "v"(krow[R]));
-            } else if constexpr (X.init) {
-                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc[A][R][AC]) : "v"(ta), "v"(sb));
-            } else {
-                asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[A][R][AC]) : "v"(ta), "v"(sb));
-            }
-            mfm3l_for<plan_t::value.gap_hi[M] - plan_t::value.gap_lo[M]>([&](auto i_tag) {
-                filler(std::integral_constant<int, plan_t::value.gap_lo[M] + decltype(i_tag)::value>{});
-            });
-            reload(m_tag);
-        });
-        mfm3l_for<plan_t::value.tail_hi - plan_t::value.tail_lo>([&](auto i_tag) {
-            filler(std::integral_constant<int, plan_t::value.tail_lo + decltype(i_tag)::value>{});
-        });
-        reload(std::integral_constant<int, NMF>{});
-#undef MFM3L_CAPTURES
-    };
-
-    if constexpr (SHADOW) {
-        /* the image behind the first one: on its way while the first tile is set up */
-        const int n1_out = NSUB > 1 ? (int)(tile * MFM_V3_OT + OPI) : (int)((tile + 1u < tend ? tile + 1u : tile) * MFM_V3_OT);
+        };
 #pragma unroll
-        for (int j = 0; j < NCH; j++) {
-            pre[j] = stage_load_q(image_start(n1_out), chunk_of(j));
+        for (int st = 0; st < PF && st < NS; st++) {
+            request(st);
         }
-    }
+#pragma unroll
+        for (int st = 0; st < NS; st++) {
+            const int gq = st / KQ, kq = st % KQ, cb = st % SLOTS;
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    hh[r] = mfm_v4i{ 0, 0, 0, 0 };
+                    md[r] = mfm_v4i{ 0, 0, 0, 0 };
+                    ll[r] = krow[r];
+                }
+            }
+            if (st + PF < NS) {
+                request(st + PF);
+            }
+            mfm3l_wait_fragments<IN8>((NS - 1 - st < PF ? NS - 1 - st : PF) * RPK, bh[cb], bl[cb]);
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                if constexpr (IN8) {
+                    if (kq < NH) {
+                        hh[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[r][kq < NH ? kq : 0], bh[cb], hh[r], 0, 0, 0);
+                    }
+                    ll[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[r][kq], bh[cb], ll[r], 0, 0, 0);
+                } else {
+                    if (kq < NH) { /* the k-steps whose high-byte tap plane is not all zero come first (L.kperm) */
+                        hh[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[r][kq < NH ? kq : 0], bh[cb], hh[r], 0, 0, 0);
+                        md[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[r][kq < NH ? kq : 0], bl[cb], md[r], 0, 0, 0);
+                    }
+                    ll[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[r][kq], bl[cb], ll[r], 0, 0, 0);
+                    md[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_l[r][kq], bh[cb], md[r], 0, 0, 0);
+                }
+            }
+            if (kq == KQ - 1) {
+                /* MFMA -> VALU read hazard: 16 wait states cover a 16x16x64 MFMA (hipcc has been seen to leave it unpadded) */
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    uint32_t a_re[2], a_im[2], f[2];
+                    if constexpr (IN8) {
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_re[c]) : "v"(hh[r][2 * c]), "v"(ll[r][2 * c]));
+                            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a_im[c]) : "v"(hh[r][2 * c + 1]), "v"(ll[r][2 * c + 1]));
+                        }
+                        mfm3_round_pack2_s(a_re, a_im, in8_sh, f);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            a_re[c] = mfm3_combine(hh[r][2 * c], md[r][2 * c], ll[r][2 * c]);
+                            a_im[c] = mfm3_combine(hh[r][2 * c + 1], md[r][2 * c + 1], ll[r][2 * c + 1]);
+                        }
+                        mfm3_round_pack2(a_re, a_im, f);
+                    }
+                    sink(gq, r, f);
+                }
+            }
+        }
+    };
 
     while (true) {
         /* this wave's row blocks: RB consecutive ones of the slice's 8 * RB; a row block past the last one recomputes the
          * last (its channels are past the end: nothing of it is stored) */
         const uint32_t rb0 = (slice * 8u + wave) * RB;
+        const bool rb_valid = rb0 < L.nrb; /* wave uniform */
         const uint32_t first_out = tile * MFM_V3_OT;
 
-        if (slice != slice_loaded) {
+        if (rb_valid && slice != slice_loaded) {
             /* A operand: 16 rows x (64 * KQ) elements, both byte planes, in fragment order, the k-steps in the order L.kperm */
 #pragma unroll
             for (int r = 0; r < RB; r++) {
@@ -665,7 +461,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         if (first_of_chunk) {
             const bool has_front = first_out != 0 || L.hist != 0; /* uniform over the workgroup */
             uint32_t wrx[RB][2], wry[RB][2];
-            {
+            if (rb_valid) {
                 /* ---- chunk set-up: where the lane's channels stand in their rotator tables and in the output ---- */
 #pragma unroll
                 for (int r = 0; r < RB; r++) {
@@ -748,14 +544,20 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                     }
                 }
                 __syncthreads();
-                phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::false_type{},
-                      (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch), 0u, 0);
+                if (rb_valid) {
+                    uint32_t fw[RB][2];
+                    matrix_phase(std::integral_constant<int, 1>{}, (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch),
+                                 [&](int, int r, const uint32_t (&f)[2]) {
+                                     fw[r][0] = f[0];
+                                     fw[r][1] = f[1];
+                                 });
 #pragma unroll
-                for (int r = 0; r < RB; r++) {
-                    uint32_t qw[2];
-                    derotate2(fq[r], wrx[r], wry[r], qw);
-                    hist[r][0] = qw[0];
-                    hist[r][1] = qw[1];
+                    for (int r = 0; r < RB; r++) {
+                        uint32_t qw[2];
+                        derotate2(fw[r], wrx[r], wry[r], qw);
+                        hist[r][0] = qw[0];
+                        hist[r][1] = qw[1];
+                    }
                 }
                 __syncthreads(); /* the idle buffer is free again: the first image's successor goes there */
             }
@@ -771,72 +573,59 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
             n_tend = (uint32_t)(((uint64_t)(n_chunk + 1u) * L.ntiles) / L.nchunks);
             n_first = true;
         }
-        const uint32_t t1 = n_valid ? n_tile : tile; /* the tile behind this one (a workgroup's last tile: itself - loads and
-                                                        stores of the loop are unconditional) */
-        uint32_t t2 = t1;                            /* ... and, whole-tile images only, the one behind that */
-        if (SHADOW && NSUB == 1) {
-            uint32_t a_chunk = n_chunk, a_slice = n_slice;
-            t2 = n_tile + 1u;
-            if (t2 >= n_tend) {
-                const bool a_valid = n_valid && mfm3_decode_item(L, n_item + gridDim.x, &a_chunk, &a_slice);
-                t2 = a_valid ? (uint32_t)(((uint64_t)a_chunk * L.ntiles) / L.nchunks) : t1;
-            }
-            t2 = n_valid ? t2 : t1;
-        }
         uint4 rva[RB][2];
-        if (prio_matrix) {
-            __builtin_amdgcn_s_setprio(1);
-        } else {
-            __builtin_amdgcn_s_setprio(0);
-        }
-        mfm3l_for<NSUB>([&](auto h_tag) {
-            constexpr int H = decltype(h_tag)::value;
-            if constexpr (SHADOW) {
-                /* the image behind the one in `pre` */
-                const int n2_out = H + 2 < NSUB ? (int)(first_out + (uint32_t)(H + 2) * OPI)
-                                                : NSUB == 1 ? (int)(t2 * MFM_V3_OT) : (int)(t1 * MFM_V3_OT + (uint32_t)(H + 2 - NSUB) * OPI);
-#if !(MFM3L_KNOCK & 16)
-                phase(std::integral_constant<int, NG>{}, h_tag, std::true_type{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch),
-                      (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch), n2_out);
-#endif
+        /* (not unrolled for part-tile images: several copies of the matrix phase cost the compiler 20-60 registers) */
+#pragma unroll 1
+        for (uint32_t h = 0; h < NSUB; h++) {
+            /* the image behind this one: the tile's next, or the first of the workgroup's next tile (a workgroup's last image
+             * re-reads its own samples into the idle buffer: loads and stores of the loop are unconditional) */
+            const int next_out = h + 1u < NSUB ? (int)(first_out + (h + 1u) * OPI)
+                                               : (int)((n_valid ? n_tile : tile) * MFM_V3_OT);
+            chunk_t pre[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                pre[j] = stage_load(image_start(next_out), j);
+            }
+            __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
+
+            if (prio_matrix) {
+                __builtin_amdgcn_s_setprio(1);
             } else {
-                /* the image behind this one: the tile's next, or the first of the workgroup's next tile */
-                const int next_out = H + 1 < NSUB ? (int)(first_out + (uint32_t)(H + 1) * OPI) : (int)(t1 * MFM_V3_OT);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (rb_valid) {
+                matrix_phase(std::integral_constant<int, NG>{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch),
+                             [&](int gq, int r, const uint32_t (&f)[2]) {
+                                 uint32_t *w = tp_w + (uint32_t)r * (8u * MFM_V3L_TP) + 16u * (h * (uint32_t)NG + (uint32_t)gq);
+                                 w[0] = f[0];
+                                 w[MFM_V3L_TP] = f[1];
+                             });
+                if (RB == 1 && h + 1u == NSUB) {
+                    /* rotator entries of this tile, four consecutive ones per channel: requested behind the tile's last matrix
+                     * phase, needed behind the staging stores and the barrier.  (In front of it - a matrix phase more to
+                     * arrive - measured 1 % slower: profiles/r05_long_filters.txt.)  With two row blocks per wave the sixteen
+                     * registers are not there across the staging stores - the compiler parked them in scratch, which waits for
+                     * the loads on the spot - so those instances ask at the top of the epilogue. */
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NCH; j++) {
-                    pre[j] = stage_load(image_start(next_out), j);
-                }
-                __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
-                phase(std::integral_constant<int, NG>{}, h_tag, std::true_type{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch), 0u, 0);
-                /* the next image goes to the other buffer; after the barrier nobody reads the current one any more */
-#pragma unroll
-                for (int j = 0; j < NCH; j++) {
-                    stage_store(cur ^ 1u, j, pre[j], L.nstage4);
+                    for (int c = 0; c < 2; c++) {
+                        rva[0][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[0][c]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (RB == 1 && H + 1 == NSUB) {
-                /* rotator entries of this tile, four consecutive ones per channel: requested behind the tile's last matrix
-                 * phase, needed behind the barrier.  With two row blocks per wave the sixteen registers are not there - those
-                 * instances ask at the top of the epilogue. */
-                __builtin_amdgcn_sched_barrier(0);
+            /* the next image goes to the other buffer; after the barrier nobody reads the current one any more */
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    rva[0][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[0][c]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NCH; j++) {
+                stage_store(cur ^ 1u, j, pre[j], L.nstage4);
             }
-            /* the stores of the phase are inline asm: the compiler does not know of them, the barrier needs them done */
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !(MFM3L_KNOCK & 4)
             __syncthreads();
-#endif
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0); /* the next image's loads stay behind this one's stores (their registers) */
             cur ^= 1u;
-        });
+        }
 
         __builtin_amdgcn_s_setprio(2); /* epilogue */
-#if !(MFM3L_KNOCK & 8)
-        {
+        if (rb_valid) {
             static_assert(MFM3_ROT4, "the long-filter kernel is written for 4-byte rotator entries");
             const uint32_t n_left = L.n_new - first_out; /* >= 1 */
             if (RB > 1) {
@@ -901,11 +690,6 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                             w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
                             w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
                             mfm3_store_pcm4(L.pcm, voff[r][c], w.x, w.y);
-                            if (want_iq) {
-                                /* the filtered samples beside the PCM: multifm/demod.c:75-81 writes them to signalDebugFile */
-                                *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + 2u * (size_t)voff[r][c]) =
-                                    make_uint4(q[0][c], q[1][c], q[2][c], q[3][c]);
-                            }
                         }
                     } else {
                         /* the last tile of the pass, partly filled */
@@ -913,9 +697,6 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                         for (int g = 0; g < 4; g++) {
                             if (ch_ok[r][c] && 4u * n + (uint32_t)g < n_left) {
                                 *reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[r][c] + 2u * g) = (int16_t)pcm[g];
-                                if (want_iq) {
-                                    *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + 2u * (size_t)voff[r][c] + 4u * g) = q[g][c];
-                                }
                             }
                         }
                     }
@@ -936,7 +717,6 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                 }
             }
         }
-#endif
 
         if (!n_valid) {
             break;
@@ -960,22 +740,19 @@ template <int KQ, int NH, int NG, int NCH, bool IN8, int RB>
 constexpr bool mfm3l_fits()
 {
     if (RB == 2) {
-        /* 128-channel slices: quarter-tile images (large decimations: configs[4]'s 400), or - few k-steps, small decimations:
-         * the 128-tap filters of 128 and more channels, multifm/receiver.c:195-244 builds as many as the configuration lists -
-         * whole-tile images, whose two row blocks' transposition areas then fit LDS beside them */
-        /* (a high tap plane brings a third accumulator per row block: eight registers the fullest instances do not have) */
-        return 8 * (KQ + NH) + (NH > 0 ? 8 : 0) <= 128 && NCH == 4 && (NG == 1 || (NG == 4 && KQ <= 4));
+        /* 128-channel slices: whole- and half-tile images of two row blocks' transposition areas do not fit LDS at the
+         * decimations that want them; built for quarter-tile images */
+        return NG == 1 && 8 * (KQ + NH) <= 128; /* (half-tile images with eight staging chunks per thread spill in the tile loop:
+                                                   0.26 -> 0.36 ms at configs[4]'s share, profiles/r05_long_filters.txt) */
     }
-    /* (eight staging chunks per thread: half-tile images of large decimations only - a whole-tile image that would need them
-     * runs as two half-tile ones) */
-    return NG != 1 && !(NCH == 8 && NG == 4) && (IN8 || 4 * (KQ + NH) + (NCH == 8 ? 32 : 16) + (NG == 2 ? 8 : 0) <= 160);
+    return NG != 1 && (IN8 || 4 * (KQ + NH) + (NCH == 8 ? 32 : 16) + (NG == 2 ? 8 : 0) <= 160);
 }
 
-template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SPLIT>
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB>
 static const void *mfm3l_instance_ptr()
 {
-    if constexpr (mfm3l_fits<KQ, NH, NG, NCH, IN8, RB>() && !(SPLIT && (NCH == 8 || RB == 2 || NG != 4))) {
-        return reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, NG, NCH, IN8, RB, false, SPLIT>);
+    if constexpr (mfm3l_fits<KQ, NH, NG, NCH, IN8, RB>()) {
+        return reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, NG, NCH, IN8, RB>);
     } else {
         return nullptr;
     }
@@ -985,16 +762,10 @@ template <int KQ, int NH, int NG, int RB>
 static const void *mfm3l_instance_fmt(const mfm_launch_v3 *L, uint32_t nch)
 {
     const bool big = mfm_v3l_built_nch(nch) == 8u;
-    if (L->split_rows) { /* decimations that are not multiples of 4 (small ones: four staging chunks, one row block per wave) */
-        if (L->in8) {
-            return big ? nullptr : mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB, true>();
-        }
-        return big ? nullptr : mfm3l_instance_ptr<KQ, NH, NG, 4, false, RB, true>();
-    }
     if (L->in8) {
-        return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, true, RB, false>() : mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB, false>();
+        return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, true, RB>() : mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB>();
     }
-    return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, false, RB, false>() : mfm3l_instance_ptr<KQ, NH, NG, 4, false, RB, false>();
+    return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, false, RB>() : mfm3l_instance_ptr<KQ, NH, NG, 4, false, RB>();
 }
 
 template <int KQ, int NH>
@@ -1010,17 +781,16 @@ static const void *mfm3l_instance_geo(const mfm_launch_v3 *L, uint32_t nch)
                           : reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, 4, 4, false, 1, true>);
         }
     }
+    if constexpr (KQ == 4) {
+        return nullptr; /* (the other layouts of this file start at five k-steps) */
+    } else {
     if (L->shift) {
         return nullptr;
     }
-    if constexpr (KQ == 4) {
-        /* four k-steps: 128-tap filters on 128-channel slices (the layouts of mfm_kernel_v3.hip take them on slices of 64) */
-        return (L->rb == 2u && L->ng == 4u) ? mfm3l_instance_fmt<KQ, NH, 4, 2>(L, nch) : nullptr;
-    } else {
-        if (L->rb == 2u) {
-            return L->ng == 1u ? mfm3l_instance_fmt<KQ, NH, 1, 2>(L, nch) : L->ng == 4u ? mfm3l_instance_fmt<KQ, NH, 4, 2>(L, nch) : nullptr;
-        }
-        return L->ng == 4u ? mfm3l_instance_fmt<KQ, NH, 4, 1>(L, nch) : L->ng == 2u ? mfm3l_instance_fmt<KQ, NH, 2, 1>(L, nch) : nullptr;
+    if (L->rb == 2u) {
+        return L->ng == 1u ? mfm3l_instance_fmt<KQ, NH, 1, 2>(L, nch) : nullptr;
+    }
+    return L->ng == 4u ? mfm3l_instance_fmt<KQ, NH, 4, 1>(L, nch) : L->ng == 2u ? mfm3l_instance_fmt<KQ, NH, 2, 1>(L, nch) : nullptr;
     }
 }
 
@@ -1032,7 +802,8 @@ static const void *mfm3l_instance(const mfm_launch_v3 *L, uint32_t nch)
     switch (mfm_v3l_built_nh((uint32_t)KQ, L->nh)) {
     case 0: return mfm3l_instance_geo<KQ, 0>(L, nch);
     case 2: return mfm3l_instance_geo<KQ, 2>(L, nch);
-    case 4: return mfm3l_instance_geo<KQ, (KQ < 4 ? KQ : 4)>(L, nch);
+    case 4: return mfm3l_instance_geo<KQ, 4>(L, nch);
+    case 8: return mfm3l_instance_geo<KQ, (KQ < 8 ? KQ : 8)>(L, nch);
     default: return mfm3l_instance_geo<KQ, KQ>(L, nch);
     }
 }

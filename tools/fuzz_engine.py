@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def case(pkg, ora, rng, long_only=False):
+def case(pkg, ora, rng, long_only=False, slice128=False):
     b = pkg.binding
     decim = int(rng.choice([25, 32, 40, 40, 64, 96, 96, 96, 100, 128, 400, 8 * int(rng.randint(1, 16)), int(rng.randint(6, 200))]))
     fs = int(rng.choice([1000000, 1200000, 2400000, 10000000]))
@@ -37,6 +37,14 @@ def case(pkg, ora, rng, long_only=False):
         decim = int(rng.choice([1, 1, 2, 4, 4, 3, 5, 6, 7]))
         ntaps = int(rng.choice([128, 128, 64, 65, 200, 256, 512, 16, decim + int(rng.randint(0, 300))]))
     nch = int(rng.choice([1, 2, 5, 8, 9, 16, 33, 64, 65, 130, int(rng.randint(1, 300))]))
+    if slice128:
+        # round 6: filters of up to 128 taps at decimations that are multiples of 32 on SLICES OF 128 CHANNELS (two row blocks per
+        # wave, whole-tile images of mfm_kernel_v3l.hip): channel counts around the slice and row-block boundaries
+        decim = int(rng.choice([96, 96, 96, 64, 128, 32]))
+        ntaps = int(rng.choice([128, 128, 128, 127, 100, decim, decim + int(rng.randint(0, 129 - decim))]))
+        ntaps = max(decim, min(ntaps, 128))
+        nch = int(rng.choice([128, 129, 130, 136, 200, 255, 256, 257, 300, 65, 17, int(rng.randint(1, 400))]))
+        small = False
     taps = pkg.synth.design_lpf(ntaps, float(rng.choice([5000.0, 12500.0, 40000.0])), fs) * float(rng.choice([1.0, 1.0, 3.0, 0.2]))
     if long_only and rng.rand() < 0.25:
         taps = rng.uniform(-0.3, 0.3, ntaps)  # high bytes in every k-step: the all-planes instances
@@ -53,8 +61,12 @@ def case(pkg, ora, rng, long_only=False):
     want_iq = bool(rng.rand() < 0.5)
     stream = bool(rng.rand() < 0.2)
     if long_only:
-        kernel, want_iq = "auto", bool(rng.rand() < 0.15)
+        kernel, want_iq = "auto", bool(rng.rand() < 0.3)
+    if slice128:
+        kernel, want_iq = "auto", bool(rng.rand() < 0.25)
     n = int(rng.randint(ntaps, 400000))
+    if slice128:
+        n = int(rng.randint(ntaps, max(ntaps + 1, min(400000, int(4.0e9 * decim / (ntaps * nch))))))
     if small:
         # bounded oracle work: n / D outputs x taps x channels
         n = int(rng.randint(ntaps, max(ntaps + 1, min(400000, int(2.0e9 * decim / (ntaps * nch))))))
@@ -64,7 +76,8 @@ def case(pkg, ora, rng, long_only=False):
         iq = pkg.synth.synth_iq(n, fs, offs[: min(nch, 6)], seed=int(rng.randint(1 << 30)))
     max_block = int(rng.choice([n, 65536, 8192, 100000]))
     flags = (b.MFM_F_FORCE_DOT2 if kernel == "dot2" else 0) | (b.MFM_F_FORCE_MFMA_V1 if kernel == "mfma1" else 0) | \
-            (b.MFM_F_STREAM_TAPS if stream else 0) | (b.MFM_F_V3L_ONE_ROW_BLOCK if rng.rand() < 0.3 else 0)
+            (b.MFM_F_STREAM_TAPS if stream else 0) | (b.MFM_F_V3L_ONE_ROW_BLOCK if rng.rand() < 0.3 else 0) | \
+            (b.MFM_F_SLICE_128 if (slice128 and rng.rand() < 0.9) or rng.rand() < 0.3 else 0)
     try:
         eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
         for o, g in zip(offs, gains):
@@ -127,7 +140,8 @@ def case8(pkg, ora, rng, long_only=False):
         offs = np.where(snap, q * rng.randint(-2 * decim + 1, 2 * decim, size=nch), offs)
     gains = rng.choice([1.0, 2.5118864315095806, 0.3], size=nch)
     max_block = int(rng.choice([65536, 8192, 100000]))
-    flags = (b.MFM_F_WIDEN_8BIT if rng.rand() < 0.15 else 0) | (b.MFM_F_STREAM_TAPS if rng.rand() < 0.2 else 0)
+    flags = (b.MFM_F_WIDEN_8BIT if rng.rand() < 0.15 else 0) | (b.MFM_F_STREAM_TAPS if rng.rand() < 0.2 else 0) | \
+            (b.MFM_F_SLICE_128 if rng.rand() < 0.4 else 0)
     try:
         eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags)
         for o, g in zip(offs, gains):
@@ -203,6 +217,7 @@ def case_stream(pkg, ora, rng, long_only=False):
     flags |= b.MFM_F_OVERLAP if rng.rand() < 0.5 else 0
     flags |= b.MFM_F_WIDEN_8BIT if rng.rand() < 0.1 else 0
     flags |= b.MFM_F_STREAM_TAPS if rng.rand() < 0.1 else 0
+    flags |= b.MFM_F_SLICE_128 if rng.rand() < 0.35 else 0
     try:
         eng = pkg.Engine(fs, decim, max_block, device=0, flags=flags, coalesce_samples=coalesce)
         for o, g in zip(offs, gains):
@@ -326,6 +341,7 @@ def main():
     ap.add_argument("--ingest8", action="store_true", help="8-bit ingest streams (mfm_engine_push_bytes) instead")
     ap.add_argument("--stream", action="store_true", help="coalescing / two streams / pinned pushes / flush / seek (round 4 engine logic)")
     ap.add_argument("--long", action="store_true", help="filters of 129..512 taps only (resident and streamed tap instances)")
+    ap.add_argument("--slice128", action="store_true", help="filters of up to 128 taps on 128-channel slices (round 6: MFM_F_SLICE_128)")
     args = ap.parse_args()
     from __graft_entry__ import load_package
     import oracle_lib as ora
@@ -337,7 +353,7 @@ def main():
         if args.stream:
             err, info = case_stream(pkg, ora, rng, args.long)
         else:
-            err, info = case8(pkg, ora, rng, args.long) if args.ingest8 else case(pkg, ora, rng, args.long)
+            err, info = case8(pkg, ora, rng, args.long) if args.ingest8 else case(pkg, ora, rng, args.long, args.slice128)
         if err:
             print("FAIL", err, "after", counts)
             return 1

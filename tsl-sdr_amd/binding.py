@@ -25,6 +25,8 @@ MFM_F_STREAM_TAPS = 0x80
 MFM_F_GATHER = 0x100
 MFM_F_OVERLAP = 0x200
 MFM_F_V3L_ONE_ROW_BLOCK = 0x400
+MFM_F_SLICE_128 = 0x800
+MFM_F_SLICE_64 = 0x1000
 MFM_RCP_TABLE_HASH_GFX950 = 0x706D94BC005BCC1A  # include/multifm_hip.h
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 
@@ -49,10 +51,27 @@ ABI_SYMBOLS = [
     "mfm_f32_process_device", "mfm_f32_process_host",
     "mfm_shard_range", "mfm_group_create", "mfm_group_destroy", "mfm_group_add_channel", "mfm_group_commit",
     "mfm_group_nr_shards", "mfm_group_shard_info", "mfm_group_push", "mfm_group_fetch", "mfm_group_release",
-    "mfm_group_sync", "mfm_group_get_stats", "mfm_group_exchange_info",
+    "mfm_group_sync", "mfm_group_get_stats", "mfm_group_exchange_info", "mfm_group_exchange_detail", "mfm_group_rccl_library",
     "mfm_flex_create", "mfm_flex_destroy", "mfm_flex_process_device", "mfm_flex_process_host", "mfm_flex_fetch_events",
     "mfm_mm_create", "mfm_mm_destroy", "mfm_mm_max_decisions", "mfm_mm_process_device", "mfm_mm_process_host",
 ]
+
+class ExchangeDetail(C.Structure):
+    """struct mfm_exchange_detail"""
+    _fields_ = [("device", C.c_int32), ("rccl_ranks", C.c_int32), ("pci_bus_id", C.c_char * 32), ("timed_exchanges", C.c_uint64),
+                ("exchange_ms", C.c_double), ("timed_launches", C.c_uint64), ("kernel_ms", C.c_double), ("bound", C.c_uint32),
+                ("reserved0", C.c_uint32)]
+
+
+def rccl_library():
+    """the RCCL file a device group of more than one GPU would use (mfm_group_rccl_library); raises MfmError when none loads"""
+    lib = load_library()
+    buf = C.create_string_buffer(1024)
+    rc = lib.mfm_group_rccl_library(buf, len(buf))
+    if rc < 0:
+        raise MfmError(rc, "mfm_group_rccl_library", lib.mfm_last_error().decode())
+    return buf.value.decode()
+
 
 MFM_POCSAG_EV_SYNC_FOUND, MFM_POCSAG_EV_BATCH, MFM_POCSAG_EV_SYNC_LOST, MFM_POCSAG_EV_SYNC_KEPT = 1, 2, 3, 4
 
@@ -244,6 +263,8 @@ def load_library():
     lib.mfm_engine_get_launch_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]
     lib.mfm_engine_get_launch_cycles.restype = C.c_size_t
     lib.mfm_engine_stream.restype = vp
+    lib.mfm_group_exchange_detail.argtypes = [vp, C.c_uint32, vp]
+    lib.mfm_group_rccl_library.argtypes = [C.c_char_p, C.c_size_t]
     lib.mfm_strerror.argtypes = [C.c_int]
     lib.mfm_strerror.restype = C.c_char_p
     lib.mfm_last_error.restype = C.c_char_p
@@ -652,6 +673,16 @@ class Group:
         u, b, x = C.c_int(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.mfm_group_exchange_info(self.h, C.byref(u), C.byref(b), C.byref(x)), "mfm_group_exchange_info")
         return bool(u.value), b.value, x.value
+
+    def exchange_detail(self, shard):
+        """one shard of the exchange as measured (mfm_group_exchange_detail): dict"""
+        d = ExchangeDetail()
+        self._chk(self.lib.mfm_group_exchange_detail(self.h, shard, C.byref(d)), "mfm_group_exchange_detail")
+        x = d.exchange_ms / d.timed_exchanges if d.timed_exchanges else None
+        k = d.kernel_ms / d.timed_launches if d.timed_launches else None
+        return {"device": d.device, "pci": d.pci_bus_id.decode(errors="replace"), "rccl_ranks": d.rccl_ranks,
+                "exchange_ms": x, "kernel_ms": k, "timed_exchanges": d.timed_exchanges, "timed_launches": d.timed_launches,
+                "bound": {0: None, 1: "kernel", 2: "exchange"}[d.bound]}
 
 
 class Resampler:

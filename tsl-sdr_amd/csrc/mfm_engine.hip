@@ -78,6 +78,8 @@ constexpr uint64_t kSparseTiming = 4; /* MFM_F_TIMING_SPARSE: one launch in this
 constexpr uint64_t kCycleRing = 1024; /* launches whose shader-clock stamps are kept (mfm_engine_get_launch_cycles) */
 constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine_get_launch_ms() */
 constexpr uint32_t kMaxOutputsPerTile = 128;
+/* 128-tap filters: slices of 128 channels from this many channels on (below, slices of 64: MFM_F_SLICE_128 / _64 override) */
+constexpr uint32_t kSlice128MinChannels = 0xffffffffu; /* measured (profiles/r06_slice128_ab.txt): slices of 64 stay ahead at every count */
 constexpr uint64_t kMaxRotEntries = 1ull << 26; /* per distinct increment: 512 MiB of table */
 
 struct Channel {
@@ -165,6 +167,7 @@ struct mfm_engine {
     /* matrix-core path (mfm_kernel_mfma.hip) */
     bool use_mfma = false;
     uint32_t m_row_bytes = 0, m_nstage = 0;
+    bool slice128 = false;        /* 128-tap filters on 128-channel slices (layout 3, two row blocks per wave) */
     uint32_t m_ks = 0, m_ot = 0, m_rs = 0, m_plane_bytes = 0, m_lut_off = 0, m_krow_off = 0, m_nrb = 0,
              m_nslices = 0, m_lds_bytes = 0, m_wg_per_cu = 1;
     uint32_t m_wg_fmt[4] = { 1, 1, 1, 1 }; /* workgroups per CU of the instance each input format runs (select_kernels) */
@@ -1103,8 +1106,7 @@ static int commit_locked(struct mfm_engine *e)
     std::vector<int32_t> krow;
     /* decimations 1, 2, 4 (etc/multifm_file.json: 1): rows shorter than a fragment - the long-filter kernel keeps 8 / D shifted
      * copies of the image instead of padding them (mfm_kernel_v3l.hip, SHIFT); the window is then the unpadded 2 T elements */
-    const bool shift_geo = (1u == D || 2u == D || 4u == D) && T <= 512u && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_FORCE_DOT2)) &&
-                           ![&] { for (const Channel &c : e->chans) { if (c.want_iq) { return true; } } return false; }();
+    const bool shift_geo = (1u == D || 2u == D || 4u == D) && T <= 512u && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_FORCE_DOT2));
     const uint32_t row_bytes_p = shift_geo ? 2u * D : (2u * D + 15u) & ~15u;
     const uint32_t k_elems = ((T - 1u) / D) * row_bytes_p + 2u * ((T - 1u) % D) + 2u; /* element index of the last tap + 1 */
     e->use_mfma = 8u * D >= 3u * row_bytes_p && k_elems <= 64u * MFM_MFMA_KQ_STREAM_MAX &&
@@ -1253,7 +1255,7 @@ static int commit_locked(struct mfm_engine *e)
         }
     }
 
-    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && 25u == D && T <= 150u && !e->any_iq) {
+    if (e->use_mfma && !(e->cfg.flags & MFM_F_FORCE_MFMA_V1) && 25u == D && T <= 150u) {
         /* decimation 25 (etc/pocsag_rtlsdr.json) on the second generation: rows of 50 plane bytes padded to 64, so that a k-step
          * is exactly one row and a window of up to 150 taps spans six of them (layout 2, mfm_kernel.h); sub-planes at the fixed
          * pitch, the image staged sample by sample.  The tap fragments are laid out for six k-steps. */
@@ -1346,12 +1348,16 @@ static int commit_locked(struct mfm_engine *e)
             e->use_mfma = false; /* the v_dot2 kernel */
         }
     }
-    if (e->use_mfma && !e->use_v3 && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_STREAM_TAPS)) && e->m_ks >= 8u &&
-        e->m_ks <= MFM_V3L_KQ_MAX && !e->any_iq) {
-        /* ---- filters of 129..512 taps on the second-generation structure (layout 3, mfm_kernel_v3l.hip): the first
-         *      generation's image - plain rows of m_row_bytes plane bytes at stride m_rs, any decimation - holding a whole
-         *      64-output tile, or half of one when two whole ones do not fit LDS (decimation 400 of configs[4]: 112 KB per
-         *      image of both planes); same tap fragments, same row constants. ---- */
+    /* ---- filters of 129..512 taps on the second-generation structure (layout 3, mfm_kernel_v3l.hip): the first
+     *      generation's image - plain rows of m_row_bytes plane bytes at stride m_rs, any decimation - holding a whole
+     *      64-output tile, or half of one when two whole ones do not fit LDS (decimation 400 of configs[4]: 112 KB per
+     *      image of both planes); same tap fragments, same row constants.
+     *      And (round 6) 128-tap filters on SLICES OF 128 CHANNELS where there are that many: two row blocks per wave share
+     *      every B fragment and every staged image - half the LDS traffic and half the staging work per (channel, output) of
+     *      the 64-channel layouts above, for two waves per SIMD instead of four.  multifm/receiver.c:195-244 builds as many
+     *      channels as the configuration lists; north_star's shape is 1024 of them on one GPU. ---- */
+    struct l3_cand { uint32_t rb, ng; };
+    auto plan_layout3 = [&](const l3_cand *cand, size_t nr_cand) -> bool {
         const uint32_t row_bytes = e->m_row_bytes, rs_l = e->m_rs;
         const uint32_t kq_inst = mfm_v3l_built_kq(e->m_kq_used);
         /* k-steps whose high-byte tap plane is not all zero (what m_ah_mask will say once the fragments are built) */
@@ -1373,9 +1379,8 @@ static int commit_locked(struct mfm_engine *e)
          * half the B-fragment traffic per (channel, output) - where there are more than 64 channels and two row blocks' taps
          * fit 128 registers, on quarter-tile images; else slices of 64 on whole- or half-tile images */
         const uint32_t nh_inst = mfm_v3l_built_nh(kq_inst, (uint32_t)__builtin_popcount(hi_mask));
-        struct { uint32_t rb, ng; } cand[3] = { { 2u, 1u }, { 1u, 4u }, { 1u, 2u } };
-        for (const auto &cd : cand) {
-            const uint32_t ng = cd.ng, rbw = cd.rb;
+        for (size_t ci = 0; ci < nr_cand; ci++) {
+            const uint32_t ng = cand[ci].ng, rbw = cand[ci].rb;
             if (2u == rbw && (e->m_nrb <= 8u || 8u * (kq_inst + nh_inst) > 128u || (e->cfg.flags & MFM_F_V3L_ONE_ROW_BLOCK))) {
                 continue;
             }
@@ -1404,6 +1409,7 @@ static int commit_locked(struct mfm_engine *e)
             probe.ng = ng;
             probe.rb = rbw;
             probe.nstage4 = nstage4;
+            probe.split_rows = (D % 4u) != 0u ? 1u : 0u; /* (sample-by-sample staging: instances of their own, one row block per wave) */
             probe.ah_mask = hi_mask;
             const void *fn = nullptr;
             if (mfm_select_channel_kernel_v3(&probe, 0, &fn) != hipSuccess) {
@@ -1443,8 +1449,24 @@ static int commit_locked(struct mfm_engine *e)
                                     ((uint32_t)order[4 * w + 3] << 24);
                 }
             }
-            break;
+            return true;
         }
+        return false;
+    };
+    if (e->use_mfma && !e->use_v3 && !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_STREAM_TAPS)) && e->m_ks >= 8u &&
+        e->m_ks <= MFM_V3L_KQ_MAX) {
+        /* (row blocks per wave, column groups per image), best first: slices of 128 channels on quarter-tile images where there
+         * are more than 64 channels and two row blocks' taps fit 128 registers; else slices of 64 on whole- or half-tile images */
+        const l3_cand cand[3] = { { 2u, 1u }, { 1u, 4u }, { 1u, 2u } };
+        plan_layout3(cand, 3);
+    }
+    e->slice128 = false;
+    if (e->use_mfma && e->use_v3 && 0u == e->v_layout && 4u == e->m_ks && (2u * D) % 64u == 0u &&
+        !(e->cfg.flags & (MFM_F_FORCE_MFMA_V1 | MFM_F_SLICE_64)) &&
+        ((e->cfg.flags & MFM_F_SLICE_128) || C >= kSlice128MinChannels)) {
+        /* the sub-plane layout above stays what runs when the instance is not built (more than two high-byte tap planes) */
+        const l3_cand cand[1] = { { 2u, 4u } };
+        e->slice128 = plan_layout3(cand, 1);
     }
 
     e->v_nslices = (e->use_v3 && 3u == e->v_layout) ? (e->m_nrb + 8u * e->v_rb - 1u) / (8u * e->v_rb) : e->m_nslices;
@@ -1963,6 +1985,9 @@ int launch_locked(mfm_engine *e)
             if (e->d_cyc) {
                 V.cyc = e->d_cyc + 2u * (e->launches % kCycleRing);
                 V.cyc_tag = (uint32_t)((e->launches + 1u) & 0xffffffu);
+                /* ... and zeroes the slot half a ring ahead, long before that launch folds its maxima into it: a slot never
+                 * holds an older launch's stamp when its turn comes, whatever the 24-bit tags compare like after 2^24 launches */
+                V.cyc_clear = e->d_cyc + 2u * ((e->launches + kCycleRing / 2u) % kCycleRing);
             }
             if (raw8) {
                 e->launches_8bit++;
@@ -2939,14 +2964,19 @@ size_t mfm_engine_get_launch_cycles(struct mfm_engine *e, uint64_t *shader_ticks
     if (!e || !e->committed || !e->d_cyc) {
         return 0;
     }
-    if (hipSetDevice(e->cfg.device) != hipSuccess || mfm_engine_sync(e) != MFM_OK) {
+    /* Only what HAS been launched is waited for: this is a read-only call (also on the engines of a device group, from whatever
+     * thread looks at the figures) - a flush from here would launch one shard of a gathering group by itself and take the
+     * shards out of step. */
+    if (hipSetDevice(e->cfg.device) != hipSuccess || hipStreamSynchronize(e->s_compute) != hipSuccess ||
+        (e->ncs > 1u && hipStreamSynchronize(e->cs[1]) != hipSuccess)) {
         return 0;
     }
     std::vector<unsigned long long> ring(kCycleRing * 2);
     if (hipMemcpy(ring.data(), e->d_cyc, ring.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
         return 0;
     }
-    const uint64_t have = std::min<uint64_t>(e->launches, kCycleRing);
+    /* (a launch clears the slot half a ring ahead of its own: the newer half of the ring is what can be read) */
+    const uint64_t have = std::min<uint64_t>(e->launches, kCycleRing / 2u);
     const size_t n = (size_t)std::min<uint64_t>(have, cap);
     for (size_t i = 0; i < n; i++) {
         const uint64_t seq = e->launches - n + i; /* 0-based index of the launch */

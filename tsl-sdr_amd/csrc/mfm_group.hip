@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -34,6 +35,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/multifm_hip.h"
@@ -68,36 +71,85 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(nccl_comm_t, int *) = nullptr;
 };
 constexpr int kNcclInt8 = 0; /* rccl.h: ncclInt8 = ncclChar = 0 */
 
+/* a librccl that is mapped into the process already: its path (dl_iterate_phdr) */
+int find_mapped_rccl(struct dl_phdr_info *info, size_t, void *out)
+{
+    const char *name = info->dlpi_name;
+    if (name && *name) {
+        const char *base = strrchr(name, '/');
+        base = base ? base + 1 : name;
+        if (0 == strncmp(base, "librccl.so", 10)) {
+            snprintf(static_cast<char *>(out), 1024, "%s", name);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* One process may carry several copies of RCCL (PyTorch ships its own beside /opt/rocm's); two of them in one address space
+ * each bring their own device state.  So: whatever is mapped already wins; else the loader's own search for the bare name
+ * (LD_LIBRARY_PATH, the cache), and where that finds nothing the ROCm tree the environment names and the usual place. */
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+char g_rccl_path[1024];
+
 int load_rccl(RcclApi *api)
 {
-    if (api->lib) {
-        return MFM_OK;
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.lib) {
+        void *h = nullptr;
+        std::string tried;
+        char mapped[1024] = "";
+        if (dl_iterate_phdr(find_mapped_rccl, mapped) && mapped[0]) {
+            h = dlopen(mapped, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            tried += std::string(mapped) + " (mapped); ";
+        }
+        std::vector<std::string> cands;
+        cands.push_back("librccl.so"); /* the loader's search: LD_LIBRARY_PATH, the cache */
+        cands.push_back("librccl.so.1");
+        if (const char *rocm = getenv("ROCM_PATH")) {
+            if (*rocm) {
+                cands.push_back(std::string(rocm) + "/lib/librccl.so");
+            }
+        }
+        cands.push_back("/opt/rocm/lib/librccl.so");
+        for (size_t i = 0; i < cands.size() && !h; i++) {
+            h = dlopen(cands[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                tried += cands[i] + "; ";
+            }
+        }
+        if (!h) {
+            return gfail(MFM_E_DEVICE, "cannot load librccl.so (tried: %s last error: %s): a device group of more than one GPU needs RCCL",
+                         tried.c_str(), dlerror());
+        }
+        RcclApi a;
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(h, "ncclBroadcast"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount")); /* optional */
+        if (!a.CommInitAll || !a.CommDestroy || !a.Broadcast || !a.GroupStart || !a.GroupEnd || !a.AllGather || !a.Send || !a.Recv) {
+            dlclose(h);
+            return gfail(MFM_E_DEVICE, "librccl.so lacks a required entry point");
+        }
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void *>(a.CommInitAll), &di) && di.dli_fname) {
+            snprintf(g_rccl_path, sizeof(g_rccl_path), "%s", di.dli_fname);
+        }
+        a.lib = h;
+        g_rccl = a;
     }
-    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) {
-        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    }
-    if (!h) {
-        return gfail(MFM_E_DEVICE, "cannot load librccl.so (%s): a device group of more than one GPU needs RCCL", dlerror());
-    }
-    api->CommInitAll = reinterpret_cast<decltype(api->CommInitAll)>(dlsym(h, "ncclCommInitAll"));
-    api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-    api->Broadcast = reinterpret_cast<decltype(api->Broadcast)>(dlsym(h, "ncclBroadcast"));
-    api->AllGather = reinterpret_cast<decltype(api->AllGather)>(dlsym(h, "ncclAllGather"));
-    api->Send = reinterpret_cast<decltype(api->Send)>(dlsym(h, "ncclSend"));
-    api->Recv = reinterpret_cast<decltype(api->Recv)>(dlsym(h, "ncclRecv"));
-    api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(dlsym(h, "ncclGroupStart"));
-    api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(dlsym(h, "ncclGroupEnd"));
-    api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!api->CommInitAll || !api->CommDestroy || !api->Broadcast || !api->GroupStart || !api->GroupEnd || !api->AllGather ||
-        !api->Send || !api->Recv) {
-        dlclose(h);
-        return gfail(MFM_E_DEVICE, "librccl.so lacks a required entry point");
-    }
-    api->lib = h;
+    *api = g_rccl;
     return MFM_OK;
 }
 
@@ -122,6 +174,13 @@ struct mfm_group {
     std::vector<nccl_comm_t> comm;
     std::vector<hipStream_t> xs; /* exchange stream per shard (shard 0: the root engine's copy stream) */
     uint64_t blocks = 0, bytes_exchanged = 0;
+    /* MFM_F_TIMING: one exchange in four is bracketed by an event pair on every shard's exchange stream */
+    std::vector<hipEvent_t> x0, x1;
+    std::vector<double> x_ms;
+    std::vector<uint64_t> x_n;
+    bool x_open = false;      /* a pair has been recorded and not yet folded */
+    uint64_t x_seq = 0;       /* exchanges so far */
+    std::mutex x_mu;          /* the sums, between the push thread and whoever asks (mfm_group_exchange_detail) */
     std::atomic<bool> broken{ false }; /* a push failed after the first shard had taken the block (mfm_group_seq.h); the push
                                           thread writes it, the fetch thread reads it */
     std::mutex mu;       /* push's submit loop against fetch's "does every shard hold a block" */
@@ -196,6 +255,16 @@ static void group_release(mfm_group *g)
         }
     }
     g->comm.clear();
+    for (size_t i = 0; i < g->x0.size(); i++) {
+        (void)hipSetDevice(g->dev[i]);
+        (void)hipEventDestroy(g->x0[i]);
+        (void)hipEventDestroy(g->x1[i]);
+    }
+    g->x0.clear();
+    g->x1.clear();
+    g->x_ms.clear();
+    g->x_n.clear();
+    g->x_open = false;
     for (size_t i = 1; i < g->xs.size(); i++) { /* xs[0] belongs to the root engine */
         if (g->xs[i]) {
             (void)hipSetDevice(g->dev[i]);
@@ -328,6 +397,19 @@ int mfm_group_commit(struct mfm_group *g)
             }
         }
     }
+    if (g->exchange && (g->cfg.flags & MFM_F_TIMING)) {
+        g->x_ms.assign(S, 0.0);
+        g->x_n.assign(S, 0);
+        for (size_t i = 0; i < S; i++) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipSetDevice(g->dev[i]) != hipSuccess || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                group_release(g);
+                return gfail(MFM_E_DEVICE, "cannot create the exchange's events on device %d", g->dev[i]);
+            }
+            g->x0.push_back(a);
+            g->x1.push_back(b);
+        }
+    }
     g->committed = true;
     return MFM_OK;
 }
@@ -350,6 +432,62 @@ int mfm_group_shard_info(struct mfm_group *g, uint32_t shard, uint32_t *first_ch
     }
     if (device) {
         *device = g->dev[shard];
+    }
+    return MFM_OK;
+}
+
+int mfm_group_exchange_detail(struct mfm_group *g, uint32_t shard, struct mfm_exchange_detail *out)
+{
+    if (!g || !out) {
+        return gfail(MFM_E_INVAL, "NULL argument");
+    }
+    if (!g->committed || shard >= g->eng.size()) {
+        return gfail(MFM_E_INVAL, "no such shard");
+    }
+    memset(out, 0, sizeof(*out));
+    out->device = g->dev[shard];
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), g->dev[shard]) != hipSuccess) {
+        out->pci_bus_id[0] = 0;
+    }
+    if (g->exchange) {
+        int n = -1;
+        if (g->rccl.CommCount && shard < g->comm.size() && g->comm[shard]) {
+            if (g->rccl.CommCount(g->comm[shard], &n) != 0) {
+                n = -1;
+            }
+        }
+        out->rccl_ranks = n;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g->x_mu);
+        if (shard < g->x_n.size()) {
+            out->timed_exchanges = g->x_n[shard];
+            out->exchange_ms = g->x_ms[shard];
+        }
+    }
+    mfm_stats st;
+    memset(&st, 0, sizeof(st));
+    if (mfm_engine_get_stats(g->eng[shard], &st) == MFM_OK) {
+        out->timed_launches = st.timed_launches;
+        out->kernel_ms = st.kernel_ms;
+    }
+    out->bound = MFM_BOUND_UNKNOWN;
+    if (out->timed_exchanges && out->timed_launches) {
+        const double x = out->exchange_ms / (double)out->timed_exchanges, k = out->kernel_ms / (double)out->timed_launches;
+        out->bound = x > k ? MFM_BOUND_EXCHANGE : MFM_BOUND_KERNEL;
+    }
+    return MFM_OK;
+}
+
+int mfm_group_rccl_library(char *path, size_t cap)
+{
+    RcclApi api;
+    const int rc = load_rccl(&api);
+    if (rc != MFM_OK) {
+        return rc;
+    }
+    if (path && cap) {
+        snprintf(path, cap, "%s", g_rccl_path);
     }
     return MFM_OK;
 }
@@ -405,6 +543,18 @@ struct GroupOps {
         const size_t part = g->cfg.exchange == MFM_X_RCCL_ALLGATHER ? (bytes / S) & ~(size_t)15 : 0;
         const size_t even = part * S;
         int nrc = 0, nre = 0;
+        const bool timed = fold_and_open_timing();
+        struct Close {
+            GroupOps *o;
+            bool on;
+            ~Close()
+            {
+                for (size_t i = 0; on && i < o->g->x1.size(); i++) {
+                    (void)hipSetDevice(o->g->dev[i]);
+                    (void)hipEventRecord(o->g->x1[i], o->g->xs[i]);
+                }
+            }
+        } close_timing{ this, timed };
         if (part) {
             /* 1. part i of the block to peer i, over S - 1 different links at once (the root keeps part 0 where it is) */
             nrc = r.GroupStart();
@@ -441,6 +591,41 @@ struct GroupOps {
             }
         }
         return MFM_OK;
+    }
+    /* the pair of the last bracketed exchange, once it is through, into the sums; every fourth exchange opens a new one */
+    bool fold_and_open_timing()
+    {
+        if (g->x0.empty()) {
+            return false;
+        }
+        if (g->x_open) {
+            bool done = true;
+            for (size_t i = 0; i < g->x1.size(); i++) {
+                done = done && hipEventQuery(g->x1[i]) == hipSuccess;
+            }
+            if (!done) {
+                g->x_seq++;
+                return false; /* (still in flight: this exchange goes unbracketed) */
+            }
+            std::lock_guard<std::mutex> lk(g->x_mu);
+            for (size_t i = 0; i < g->x1.size(); i++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, g->x0[i], g->x1[i]) == hipSuccess) {
+                    g->x_ms[i] += ms;
+                    g->x_n[i]++;
+                }
+            }
+            g->x_open = false;
+        }
+        if ((g->x_seq++ & 3u) != 0u) {
+            return false;
+        }
+        for (size_t i = 0; i < g->x0.size(); i++) {
+            (void)hipSetDevice(g->dev[i]);
+            (void)hipEventRecord(g->x0[i], g->xs[i]);
+        }
+        g->x_open = true;
+        return true;
     }
     int submit(size_t i, size_t n, bool launch)
     {

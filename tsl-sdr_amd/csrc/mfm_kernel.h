@@ -162,7 +162,7 @@ static inline uint32_t mfm_v3l_built_kq(uint32_t kq_used)
 }
 static inline uint32_t mfm_v3l_built_nh(uint32_t kq, uint32_t nh)
 {
-    const uint32_t b = nh == 0u ? 0u : nh <= 2u ? 2u : nh <= 4u ? 4u : nh <= 8u ? 8u : kq;
+    const uint32_t b = nh == 0u ? 0u : nh <= 2u ? 2u : nh <= 4u ? 4u : kq;
     return b < kq ? b : kq;
 }
 /* ... and the staging chunks per thread */
@@ -262,6 +262,7 @@ struct mfm_launch_v3 {
      * launch.  The values carry the launch's tag in their top 24 bits (cyc_tag << 40), which makes a slot reusable without
      * clearing it.  NULL: no stamps. */
     unsigned long long *cyc;
+    unsigned long long *cyc_clear; /* the two words of the slot half a ring ahead, zeroed by this launch (NULL with cyc) */
     uint32_t cyc_tag, pad2;
     const uint32_t *afrag;
     const int32_t *krow;

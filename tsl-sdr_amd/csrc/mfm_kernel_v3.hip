@@ -1284,7 +1284,7 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
     if (L->layout == 3u) {
         /* L->kq is a built count of k-steps (mfm_v3l_built_kq), the tap fragments are laid out for exactly that many */
         const uint32_t nch4 = (L->nstage4 + MFM3_NT - 1) / MFM3_NT;
-        if (dbg_iq || nch4 < 1 || nch4 > MFM_V3_CH_MAX || (L->ng != 1u && L->ng != 2u && L->ng != 4u) || (L->rb != 1u && L->rb != 2u) ||
+        if (nch4 < 1 || nch4 > MFM_V3_CH_MAX || (L->ng != 1u && L->ng != 2u && L->ng != 4u) || (L->rb != 1u && L->rb != 2u) ||
             L->kq_used > L->kq || L->nh > L->kq ||
             L->kq != mfm_v3l_built_kq(L->kq) || (L->in8 != 0u && L->in8 != 7u && L->in8 != 14u) ||
             /* (a description with the LDS layout filled in: the plane pitch the instances' immediates assume) */
@@ -1384,8 +1384,17 @@ extern "C" hipError_t mfm_select_channel_kernel_v3(const mfm_launch_v3 *L, int d
     if (L->layout == 2u) {
         /* decimation 25 (etc/pocsag_rtlsdr.json) on padded rows: fixed geometry, six k-steps; instances by which k-steps carry a
          * high-byte tap plane (a mask that is a subset of an instance's runs on it: a zero plane multiplies zeros) */
-        if (dbg_iq || L->decim != 25u || L->kq != 6u || L->rs != mfm3_geo<25>::rs || L->sp_pitch != mfm3_geo<25>::sp) {
+        if (L->decim != 25u || L->kq != 6u || L->rs != mfm3_geo<25>::rs || L->sp_pitch != mfm3_geo<25>::sp || (dbg_iq && L->in8 != 0u)) {
             return hipErrorInvalidValue;
+        }
+        if (dbg_iq) {
+            /* a channel wants its filtered IQ beside the PCM (signalDebugFile, multifm/demod.c:75-81): int16 input only */
+            if ((L->ah_mask & ~0xeu) == 0u) {
+                *kfn_out = reinterpret_cast<const void *>(&mfm_channel_kernel_v3<6, true, 1, 0xe, 25, 0>);
+            } else {
+                *kfn_out = reinterpret_cast<const void *>(&mfm_channel_kernel_v3<6, true, 1, -1, 25, 0>);
+            }
+            return hipSuccess;
         }
 #define MFM3_LAUNCH_25(IN8_)                                                                                 \
     do {                                                                                                     \

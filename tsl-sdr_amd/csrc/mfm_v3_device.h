@@ -347,6 +347,10 @@ static __device__ __forceinline__ void mfm3_stamp_end(const mfm_launch_v3 &L, ui
         const uint64_t dt = (uint32_t)((uint32_t)__builtin_amdgcn_s_memtime() - t0), dr = (uint32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - r0);
         atomicMax(L.cyc, (unsigned long long)(tag | dt));
         atomicMax(L.cyc + 1, (unsigned long long)(tag | dr));
+        if (blockIdx.x == 0) {
+            L.cyc_clear[0] = 0ull; /* the slot of the launch half a ring from now */
+            L.cyc_clear[1] = 0ull;
+        }
     }
 }
 

@@ -77,8 +77,19 @@ static aresult_t _sample_buf_release(struct sample_buf *buf)
 {
     TSL_ASSERT_ARG(NULL != buf);
     TSL_BUG_ON(atomic_load((_Atomic uint32_t *)&buf->refcount) != 0);
-    struct frame_alloc *fa = buf->priv;
-    return frame_free(fa, (void **)&buf);
+    struct receiver *rx = buf->priv;
+    return frame_free(rx->samp_alloc, (void **)&buf);
+}
+
+/* ... of a buffer the front end got from receiver_sample_buf_alloc() and lets go of without delivering it (end of a file,
+ * multifm/airspy_if.c:71-75): it no longer holds one */
+static aresult_t _sample_buf_release_undelivered(struct sample_buf *buf)
+{
+    TSL_ASSERT_ARG(NULL != buf);
+    struct receiver *rx = buf->priv;
+    const aresult_t ret = _sample_buf_release(buf);
+    atomic_fetch_sub(&rx->front_end_holds, 1);
+    return ret;
 }
 
 /* ---- channels ---- */
@@ -251,16 +262,26 @@ aresult_t receiver_sample_buf_alloc(struct receiver *rx, struct sample_buf **pbu
     TSL_ASSERT_ARG(NULL != pbuf);
     *pbuf = NULL;
 
+    /* receiver_cleanup() takes the pool away under a front end whose reader it cannot stop first (librtlsdr's is only cancelled
+     * by the front end's own cleanup function, which frees `rx` and so runs last): a buffer the front end holds is counted from
+     * here to its delivery, and once the receiver is closing there are no more - the callback drops its samples as if the pool
+     * were empty.  Count first, then look at the flag; cleanup sets the flag first, then looks at the count. */
+    atomic_fetch_add(&rx->front_end_holds, 1);
+    if (atomic_load(&rx->closing)) {
+        atomic_fetch_sub(&rx->front_end_holds, 1);
+        return A_E_BUSY;
+    }
     /* pool exhausted: drop and count, log once (multifm/receiver.c:57-63) */
     if (FAILED(ret = frame_alloc(rx->samp_alloc, (void **)&sbuf))) {
+        atomic_fetch_sub(&rx->front_end_holds, 1);
         if (0 == rx->nr_samp_buf_alloc_fails) {
             MFM_MSG(SEV_INFO, "NO-SAMPLE-BUFFER", "There are no available sample buffers, dropping received samples.");
         }
         rx->nr_samp_buf_alloc_fails++;
         return ret;
     }
-    sbuf->release = _sample_buf_release;
-    sbuf->priv = rx->samp_alloc;
+    sbuf->release = _sample_buf_release_undelivered;
+    sbuf->priv = rx;
     sbuf->refcount = 0;
     sbuf->sample_type = COMPLEX_INT_16;
     *pbuf = sbuf;
@@ -280,15 +301,17 @@ aresult_t receiver_sample_buf_deliver(struct receiver *rx, struct sample_buf *bu
      * receiver_sample_buf_alloc() and drops there, counted, as the reference does. */
     atomic_store((_Atomic uint32_t *)&buf->refcount, 1);
     if (rx->failed) {
-        (void)sample_buf_decref(buf);
+        (void)sample_buf_decref(buf); /* (undelivered: the release counts it off the front end's holds) */
         return A_E_DEVICE;
     }
+    buf->release = _sample_buf_release;
     const size_t head = rx->ring_head;
     TSL_BUG_ON(head - rx->ring_tail >= rx->ring_slots); /* more buffers in flight than the pool holds */
     rx->ring[head % rx->ring_slots] = buf;
     rx->ring_head = head + 1; /* publishes the slot */
     rx->nr_bufs_delivered++;
     _bell_ring(&rx->ring_bell); /* wakes the submit thread if it sleeps; never waits */
+    atomic_fetch_sub(&rx->front_end_holds, 1); /* the last touch of the receiver's ring and bell on this path */
     const uint64_t dt = tsl_get_clock_monotonic() - t0;
     if (dt > rx->max_deliver_ns) {
         rx->max_deliver_ns = dt;
@@ -731,6 +754,8 @@ static void _receiver_zero(struct receiver *rx, receiver_rx_thread_func_t rx_fun
     pthread_mutex_init(&rx->life->mu, NULL);
     rx->life->refs = 1;
     atomic_store(&rx->nr_samp_buf_alloc_fails, 0);
+    atomic_store(&rx->closing, 0);
+    atomic_store(&rx->front_end_holds, 0);
     atomic_store(&rx->input_done, false);
     atomic_store(&rx->nr_blocks_drained, 0);
     atomic_store(&rx->ring_head, 0);
@@ -948,11 +973,27 @@ aresult_t receiver_cleanup(struct receiver **prx)
     TSL_ASSERT_ARG(NULL != *prx);
     rx = *prx;
 
+    bool leak = false;
     TSL_BUG_IF_FAILED(worker_thread_request_shutdown(&rx->wthr));
     const bool joined = _receiver_join_front_end(rx, 500u);
     if (!joined) {
+        /* A reader this function cannot stop (see above): no new buffers from here on, and wait for the one a callback may be
+         * holding - it is in receiver_sample_buf_alloc(), filling the buffer, or in receiver_sample_buf_deliver() - to be
+         * delivered.  A callback that was past its muted check but not yet in receiver_sample_buf_alloc() gets A_E_BUSY there and
+         * touches nothing of what is torn down below. */
         rx->muted = true;
-        usleep(20000); /* a callback that was past its muted check delivers its buffer */
+        atomic_store(&rx->closing, 1);
+        unsigned waited_ms = 0;
+        while (atomic_load(&rx->front_end_holds) > 0 && waited_ms < 5000u) {
+            usleep(1000);
+            waited_ms++;
+        }
+        if (atomic_load(&rx->front_end_holds) > 0) {
+            /* a callback stuck for seconds with a buffer in its hands (a write to iqDumpFile that does not return): the pool, the
+             * ring and the device group stay behind rather than being freed under it */
+            MFM_MSG(SEV_WARNING, "FRONT-END-STUCK", "The front end still holds a sample buffer after %u ms; leaving its pool behind.", waited_ms);
+            leak = true;
+        }
     }
     if (NULL != rx->group && rx->drain_thr.started) {
         (void)receiver_drain(rx); /* returns A_E_DEVICE instead of waiting for a thread that has given up */
@@ -972,7 +1013,9 @@ aresult_t receiver_cleanup(struct receiver **prx)
                 "%zu blocks written out", (size_t)rx->nr_bufs_delivered, (size_t)rx->nr_bufs_submitted, (size_t)rx->nr_copy_commands,
                 (size_t)rx->nr_samp_buf_alloc_fails, (size_t)rx->nr_blocks_drained);
     }
-    _receiver_teardown(rx);
+    if (!leak) {
+        _receiver_teardown(rx);
+    }
 
     /* from here on `rx` belongs to the front end */
     struct mfm_rx_lifeline *life = rx->life;

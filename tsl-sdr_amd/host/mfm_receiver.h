@@ -127,6 +127,8 @@ struct receiver {
      * consistent by default; a slot of `ring` is published by the store to ring_head that follows it) */
     _Atomic size_t ring_head, ring_tail;
     _Atomic bool input_done;      /* front end reached end of input */
+    _Atomic int closing;          /* receiver_cleanup() has begun: receiver_sample_buf_alloc() hands out nothing any more */
+    _Atomic int front_end_holds;  /* buffers the front end got from receiver_sample_buf_alloc() and has not yet delivered or released */
     _Atomic int failed;           /* a device error stopped the submit or the drain thread (A_E_DEVICE from then on) */
     _Atomic size_t nr_bufs_delivered, nr_bufs_submitted;
     _Atomic size_t nr_blocks_drained;
