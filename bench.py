@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "mfma1", "mfma1s", "dot2", "v3l1", "slice64", "slice128"], default="auto",
                     help="mfma1 / dot2 = the first-generation matrix kernel / the v_dot2 kernel through the "
                          "MFM_F_FORCE_* flags (A/B timing)")
+    ap.add_argument("--pcm-write-back", action="store_true", help="MFM_F_PCM_WRITE_BACK: no system-scope PCM stores (A/B timing, traffic)")
     ap.add_argument("--block-log2", type=int, default=26, help="log2 of wideband samples per step")
     ap.add_argument("--config", default="cfg2_64ch", help="plan name in tsl-sdr_amd/synth.py")
     ap.add_argument("--overlap", action="store_true", help="MFM_F_OVERLAP: consecutive launches on two compute streams")
@@ -310,7 +311,7 @@ def library_sha16(pkg):
 
 
 def instance_name(pkg, st, in8):
-    """key of a (kernel, geometry) in profiles/r05_issue_model.json"""
+    """key of a (kernel, geometry) in profiles/r*_issue_model.json"""
     return "variant%d_ch%d_taps%d_ksteps%d_mask%x_tile%d%s" % (st["kernel_variant"], st["nr_channels"], st["nr_taps"], st["k_steps"],
                                                                 st["tap_hi_mask"], st["outputs_per_tile"], "_in8" if in8 else "")
 
@@ -422,22 +423,27 @@ def launch_clocks(eng, n):
 def issue_model(kname_full, st, cycles, hbm_frac, lib_sha16):
     """How much of the launch the SIMDs spent issuing: (matrix instructions x 16 + other vector instructions x 3 cycles) / 1024
     SIMDs against THIS run's shader cycles.  The instruction counts are properties of (binary, geometry), not of a box: SQ_INSTS_*
-    per launch from the committed rocprofv3 passes of this command (profiles/r05_issue_model.json), only used when that file was
+    per launch from the committed rocprofv3 passes of this command (profiles/r*_issue_model.json), only used when that file was
     collected on this very library (sha) and kernel instance.  ceiling_frac = the HBM fraction the kernel would reach if every
     issue slot of the launch were used."""
-    path = os.path.join(ROOT, "profiles", "r05_issue_model.json")
-    if cycles is None or not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_model.json")), reverse=True)   # the newest round's first
+    if cycles is None or not paths:
         return None
-    im = json.load(open(path))
-    ent = im.get("shapes", {}).get(kname_full)
-    if ent is None or im.get("library_sha16") != lib_sha16:
-        return {"ceiling_frac": None, "reason": "profiles/r05_issue_model.json was collected on another build or kernel instance",
+    im, ent, path = None, None, paths[0]
+    for path in paths:
+        im = json.load(open(path))
+        ent = im.get("shapes", {}).get(kname_full) if im.get("library_sha16") == lib_sha16 else None
+        if ent is not None:
+            break
+    if ent is None:
+        return {"ceiling_frac": None, "reason": "no profiles/r*_issue_model.json was collected on this build and kernel instance",
                 "library_sha16": lib_sha16, "profile_library_sha16": im.get("library_sha16")}
     mfma, valu = ent["mfma_insts_per_launch"], ent["other_valu_insts_per_launch"]
     issue_cycles = (mfma * MFMA_ISSUE_CYCLES + valu * VALU_ISSUE_CYCLES) / SIMDS
     busy = issue_cycles / cycles["shader_ticks_median"]
     return {"mfma_insts_per_launch": mfma, "other_valu_insts_per_launch": valu,
-            "counts_source": "profiles/r05_issue_model.json: SQ_INSTS_MFMA, SQ_INSTS_VALU - SQ_INSTS_MFMA per launch (rocprofv3 --pmc of this "
+            "counts_source": "profiles/" + os.path.basename(path) + ": SQ_INSTS_MFMA, SQ_INSTS_VALU - SQ_INSTS_MFMA per launch (rocprofv3 --pmc of this "
                              "command on this library; instruction counts do not depend on the box)",
             "mfma_issue_cycles": MFMA_ISSUE_CYCLES, "valu_issue_cycles": VALU_ISSUE_CYCLES, "simds": SIMDS,
             "issue_cycles_per_simd": issue_cycles, "launch_shader_cycles": cycles["shader_ticks_median"],
@@ -1216,7 +1222,8 @@ def main():
                      (pkg.binding.MFM_F_STREAM_TAPS if args.kernel == "mfma1s" else 0) |
                      (pkg.binding.MFM_F_V3L_ONE_ROW_BLOCK if args.kernel == "v3l1" else 0) |
                      (pkg.binding.MFM_F_SLICE_64 if args.kernel == "slice64" else 0) |
-                     (pkg.binding.MFM_F_SLICE_128 if args.kernel == "slice128" else 0),
+                     (pkg.binding.MFM_F_SLICE_128 if args.kernel == "slice128" else 0) |
+                     (pkg.binding.MFM_F_PCM_WRITE_BACK if args.pcm_write_back else 0),
                      ext_input=(bufs[0].data_ptr(), bufs[1].data_ptr()))
     for o, g in zip(offs, gains):
         eng.add_channel(int(o), taps, float(g))

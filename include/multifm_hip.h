@@ -96,6 +96,8 @@ extern "C" {
                                   (mfm_kernel_v3l.hip) - whatever the channel count; the default takes them from the channel count
                                   at which they measured faster than slices of 64.  Same bits; parity tests, A/B timing */
 #define MFM_F_SLICE_64 0x1000u  /* ... never: slices of 64 channels (mfm_kernel_v3.hip) at any channel count */
+#define MFM_F_PCM_WRITE_BACK 0x2000u /* second-generation kernels: PCM stores never go through to memory with system scope (the default does
+                                  that for launches of 512 channels and more: less L2-miss traffic there); same bits; A/B timing */
 #define MFM_F_WIDEN_8BIT 0x10u /* mfm_engine_push_bytes: always widen 8-bit blocks to int16 in HBM first, also where the
                                   matrix kernel could read the bytes themselves (same bits; parity tests and A/B timing) */
 

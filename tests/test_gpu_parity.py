@@ -194,7 +194,8 @@ def test_decimations_1_2_4_run_on_the_matrix_cores(pkg, ora, decim, ntaps, nch):
     of 2 D plane bytes is shorter than a 16-byte fragment there, so the long-filter kernel keeps 8 / D shifted copies of the tile's
     image and every column reads the copy in which its window starts aligned (mfm_kernel_v3l.hip, SHIFT; round 5 - the v_dot2
     kernel before).  int16 blocks and the three 8-bit forms as bytes, ragged block lengths, mixed rotator classes, 4 .. 16
-    k-steps; a channel that wants its filtered IQ stays on the v_dot2 kernel."""
+    k-steps; since round 6 also with a channel that wants its filtered IQ (signalDebugFile, multifm/demod.c:75-81: a run-time
+    switch in that kernel's epilogue)."""
     fs = 1000000
     taps = pkg.synth.design_lpf(ntaps, 100000.0, fs) if ntaps > 1 else np.array([0.9])
     rng = np.random.RandomState(decim * 100 + ntaps)
@@ -209,8 +210,9 @@ def test_decimations_1_2_4_run_on_the_matrix_cores(pkg, ora, decim, ntaps, nch):
     _check(pkg, ora, fs, decim, taps, offs, iq, 1 << 15, want_iq=False)
     _check(pkg, ora, fs, decim, taps, offs, iq, 7001, want_iq=False)
     eng = _mk_engine(pkg, fs, decim, taps, offs[:2], max_block=1 << 15, want_iq=True)
-    assert eng.stats()["kernel_variant"] == 0
+    assert eng.stats()["kernel_variant"] == 2
     eng.close()
+    _check(pkg, ora, fs, decim, taps, offs, iq[: 4000 * decim + ntaps], 7001, want_iq=True)
     for fmt in (1, 2, 3):
         raw = np.random.RandomState(nch + fmt).randint(0, 256, size=(n, 2)).astype(np.uint8)
         sizes = [32768, 4096, 2, 30000, 8, 12346]
@@ -360,10 +362,18 @@ def test_long_filters_keep_their_taps_in_registers(pkg, ora, decim, ntaps, shape
         assert masks["auto"] == 0
     if shape == "dense":  # high bytes in every k-step that holds taps: the all-planes instance
         assert masks["auto"] & ~(0x0ff0 if st["k_steps"] == 16 else 0x3c), hex(masks["auto"])
-    # a filtered-IQ consumer: the streamed form (the resident instances are not built with the IQ store)
-    eng = _mk_engine(pkg, fs, decim, taps, offs[:5], max_block=1 << 16, want_iq=True)
-    assert eng.stats()["taps_resident"] == 0
+    # a filtered-IQ consumer (signalDebugFile, multifm/demod.c:75-81): since round 6 on the long-filter kernel as well (a run-time
+    # switch in its epilogue) wherever that kernel takes the geometry; the first generation's streamed form elsewhere (its
+    # resident instances are not built with the IQ store)
+    eng = _mk_engine(pkg, fs, decim, taps, offs[:5], max_block=1 << 16, want_iq=False)
+    plain = eng.stats()
     eng.close()
+    eng = _mk_engine(pkg, fs, decim, taps, offs[:5], max_block=1 << 16, want_iq=True)
+    st_iq = eng.stats()
+    eng.close()
+    assert st_iq["kernel_variant"] == plain["kernel_variant"]
+    assert st_iq["taps_resident"] == (1 if plain["kernel_variant"] == 2 else 0), (st_iq, plain)
+    _check(pkg, ora, fs, decim, taps, offs[:5], iq, 30001, want_iq=True)
 
 
 @pytest.mark.parametrize("fmt", [1, 2, 3])

@@ -19,13 +19,13 @@ CHECKER = r"""
 #include "mfm_v3l_plan.h"
 static int bad = 0;
 #define REQUIRE(c, ...) do { if (!(c)) { bad++; printf("FAIL %s: ", name); printf(__VA_ARGS__); printf("\n"); } } while (0)
-template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool DB, bool PI, bool CO, int NST>
+template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool DB, bool PI, bool CO, int NST, int STGM = (IN8 ? MFM3L_STG_I8 : MFM3L_STG_I16)>
 void check(const char *name)
 {
-    static constexpr auto P = mfm3l_make_plan<KQ, NH, NGC, RB, IN8, PF, false, DB, PI, CO, NST>();
-    constexpr int NMF = P.NMF, NS = NGC * KQ, RPK = IN8 ? 1 : 2, SPC = mfm3l_stg_ops(IN8);
+    static constexpr auto P = mfm3l_make_plan<KQ, NH, NGC, RB, IN8, PF, false, DB, PI, CO, NST, STGM>();
+    constexpr int NMF = P.NMF, NS = NGC * KQ, RPK = IN8 ? 1 : 2, SPC = mfm3l_stg_ops(STGM);
     // emission order: prologue reads, then per matrix instruction [wait] MFMA fillers..., then the tail
-    int nl = 0, rd_done[NS + 1] = {}, req_seen[NS + 1] = {}, stg_seen[9][16] = {}, rec_seen[NGC + 1] = {};
+    int nl = 0, rd_done[NS + 1] = {}, req_seen[NS + 1] = {}, stg_seen[9][20] = {}, rec_seen[NGC + 1] = {};
     for (int st = 0; st < PF && st < NS; st++) { nl += RPK; rd_done[st] = nl; req_seen[st] = RPK; }
     int last_write[NGC][2][3];
     for (auto &a : last_write) for (auto &b : a) for (int &c : b) c = -1;
@@ -37,7 +37,7 @@ void check(const char *name)
         case MFM3L_F_RDH: nl++; req_seen[f.a]++; if (IN8) rd_done[f.a] = nl; break;
         case MFM3L_F_RDL: nl++; req_seen[f.a]++; rd_done[f.a] = nl; break;
         case MFM3L_F_TPW: nl++; break;
-        case MFM3L_F_STG: stg_seen[f.a][f.b]++; if (mfm3l_stg_is_lds(IN8, f.b)) nl++; break;
+        case MFM3L_F_STG: stg_seen[f.a][f.b]++; if (mfm3l_stg_is_lds(STGM, f.b)) nl++; break;
         default: break;
         }
         if (f.kind == MFM3L_F_LA || f.kind == MFM3L_F_SH0 || f.kind == MFM3L_F_SH1 || f.kind == MFM3L_F_TPW) {
@@ -95,7 +95,8 @@ int main()
     check<4, 2, 4, 2, false, 4, true, false, false, 4>("kq4 nh2 ng4 rb2");
     check<4, 2, 4, 2, true, 4, true, false, false, 4>("kq4 nh2 ng4 rb2 in8");
     // 256-tap POCSAG low-passes (etc/pocsag_1200khz_fs.json at D = 25: old-style staging; etc/pocsag_narrow.json at D = 100)
-    check<11, 4, 4, 1, false, 4, true, false, false, 0>("kq11 nh4 ng4 rb1 split");
+    check<11, 4, 4, 1, false, 4, true, false, false, 1, MFM3L_STG_I16_S>("kq11 nh4 ng4 rb1 split rows, one chunk");
+    check<6, 2, 4, 1, true, 4, true, false, false, 4, MFM3L_STG_I8_S>("kq6 nh2 ng4 rb1 in8 split rows, four chunks");
     check<9, 4, 4, 1, false, 4, true, false, false, 4>("kq9 nh4 ng4 rb1");
     // 512 taps at D = 120 (etc/flex_25khz_lpf_3mhz.json): half-tile images, a group carried from the first to the second
     check<16, 2, 2, 1, false, 4, true, false, true, 4>("kq16 nh2 ng2 rb1 first image");
@@ -120,4 +121,4 @@ def test_matrix_phase_plans_hold_their_invariants(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout[-4000:]
-    assert r.stdout.count("matrix instructions") == 11
+    assert r.stdout.count("matrix instructions") == 12

@@ -27,6 +27,7 @@ MFM_F_OVERLAP = 0x200
 MFM_F_V3L_ONE_ROW_BLOCK = 0x400
 MFM_F_SLICE_128 = 0x800
 MFM_F_SLICE_64 = 0x1000
+MFM_F_PCM_WRITE_BACK = 0x2000
 MFM_RCP_TABLE_HASH_GFX950 = 0x706D94BC005BCC1A  # include/multifm_hip.h
 MFM_IN_CS16, MFM_IN_CS8, MFM_IN_CU8, MFM_IN_RTLSDR_U8 = 0, 1, 2, 3
 

@@ -80,6 +80,10 @@ constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine
 constexpr uint32_t kMaxOutputsPerTile = 128;
 /* 128-tap filters: slices of 128 channels from this many channels on (below, slices of 64: MFM_F_SLICE_128 / _64 override) */
 constexpr uint32_t kSlice128MinChannels = 0xffffffffu; /* measured (profiles/r06_slice128_ab.txt): slices of 64 stay ahead at every count */
+/* second-generation kernels: PCM stores with system scope from this many channels per launch on (profiles/r05_store_policy.txt,
+ * r06_hbm_traffic_1024ch.json: L2-miss traffic 1.27 -> 1.16 x algorithmic at 1024 channels at unchanged time; +0.4 % time at 256
+ * channels and 1.5-5 % at 64, where there is nothing to gain: profiles/r06_ab_store_policy.txt) */
+constexpr uint32_t kPcmWriteThroughMinChannels = 512;
 constexpr uint64_t kMaxRotEntries = 1ull << 26; /* per distinct increment: 512 MiB of table */
 
 struct Channel {
@@ -332,6 +336,7 @@ void fill_v3(const mfm_engine *e, int fmt, mfm_launch_v3 &V)
     V.nslices = e->v_nslices;
     V.nrb = e->m_nrb;
     V.nchan = (uint32_t)e->chans.size();
+    V.pcm_scope = (V.nchan >= kPcmWriteThroughMinChannels && !(e->cfg.flags & MFM_F_PCM_WRITE_BACK)) ? 1u : 0u;
     V.out_stride = e->out_stride;
     V.ah_mask = e->m_ah_mask;
     V.rc = e->v_rc;

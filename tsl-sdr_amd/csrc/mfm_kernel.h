@@ -186,7 +186,9 @@ struct mfm_launch_v3 {
                              one, i.e. the first row of the window of the output in front of this launch.  That output is
                              RECOMPUTED (its filtered sample is the discriminator's history, multifm/fm_demod.c:16-17), so
                              a launch depends on the launch before it through nothing but input samples */
-    uint32_t pad1;
+    uint32_t pcm_scope;   /* 1: the PCM stores go through to memory (system scope) instead of waiting in L2 for their line to fill:
+                             launches of 512 channels and more, where the PCM stream is several times the input's bytes and
+                             would push the rotator tables out of L2 between two uses (mfm3_store_pcm4) */
     uint64_t k_base;      /* outputs the stream produced before this launch: output n of the launch is rotated by the
                              (k_base + n)-th state of the recurrence (filter/direct_fir.c:151-172), found by folding that
                              index into the channel's table - so the rotator position needs no carried state either */

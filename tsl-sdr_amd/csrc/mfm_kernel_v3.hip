@@ -418,6 +418,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
     const uint32_t t_per = DFIX ? G::per : L.t_per, t_pitch = DFIX ? G::pitch : L.t_pitch;
     const uint32_t ah_mask = AHM >= 0 ? (uint32_t)AHM : (uint32_t)__builtin_amdgcn_readfirstlane(L.ah_mask);
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(smem + L.lut_off) | (MFM3_LUT_MODE == 2 ? 1u : 0u);
+    const bool pcm_sys = L.pcm_scope != 0u; /* launches of many channels write their PCM through (mfm3_store_pcm4) */
 
     /* atan LUT, once per workgroup: {T[i], T[i+1]-T[i]} pairs as the engine holds them (MFM3_LUT_MODE).  Requested here,
      * stored behind the first image (MFM3_PROLOGUE: everything a workgroup needs before its first matrix phase - table,
@@ -1175,7 +1176,7 @@ __global__ __launch_bounds__(MFM3_NT, 4) void mfm_channel_kernel_v3(const mfm_la
                         w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
                         w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
 #if MFM3_NONTEMPORAL & 2
-                        mfm3_store_pcm4(L.pcm, voff[c], w.x, w.y);
+                        mfm3_store_pcm4(L.pcm, voff[c], w.x, w.y, pcm_sys);
 #else
                         *reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(L.pcm) + voff[c]) = w;
 #endif

@@ -29,6 +29,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <tuple>
 #include <type_traits>
 
 #include "mfm_kernel.h"
@@ -45,7 +46,8 @@ typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
 #endif
 #ifndef MFM3L_KNOCK
 #define MFM3L_KNOCK 0 /* TIMING-ONLY builds (wrong results), tools/exp/variant_l.sh: bit 2 = no barrier behind an image, bit 3 = no
-                         epilogue, bit 4 = no matrix phase (and with it no staging) */
+                         epilogue, bit 4 = no matrix phase (and with it no staging), bit 5 = no rotator-table loads, bit 6 = no
+                         discriminator arithmetic, bit 7 = no PCM stores */
 #endif
 #ifndef MFM3L_PF
 #define MFM3L_PF 4 /* k-steps of B fragments in flight ahead of the matrix instructions (2 where all 128 tap registers are in use) */
@@ -100,10 +102,28 @@ static __device__ __forceinline__ uint32_t mfm3l_word(const T &c)
     }
 }
 
+/* dst = v where dst IS sixteen bytes of staging registers (int16 input); nothing elsewhere (never reached there) */
+template <typename T>
+static __device__ __forceinline__ void mfm3l_put16(T &dst, const uint4 &v)
+{
+    if constexpr (std::is_same<T, uint4>::value) {
+        dst = v;
+    }
+}
+template <typename T>
+static __device__ __forceinline__ uint4 mfm3l_get16(const T &src)
+{
+    if constexpr (std::is_same<T, uint4>::value) {
+        return src;
+    } else {
+        return make_uint4(0, 0, 0, 0);
+    }
+}
+
 /* the schedule of one phase as a compile-time object (only ever used in constant expressions: nothing of it exists on the device) */
-template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool SHIFTRD, bool DB, bool PI, bool CO, int NST>
+template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool SHIFTRD, bool DB, bool PI, bool CO, int NST, int STGM>
 struct mfm3l_plan_of {
-    static constexpr auto value = mfm3l_make_plan<KQ, NH, NGC, RB, IN8, PF, SHIFTRD, DB, PI, CO, NST>();
+    static constexpr auto value = mfm3l_make_plan<KQ, NH, NGC, RB, IN8, PF, SHIFTRD, DB, PI, CO, NST, STGM>();
 };
 
 /* two accumulator sets (a column group's recombination in the gaps of the next group's matrix instructions) where the taps leave
@@ -114,7 +134,7 @@ constexpr bool mfm3l_two_acc_sets(int KQ, int NH, int RB, bool SHIFT, bool IN8)
 }
 
 /* SPLIT: the decimation is not a multiple of 4 - a 4-sample staging chunk can straddle two rows of the image and is stored sample
- * by sample, behind the matrix phase as in round 5 (such decimations are small: the image is a few hundred chunks) */
+ * by sample (such decimations are small - the image is a few hundred chunks -: instances of one and of four chunks per thread) */
 template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SHIFT = false, bool SPLIT = false>
 __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8)) void mfm_channel_kernel_v3l(const mfm_launch_v3 L)
 {
@@ -126,13 +146,24 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
     static_assert(NH >= 0 && NH <= KQ, "planes held");
     /* two k-steps ahead where the taps take 112 registers or more and the fragments are pairs */
     /* (and with four waves per SIMD, which have each other to hide an LDS round trip and 128 registers each) */
-    constexpr int PF = ((4 * RB * (KQ + NH) >= 112 && !IN8) || mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8) == 4) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
+    /* (two row blocks: a k-step is four matrix instructions and more per fragment pair - two k-steps are lead enough - and from 96
+     * tap registers on the five fragment buffers of the deeper pipeline are not there) */
+    constexpr int PF = ((4 * RB * (KQ + NH) >= (RB == 2 ? 96 : 112) && !IN8) || mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN8) == 4) ? (MFM3L_PF < 2 ? MFM3L_PF : 2) : MFM3L_PF;
     constexpr int SLOTS = PF + 1;
     /* SHADOW: the next image's staging stores sit in the gaps of this image's matrix instructions, and the image after next is
      * requested from memory as soon as a chunk's registers are free (a whole phase to arrive) */
-    constexpr bool SHADOW = !SHIFT && !SPLIT;
+    constexpr bool SHADOW = !SHIFT;
+    constexpr int STGM = SPLIT ? (IN8 ? MFM3L_STG_I8_S : MFM3L_STG_I16_S) : (IN8 ? MFM3L_STG_I8 : MFM3L_STG_I16);
     constexpr bool DB = mfm3l_two_acc_sets(KQ, NH, RB, SHIFT, IN8);
     constexpr int NACC = DB ? 2 : 1;
+    /* the rotator entries of a tile travel in the staging registers of its last image (see the matrix phase) */
+    constexpr bool ROT_IN_PRE = SHADOW && !IN8 && NCH >= 2 * RB;
+    /* the epilogue's channels strictly one after the other (scheduling barriers) where two row blocks' taps leave it some 100
+     * registers; where the taps are few the compiler may interleave the dependent chains of several channels */
+#ifndef MFM3L_EPI_FREE_BELOW
+#define MFM3L_EPI_FREE_BELOW 64 /* tap registers below which the barriers are dropped (-1.2 % at 1024 channels on 128-channel slices) */
+#endif
+    constexpr bool EPI_SERIAL = RB > 1 && 4 * RB * (KQ + NH) >= MFM3L_EPI_FREE_BELOW;
     struct one_sample { uint32_t x; };
     using chunk_t = typename std::conditional<SHIFT, one_sample, typename std::conditional<IN8, uint2, uint4>::type>::type;
 
@@ -148,6 +179,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
     /* some channel of the set wants its filtered IQ (signalDebugFile, multifm/demod.c:75-81): a run-time switch here - a
      * wave-uniform branch around a 16-byte store per channel and tile - where mfm_kernel_v3.hip has instances */
     const bool want_iq = L.iq_dbg != nullptr;
+    const bool pcm_sys = L.pcm_scope != 0u; /* launches of many channels write their PCM through (mfm3_store_pcm4) */
 
     /* atan LUT, once per workgroup: {T[i], T[i+1]-T[i]} pairs as the engine holds them */
     static_assert(MFM3_NT == 512, "one table dword per thread");
@@ -162,7 +194,9 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
     uint8_t *sta_in_row_s = smem + L.sta_off + NCH * MFM3_NT * 2u;
     /* SHADOW: the offsets stay in registers, and a chunk past the image's last one is the last one again (the same bytes to the
      * same place: no lane is ever masked off in the matrix phase) */
-    uint32_t sta_r[NCH];
+    /* SPLIT: every sample of the chunk has its own offset (2 m on, and rs - 2 D further from the sample that begins the next
+     * row), two 16-bit offsets per register */
+    uint32_t sta_r[NCH][SPLIT ? 2 : 1];
 #pragma unroll
     for (int j = 0; j < NCH && !SHIFT; j++) {
         uint32_t q = tid + (uint32_t)j * MFM3_NT;
@@ -171,10 +205,19 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         }
         const uint32_t s0 = q * 4u;
         const uint32_t r0 = s0 / D, c0 = s0 % D;
-        sta_r[j] = r0 * rs + 2u * c0;
-        sta16_s[j * MFM3_NT + tid] = (uint16_t)sta_r[j];
+        const uint32_t o0 = r0 * rs + 2u * c0, in_row = min(4u, D - c0), hop = rs - 2u * D;
+        if constexpr (SPLIT) {
+            const uint32_t o1 = o0 + 2u + (1u >= in_row ? hop : 0u), o2 = o0 + 4u + (2u >= in_row ? hop : 0u), o3 = o0 + 6u + (3u >= in_row ? hop : 0u);
+            sta_r[j][0] = o0 | (o1 << 16);
+            sta_r[j][SPLIT ? 1 : 0] = o2 | (o3 << 16);
+        } else {
+            sta_r[j][0] = o0;
+        }
+        /* (the tables of the synchronous staging - a workgroup's first image, the image in front of a chunk - by the plain chunk) */
+        const uint32_t sq = (tid + (uint32_t)j * MFM3_NT) * 4u;
+        sta16_s[j * MFM3_NT + tid] = (uint16_t)((sq / D) * rs + 2u * (sq % D));
         if (split_rows) {
-            sta_in_row_s[j * MFM3_NT + tid] = (uint8_t)min(4u, D - c0);
+            sta_in_row_s[j * MFM3_NT + tid] = (uint8_t)min(4u, D - sq % D);
         }
     }
 
@@ -422,22 +465,22 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
      *   requested into the same registers.
      *   FRONT: the one-group image in front of a chunk; the samples stay in fq.
      */
-    auto phase = [&](auto ngc_tag, auto h_tag, auto main_tag, uint32_t lds_h, uint32_t lds_other, int n2_out) {
+    auto phase = [&](auto ngc_tag, auto h_tag, auto main_tag, uint32_t lds_h, uint32_t lds_other, int n2_out, auto &&behind_matrix) {
         constexpr int NGC = decltype(ngc_tag)::value, H = decltype(h_tag)::value;
         constexpr bool MAIN = decltype(main_tag)::value;
         constexpr bool PDB = DB && MAIN;
         constexpr bool PEND_IN = PDB && H > 0, CARRY_OUT = PDB && H + 1 < NSUB;
         constexpr int P0 = PDB ? (H * NG) & 1 : 0;
         constexpr int NST = (MAIN && SHADOW) ? NCH : 0;
-        using plan_t = mfm3l_plan_of<KQ, NH, NGC, RB, IN8, PF, SHIFT, PDB, PEND_IN, CARRY_OUT, NST>;
+        using plan_t = mfm3l_plan_of<KQ, NH, NGC, RB, IN8, PF, SHIFT, PDB, PEND_IN, CARRY_OUT, NST, STGM>;
         constexpr int NMF = mfm3l_nmf(KQ, NH, NGC, RB, IN8), NS = NGC * KQ;
         constexpr int PL = RB == 2 ? 24576 : 31744; /* mfm_v3l_plane_pitch: the low plane lies a constant behind the high one */
 
         const uint32_t lds_u = (uint32_t)__builtin_amdgcn_readfirstlane(lds_h);
         const uint32_t sto_u = (uint32_t)__builtin_amdgcn_readfirstlane(lds_other);
-        uint32_t at = 0, at_l = 0, sa = 0, s0 = 0, s1 = 0;
+        uint32_t at = 0, at_l = 0, sa = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, sam[4] = { 0, 0, 0, 0 };
         /* (named here so that every level of these nested generic lambdas captures them when it is defined) */
-#define MFM3L_CAPTURES (void)&bl, (void)&bh, (void)&acc, (void)&tq, (void)&fq, (void)&pre, (void)&a_h, (void)&a_l, (void)&krow, (void)&boff, (void)&sta_r; (void)&at, (void)&at_l, (void)&sa, (void)&s0, (void)&s1
+#define MFM3L_CAPTURES (void)&bl, (void)&bh, (void)&acc, (void)&tq, (void)&fq, (void)&pre, (void)&a_h, (void)&a_l, (void)&krow, (void)&boff, (void)&sta_r; (void)&at, (void)&at_l, (void)&sa, (void)&s0, (void)&s1, (void)&s2, (void)&s3, (void)&sam
         MFM3L_CAPTURES;
 
         auto filler = [&](auto idx_tag) {
@@ -507,8 +550,48 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                 }
             } else if constexpr (F.kind == MFM3L_F_STG) {
                 constexpr int J = F.a, OP = F.b;
-                if constexpr (OP == 0) {
-                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(sa) : "s"(sto_u), "v"(sta_r[J]));
+                if constexpr (SPLIT) {
+                    /* sample by sample: s0, s1 = the high (or only) plane's two dwords - sample m is half m & 1 of dword m >> 1 -,
+                     * s2, s3 the low plane's; sam[m] = where sample m goes */
+                    constexpr int NPREP = IN8 ? 2 : 6; /* operations in front of the address adds */
+                    if constexpr (IN8 && OP == 0) {
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(s0) : "s"(L.in8_xor), "v"(mfm3l_word<0>(pre[J])));
+                    } else if constexpr (IN8 && OP == 1) {
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(s1) : "s"(L.in8_xor), "v"(mfm3l_word<1>(pre[J])));
+                    } else if constexpr (!IN8 && OP == 0) {
+                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s0) : "v"(mfm3l_word<1>(pre[J])), "v"(mfm3l_word<0>(pre[J])), "s"(0x07050301u));
+                    } else if constexpr (!IN8 && OP == 1) {
+                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s1) : "v"(mfm3l_word<3>(pre[J])), "v"(mfm3l_word<2>(pre[J])), "s"(0x07050301u));
+                    } else if constexpr (!IN8 && OP == 2) {
+                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s2) : "v"(mfm3l_word<1>(pre[J])), "v"(mfm3l_word<0>(pre[J])), "s"(0x06040200u));
+                    } else if constexpr (!IN8 && OP == 3) {
+                        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(s3) : "v"(mfm3l_word<3>(pre[J])), "v"(mfm3l_word<2>(pre[J])), "s"(0x06040200u));
+                    } else if constexpr (!IN8 && OP == 4) {
+                        asm volatile("v_xor_b32 %0, 0x80808080, %0" : "+v"(s2));
+                    } else if constexpr (!IN8 && OP == 5) {
+                        asm volatile("v_xor_b32 %0, 0x80808080, %0" : "+v"(s3));
+                    } else if constexpr (OP < NPREP + 4) {
+                        constexpr int M = OP - NPREP;
+                        if constexpr ((M & 1) == 0) {
+                            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(sam[M]) : "s"(sto_u), "v"(sta_r[J][M >> 1]));
+                        } else {
+                            asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(sam[M]) : "s"(sto_u), "v"(sta_r[J][M >> 1]));
+                        }
+                    } else {
+                        constexpr int W = OP - NPREP - 4, M = W & 3; /* W < 4: the high (or only) plane, else the low one */
+                        const uint32_t &src = W < 4 ? (M < 2 ? s0 : s1) : (M < 2 ? s2 : s3);
+                        if constexpr (W < 4 && (M & 1) == 0) {
+                            asm volatile("ds_write_b16 %0, %1" ::"v"(sam[M]), "v"(src) : "memory");
+                        } else if constexpr (W < 4) {
+                            asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(sam[M]), "v"(src) : "memory");
+                        } else if constexpr ((M & 1) == 0) {
+                            asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(sam[M]), "v"(src), "n"(PL) : "memory");
+                        } else {
+                            asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(sam[M]), "v"(src), "n"(PL) : "memory");
+                        }
+                    }
+                } else if constexpr (OP == 0) {
+                    asm volatile("v_add_u32 %0, %1, %2" : "=v"(sa) : "s"(sto_u), "v"(sta_r[J][0]));
                 } else if constexpr (IN8) {
                     if constexpr (OP == 1) {
                         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(s0) : "s"(L.in8_xor), "v"(mfm3l_word<0>(pre[J])));
@@ -554,7 +637,19 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                     MFM3L_CAPTURES;
                     constexpr int J = decltype(j_tag)::value;
                     if constexpr (plan_t::value.stg_done[J] == M) {
-                        pre[J] = stage_load_q(image_start(n2_out), chunk_of(J));
+                        if constexpr (ROT_IN_PRE && H + 1 == NSUB && J < 2 * RB) {
+                            /* the tile's last image: the registers of the first chunks carry the tile's rotator entries to the
+                             * epilogue (four consecutive 4-byte entries per channel - a chunk's 16 bytes), requested here, half a
+                             * phase and more ahead of their use; the chunk's successor is requested behind the last matrix
+                             * instruction instead (the epilogue to arrive) */
+#if MFM3L_KNOCK & 32
+                            mfm3l_put16(pre[J], make_uint4(kb8[J / 2][J % 2], 16384u, 16384u, 16384u));
+#else
+                            mfm3l_put16(pre[J], *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[J / 2][J % 2])));
+#endif
+                        } else {
+                            pre[J] = stage_load_q(image_start(n2_out), chunk_of(J));
+                        }
                     }
                 });
             }
@@ -609,6 +704,9 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
             });
             reload(m_tag);
         });
+        /* behind the last matrix instruction, in front of what is left to finish (a group's recombination behind its 16 wait
+         * states): the fragment registers are free from here on */
+        behind_matrix();
         mfm3l_for<plan_t::value.tail_hi - plan_t::value.tail_lo>([&](auto i_tag) {
             filler(std::integral_constant<int, plan_t::value.tail_lo + decltype(i_tag)::value>{});
         });
@@ -616,9 +714,30 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
 #undef MFM3L_CAPTURES
     };
 
+    /* what follows a tile in the workgroup's stream: the next tile of the chunk, or the first tile of the workgroup's next item
+     * (false: nothing - the workgroup's last tile) */
+    auto advance = [&](uint32_t &it, uint32_t &ch, uint32_t &sl, uint32_t &ti, uint32_t &te, bool &first) -> bool {
+        ti += 1u;
+        first = false;
+        if (ti >= te) {
+            it += gridDim.x;
+            const bool v = mfm3_decode_item(L, it, &ch, &sl);
+            ti = (uint32_t)(((uint64_t)ch * L.ntiles) / L.nchunks);
+            te = (uint32_t)(((uint64_t)(ch + 1u) * L.ntiles) / L.nchunks);
+            first = true;
+            return v;
+        }
+        return true;
+    };
     if constexpr (SHADOW) {
         /* the image behind the first one: on its way while the first tile is set up */
-        const int n1_out = NSUB > 1 ? (int)(tile * MFM_V3_OT + OPI) : (int)((tile + 1u < tend ? tile + 1u : tile) * MFM_V3_OT);
+        int n1_out = (int)(tile * MFM_V3_OT + OPI);
+        if (NSUB == 1) {
+            uint32_t a_item = item, a_chunk = chunk, a_slice = slice, a_tile = tile, a_tend = tend;
+            bool a_first = false;
+            const bool a_valid = advance(a_item, a_chunk, a_slice, a_tile, a_tend, a_first);
+            n1_out = (int)((a_valid ? a_tile : tile) * MFM_V3_OT);
+        }
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
             pre[j] = stage_load_q(image_start(n1_out), chunk_of(j));
@@ -749,7 +868,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                 }
                 __syncthreads();
                 phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::false_type{},
-                      (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch), 0u, 0);
+                      (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch), 0u, 0, [] {});
 #pragma unroll
                 for (int r = 0; r < RB; r++) {
                     uint32_t qw[2];
@@ -762,26 +881,17 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         }
 
         /* ---- the tile: NSUB images, the next one staged into the other buffer while this one multiplies ---- */
-        uint32_t n_item = item, n_chunk = chunk, n_slice = slice, n_tile = tile + 1u, n_tend = tend;
-        bool n_first = false, n_valid = true;
-        if (n_tile >= n_tend) {
-            n_item = item + gridDim.x;
-            n_valid = mfm3_decode_item(L, n_item, &n_chunk, &n_slice);
-            n_tile = (uint32_t)(((uint64_t)n_chunk * L.ntiles) / L.nchunks);
-            n_tend = (uint32_t)(((uint64_t)(n_chunk + 1u) * L.ntiles) / L.nchunks);
-            n_first = true;
-        }
+        uint32_t n_item = item, n_chunk = chunk, n_slice = slice, n_tile = tile, n_tend = tend;
+        bool n_first = false;
+        const bool n_valid = advance(n_item, n_chunk, n_slice, n_tile, n_tend, n_first);
         const uint32_t t1 = n_valid ? n_tile : tile; /* the tile behind this one (a workgroup's last tile: itself - loads and
                                                         stores of the loop are unconditional) */
         uint32_t t2 = t1;                            /* ... and, whole-tile images only, the one behind that */
-        if (SHADOW && NSUB == 1) {
-            uint32_t a_chunk = n_chunk, a_slice = n_slice;
-            t2 = n_tile + 1u;
-            if (t2 >= n_tend) {
-                const bool a_valid = n_valid && mfm3_decode_item(L, n_item + gridDim.x, &a_chunk, &a_slice);
-                t2 = a_valid ? (uint32_t)(((uint64_t)a_chunk * L.ntiles) / L.nchunks) : t1;
-            }
-            t2 = n_valid ? t2 : t1;
+        if (SHADOW && NSUB == 1 && n_valid) {
+            uint32_t a_item = n_item, a_chunk = n_chunk, a_slice = n_slice, a_tile = n_tile, a_tend = n_tend;
+            bool a_first = false;
+            const bool a_valid = advance(a_item, a_chunk, a_slice, a_tile, a_tend, a_first);
+            t2 = a_valid ? a_tile : t1;
         }
         uint4 rva[RB][2];
         if (prio_matrix) {
@@ -789,15 +899,51 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         } else {
             __builtin_amdgcn_s_setprio(0);
         }
+        /* rotator entries of this tile, four consecutive ones per channel: requested behind the tile's last matrix instruction -
+         * the B fragments' registers are free then - and needed behind the group's recombination and the barrier (at the top of
+         * the epilogue, where two-row-block instances asked until round 6, their latency was 8 % of configs[4]'s launch:
+         * profiles/r06_knockout_v3l.txt) */
+        auto request_rotators = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+#if MFM3L_KNOCK & 32
+                    rva[r][c] = make_uint4(kb8[r][c], 16384u, 16384u, 16384u);
+#else
+                    rva[r][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[r][c]));
+#endif
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
         mfm3l_for<NSUB>([&](auto h_tag) {
             constexpr int H = decltype(h_tag)::value;
+            int n2_here = 0; /* (set below) */
+            auto behind = [&]() {
+                if constexpr (H + 1 == NSUB) {
+                    if constexpr (ROT_IN_PRE) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 2 * RB; j++) {
+                            rva[j / 2][j % 2] = mfm3l_get16(pre[j]);
+                            pre[j] = stage_load_q(image_start(n2_here), chunk_of(j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        request_rotators();
+                    }
+                }
+            };
             if constexpr (SHADOW) {
                 /* the image behind the one in `pre` */
                 const int n2_out = H + 2 < NSUB ? (int)(first_out + (uint32_t)(H + 2) * OPI)
                                                 : NSUB == 1 ? (int)(t2 * MFM_V3_OT) : (int)(t1 * MFM_V3_OT + (uint32_t)(H + 2 - NSUB) * OPI);
+                n2_here = n2_out;
 #if !(MFM3L_KNOCK & 16)
                 phase(std::integral_constant<int, NG>{}, h_tag, std::true_type{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch),
-                      (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch), n2_out);
+                      (uint32_t)(uintptr_t)(smem + (cur ^ 1u) * buf_pitch), n2_out, behind);
 #endif
             } else {
                 /* the image behind this one: the tile's next, or the first of the workgroup's next tile */
@@ -807,23 +953,12 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                     pre[j] = stage_load(image_start(next_out), j);
                 }
                 __builtin_amdgcn_sched_barrier(MFM3_SCHED_ALL_BUT_VMEM);
-                phase(std::integral_constant<int, NG>{}, h_tag, std::true_type{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch), 0u, 0);
+                phase(std::integral_constant<int, NG>{}, h_tag, std::true_type{}, (uint32_t)(uintptr_t)(smem + cur * buf_pitch), 0u, 0, behind);
                 /* the next image goes to the other buffer; after the barrier nobody reads the current one any more */
 #pragma unroll
                 for (int j = 0; j < NCH; j++) {
                     stage_store(cur ^ 1u, j, pre[j], L.nstage4);
                 }
-            }
-            if (RB == 1 && H + 1 == NSUB) {
-                /* rotator entries of this tile, four consecutive ones per channel: requested behind the tile's last matrix
-                 * phase, needed behind the barrier.  With two row blocks per wave the sixteen registers are not there - those
-                 * instances ask at the top of the epilogue. */
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    rva[0][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[0][c]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
             /* the stores of the phase are inline asm: the compiler does not know of them, the barrier needs them done */
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -839,15 +974,6 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         {
             static_assert(MFM3_ROT4, "the long-filter kernel is written for 4-byte rotator entries");
             const uint32_t n_left = L.n_new - first_out; /* >= 1 */
-            if (RB > 1) {
-#pragma unroll
-                for (int r = 0; r < RB; r++) {
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        rva[r][c] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(L.rot) + mfm3_opaque(kb8[r][c]));
-                    }
-                }
-            }
 #pragma unroll
             for (int r = 0; r < RB; r++) {
                 uint32_t q[4][2];
@@ -889,10 +1015,14 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                     for (int g = 0; g < 4; g++) {
                         mfm3_conj_mul(q[g][c], pp[g], &s_re[g], &s_im[g]);
                     }
+#if MFM3L_KNOCK & 64
+                    pcm[0] = s_re[0] + s_im[1], pcm[1] = s_re[1] + s_im[2], pcm[2] = s_re[2] + s_im[3], pcm[3] = s_re[3] + s_im[0];
+#else
                     mfm3_discriminate4(s_re, s_im, lut_addr, pcm);
+#endif
                     /* lane 0 of each row of 16 lanes gets lane 15's last sample: the next tile's history */
                     hist[r][c] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[3][c], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
-                    if (RB > 1 && c == 0) {
+                    if (EPI_SERIAL && c == 0) {
                         __builtin_amdgcn_sched_barrier(0); /* ... and one channel after the other */
                     }
                     if (n_left >= MFM_V3_OT) {
@@ -900,7 +1030,11 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                             uint2 w;
                             w.x = __builtin_amdgcn_perm((uint32_t)pcm[1], (uint32_t)pcm[0], 0x05040100u);
                             w.y = __builtin_amdgcn_perm((uint32_t)pcm[3], (uint32_t)pcm[2], 0x05040100u);
-                            mfm3_store_pcm4(L.pcm, voff[r][c], w.x, w.y);
+#if MFM3L_KNOCK & 128
+                            asm volatile("" ::"v"(w.x), "v"(w.y));
+#else
+                            mfm3_store_pcm4(L.pcm, voff[r][c], w.x, w.y, pcm_sys);
+#endif
                             if (want_iq) {
                                 /* the filtered samples beside the PCM: multifm/demod.c:75-81 writes them to signalDebugFile */
                                 *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(L.iq_dbg) + 2u * (size_t)voff[r][c]) =
@@ -920,7 +1054,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
                         }
                     }
                 }
-                if (RB > 1) {
+                if (EPI_SERIAL) {
                     /* two row blocks' taps leave the epilogue some 100 registers: one row block after the other */
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -963,18 +1097,31 @@ constexpr bool mfm3l_fits()
         /* 128-channel slices: quarter-tile images (large decimations: configs[4]'s 400), or - few k-steps, small decimations:
          * the 128-tap filters of 128 and more channels, multifm/receiver.c:195-244 builds as many as the configuration lists -
          * whole-tile images, whose two row blocks' transposition areas then fit LDS beside them */
-        /* (a high tap plane brings a third accumulator per row block: eight registers the fullest instances do not have) */
-        return 8 * (KQ + NH) + (NH > 0 ? 8 : 0) <= 128 && NCH == 4 && (NG == 1 || (NG == 4 && KQ <= 4));
+        /* (a high tap plane brings a third accumulator per row block and a second recombination level: registers the fullest instances do not have) */
+        return 8 * (KQ + NH) + (NH > 0 ? 16 : 0) <= 128 && NCH == 4 && (NG == 1 || (NG == 4 && KQ <= 4));
     }
     /* (eight staging chunks per thread: half-tile images of large decimations only - a whole-tile image that would need them
      * runs as two half-tile ones) */
     return NG != 1 && !(NCH == 8 && NG == 4) && (IN8 || 4 * (KQ + NH) + (NCH == 8 ? 32 : 16) + (NG == 2 ? 8 : 0) <= 160);
 }
 
+/* experiment builds (tools/exp/variant_l.sh): -DMFM3L_ONLY_INSTANCE=16,0,1,4,2,false (KQ, NH, NG, NCH, RB, SPLIT) compiles that instance only, for both input formats */
+template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SPLIT>
+constexpr bool mfm3l_wanted()
+{
+#ifdef MFM3L_ONLY_INSTANCE
+    (void)IN8; /* (both input formats of the instance: the engine asks for every format at commit) */
+    return std::make_tuple(KQ, NH, NG, NCH, RB, SPLIT) == std::make_tuple(MFM3L_ONLY_INSTANCE);
+#else
+    return true;
+#endif
+}
+
 template <int KQ, int NH, int NG, int NCH, bool IN8, int RB, bool SPLIT>
 static const void *mfm3l_instance_ptr()
 {
-    if constexpr (mfm3l_fits<KQ, NH, NG, NCH, IN8, RB>() && !(SPLIT && (NCH == 8 || RB == 2 || NG != 4))) {
+    if constexpr (mfm3l_wanted<KQ, NH, NG, NCH, IN8, RB, SPLIT>() && mfm3l_fits<KQ, NH, NG, (NCH == 1 ? 4 : NCH), IN8, RB>() &&
+                  !(SPLIT && (NCH == 8 || RB == 2 || NG != 4)) && (NCH != 1 || SPLIT)) {
         return reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, NG, NCH, IN8, RB, false, SPLIT>);
     } else {
         return nullptr;
@@ -985,11 +1132,14 @@ template <int KQ, int NH, int NG, int RB>
 static const void *mfm3l_instance_fmt(const mfm_launch_v3 *L, uint32_t nch)
 {
     const bool big = mfm_v3l_built_nch(nch) == 8u;
-    if (L->split_rows) { /* decimations that are not multiples of 4 (small ones: four staging chunks, one row block per wave) */
-        if (L->in8) {
-            return big ? nullptr : mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB, true>();
+    if (L->split_rows) { /* decimations that are not multiples of 4 (small ones: one or four staging chunks, one row block per wave) */
+        if (big) {
+            return nullptr;
         }
-        return big ? nullptr : mfm3l_instance_ptr<KQ, NH, NG, 4, false, RB, true>();
+        if (nch <= 1u) {
+            return L->in8 ? mfm3l_instance_ptr<KQ, NH, NG, 1, true, RB, true>() : mfm3l_instance_ptr<KQ, NH, NG, 1, false, RB, true>();
+        }
+        return L->in8 ? mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB, true>() : mfm3l_instance_ptr<KQ, NH, NG, 4, false, RB, true>();
     }
     if (L->in8) {
         return big ? mfm3l_instance_ptr<KQ, NH, NG, 8, true, RB, false>() : mfm3l_instance_ptr<KQ, NH, NG, 4, true, RB, false>();
@@ -1001,6 +1151,7 @@ template <int KQ, int NH>
 static const void *mfm3l_instance_geo(const mfm_launch_v3 *L, uint32_t nch)
 {
     /* decimations 1, 2, 4 on shifted copies of the image: whole-tile images, one row block per wave, k-step counts 4, 8, 16 */
+#ifndef MFM3L_ONLY_INSTANCE
     if constexpr (KQ == 4 || KQ == 8 || KQ == 16) {
         if (L->shift) {
             if (L->ng != 4u || L->rb != 1u || mfm_v3l_built_nch(nch) != 4u) {
@@ -1010,6 +1161,7 @@ static const void *mfm3l_instance_geo(const mfm_launch_v3 *L, uint32_t nch)
                           : reinterpret_cast<const void *>(&mfm_channel_kernel_v3l<KQ, NH, 4, 4, false, 1, true>);
         }
     }
+#endif
     if (L->shift) {
         return nullptr;
     }

@@ -37,9 +37,6 @@ typedef int mfm_v4i __attribute__((ext_vector_type(4)));
                               0.98 x with it) (mfm3_store_pcm4); bit 0 (A/B builds): the image loads
                               too - wrong, the slices of a chunk share the image through L2 (fetch + 40 %, 4 % slower) */
 #endif
-#ifndef MFM3_PCM_SYSTEM_SCOPE
-#define MFM3_PCM_SYSTEM_SCOPE 0 /* mfm3_store_pcm4: 1 = A/B builds (system scope: less L2-miss traffic at 1024 channels, 1.5-5 % slower at 64) */
-#endif
 #ifndef MFM3_SP
 #define MFM3_SP 4096u /* bytes between the four sub-planes of a byte plane at the fixed geometries (A/B builds: 4160 - not a
                          multiple of the LDS bank cycle, so that the image stores of rows r and r + 1 do not meet in one bank) */
@@ -172,19 +169,20 @@ static __device__ __forceinline__ uint32_t mfm3_sign_flip(uint32_t f, uint32_t s
 }
 
 /* A lane's four PCM samples of one channel (8 bytes; the 16 lanes of a row write one 128-byte line between them), stored
- * with the non-temporal hint.  MFM3_PCM_SYSTEM_SCOPE = 1 (A/B builds) adds system scope: the lines are written through, so that
- * WRITE_SIZE is the PCM bytes to the byte and the PCM stream - 5.3 x the input's bytes at 1024 channels - pushes fewer rotator
- * table lines out of L2 between two uses (L2-miss traffic 1.27 -> 1.155 x algorithmic there, time unchanged), but the 64-channel
- * shapes, whose writes are a larger share of a shorter launch, run 1.5-5 % slower: not shipped (profiles/r05_store_policy.txt). */
-static __device__ __forceinline__ void mfm3_store_pcm4(void *base, uint32_t byte_off, uint32_t w0, uint32_t w1)
+ * with the non-temporal hint.  sys (mfm_launch_v3::pcm_scope, wave uniform): system scope as well - the lines are written through,
+ * so that WRITE_SIZE is the PCM bytes to the byte and the PCM stream - 5.3 x the input's bytes at 1024 channels - pushes fewer
+ * rotator-table lines out of L2 between two uses (L2-miss traffic 1.27 -> 1.155 x algorithmic there at unchanged time,
+ * profiles/r05_store_policy.txt), while the 64-channel shapes, whose writes are a larger share of a shorter launch, run 1.5-5 %
+ * slower with it: the engine asks for it from 512 channels per launch on. */
+static __device__ __forceinline__ void mfm3_store_pcm4(void *base, uint32_t byte_off, uint32_t w0, uint32_t w1, bool sys)
 {
-    typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
-    const mfm_v2u wv = { w0, w1 };
-#if MFM3_PCM_SYSTEM_SCOPE
-    asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1 nt" ::"v"(byte_off), "v"(wv), "s"(base) : "memory");
-#else
-    __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u *>(reinterpret_cast<uint8_t *>(base) + byte_off));
-#endif
+    typedef unsigned int mfm_v2u_t __attribute__((ext_vector_type(2)));
+    const mfm_v2u_t wv = { w0, w1 };
+    if (sys) {
+        asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1 nt" ::"v"(byte_off), "v"(wv), "s"(base) : "memory");
+    } else {
+        __builtin_nontemporal_store(wv, reinterpret_cast<mfm_v2u_t *>(reinterpret_cast<uint8_t *>(base) + byte_off));
+    }
 }
 
 static __device__ __forceinline__ uint32_t mfm3_opaque(uint32_t v)

@@ -66,15 +66,21 @@ struct mfm3l_plan {
     int shadowed, total;   /* fillers placed in gaps / all fillers (NOP16 excluded) */
 };
 
-/* staging operations per chunk: int16 input = address add, 2 x perm + store of the high plane, 2 x perm + 2 x xor + store of the
- * low plane; 8-bit input = address add, 2 x xor, store */
-constexpr int mfm3l_stg_ops(bool in8)
+/* How a staging chunk (4 samples) gets from its registers into the image - the list of single instructions per chunk:
+ *   MFM3L_STG_I16    int16 input, rows whose length is a multiple of 4 samples: address add, 2 x perm + ds_write_b64 of the high
+ *                    plane, 2 x perm + 2 x xor + ds_write_b64 of the low plane (9);
+ *   MFM3L_STG_I8     8-bit input (one sample plane): address add, 2 x xor, ds_write_b64 (4);
+ *   MFM3L_STG_I16_S  int16, decimations that are not multiples of 4 - the chunk can straddle two rows, every sample has its own
+ *                    address: 4 x perm, 2 x xor, 4 address adds, 4 + 4 x ds_write_b16 (18);
+ *   MFM3L_STG_I8_S   the same for 8-bit input: 2 x xor, 4 address adds, 4 x ds_write_b16 (10). */
+enum : int { MFM3L_STG_I16 = 0, MFM3L_STG_I8 = 1, MFM3L_STG_I16_S = 2, MFM3L_STG_I8_S = 3 };
+constexpr int mfm3l_stg_ops(int mode)
 {
-    return in8 ? 4 : 9;
+    return mode == MFM3L_STG_I16 ? 9 : mode == MFM3L_STG_I8 ? 4 : mode == MFM3L_STG_I16_S ? 18 : 10;
 }
-constexpr bool mfm3l_stg_is_lds(bool in8, int op)
+constexpr bool mfm3l_stg_is_lds(int mode, int op)
 {
-    return in8 ? op == 3 : (op == 3 || op == 8);
+    return mode == MFM3L_STG_I16 ? (op == 3 || op == 8) : mode == MFM3L_STG_I8 ? op == 3 : mode == MFM3L_STG_I16_S ? op >= 10 : op >= 6;
 }
 /* levels of shift-adds that recombine the byte-plane products: (hh << 8 + md) << 8 + ll; no high tap plane: md << 8 + ll;
  * one sample plane: hh << 8 + ll, or nothing */
@@ -96,9 +102,10 @@ constexpr int mfm3l_rec_items(int rb, bool in8, int nh)
  * fragments requested PF k-steps ahead into PF + 1 rotating buffers; SHIFTRD: the low plane's read needs its own address;
  * DB: two accumulator sets - a group's recombination runs in the gaps of the next group (else behind its last matrix
  * instruction, after 16 wait states); PEND_IN: the phase before left its last group to this one; CARRY_OUT: this phase
- * leaves its last group to the next (else it is flushed in the tail); NSTGC staging chunks to store in the gaps.
+ * leaves its last group to the next (else it is flushed in the tail); NSTGC staging chunks to store in the gaps, each the
+ * instruction list of STGM.
  */
-template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool SHIFTRD, bool DB, bool PEND_IN, bool CARRY_OUT, int NSTGC>
+template <int KQ, int NH, int NGC, int RB, bool IN8, int PF, bool SHIFTRD, bool DB, bool PEND_IN, bool CARRY_OUT, int NSTGC, int STGM = (IN8 ? MFM3L_STG_I8 : MFM3L_STG_I16)>
 constexpr auto mfm3l_make_plan()
 {
     constexpr int NMF = mfm3l_nmf(KQ, NH, NGC, RB, IN8);
@@ -106,7 +113,7 @@ constexpr auto mfm3l_make_plan()
     constexpr int RPK = IN8 ? 1 : 2;
     constexpr int NLA = mfm3l_la_levels(IN8, NH);
     constexpr int NREC = mfm3l_rec_items(RB, IN8, NH);
-    constexpr int SPC = mfm3l_stg_ops(IN8);
+    constexpr int SPC = mfm3l_stg_ops(STGM);
     constexpr int NREQ = SHIFTRD && !IN8 ? 4 : 1 + RPK;
     constexpr int NFL = NS * NREQ + (NGC + 1) * (NREC + 1) + NSTGC * SPC + 4;
     static_assert(!CARRY_OUT || DB, "a group can only be left to the next phase when there are two accumulator sets");
@@ -189,7 +196,7 @@ constexpr auto mfm3l_make_plan()
     auto emit = [&](const mfm3l_fl &f, int at_m) {
         p.fl[nf++] = f;
         if (f.kind == MFM3L_F_RDH || f.kind == MFM3L_F_RDL || f.kind == MFM3L_F_TPW ||
-            (f.kind == MFM3L_F_STG && mfm3l_stg_is_lds(IN8, f.b))) {
+            (f.kind == MFM3L_F_STG && mfm3l_stg_is_lds(STGM, f.b))) {
             nl++;
         }
         if ((f.kind == MFM3L_F_RDH && IN8) || f.kind == MFM3L_F_RDL) {
