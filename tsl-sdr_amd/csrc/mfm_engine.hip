@@ -2543,6 +2543,14 @@ int mfm_engine_push_pinned_run(struct mfm_engine *e, const void *first, size_t s
             const size_t pend = (size_t)mfm_engine_pending_samples(e);
             const size_t until = co > pend ? (co - pend + nr_samples_each - 1u) / nr_samples_each : 1u;
             k = std::min(k, std::max<size_t>(until, 1u));
+            /* ... and not at all where ONE buffer pushed by itself would launch right away (the device has nothing to do, or a
+             * quarter of the running launch has gathered: plan_block's `want`): the first buffer goes alone, as per-buffer pushes
+             * would have sent it, and the run behind it gathers under that launch */
+            SubmitPlan one;
+            plan_block(e, nr_samples_each, &one, false);
+            if (one.want || one.must) {
+                k = 1;
+            }
         } else {
             k = 1; /* no gathering: every buffer is a launch of its own */
         }

@@ -706,11 +706,16 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
         });
         /* behind the last matrix instruction, in front of what is left to finish (a group's recombination behind its 16 wait
          * states): the fragment registers are free from here on */
-        behind_matrix();
-        mfm3l_for<plan_t::value.tail_hi - plan_t::value.tail_lo>([&](auto i_tag) {
+        /* (first what is left of the staging - instances with more staging operations than gaps -, and the successors of the
+         * chunks that only now are through) */
+        mfm3l_for<plan_t::value.tail_mid - plan_t::value.tail_lo>([&](auto i_tag) {
             filler(std::integral_constant<int, plan_t::value.tail_lo + decltype(i_tag)::value>{});
         });
         reload(std::integral_constant<int, NMF>{});
+        behind_matrix();
+        mfm3l_for<plan_t::value.tail_hi - plan_t::value.tail_mid>([&](auto i_tag) {
+            filler(std::integral_constant<int, plan_t::value.tail_mid + decltype(i_tag)::value>{});
+        });
 #undef MFM3L_CAPTURES
     };
 

@@ -61,6 +61,8 @@ struct mfm3l_plan {
     int gap_lo[NMF_ > 0 ? NMF_ : 1], gap_hi[NMF_ > 0 ? NMF_ : 1]; /* fillers behind matrix instruction m: fl[gap_lo[m] .. gap_hi[m]) */
     mfm3l_fl fl[NFL_];
     int tail_lo, tail_hi;  /* fillers behind the last gap */
+    int tail_mid;          /* ... of which [tail_lo, tail_mid) end with the last staging operation: the chunks whose staging only
+                              finishes there are reloaded behind it, in front of the rest of the tail */
     int stg_done[9];       /* per staging chunk: the matrix instruction in whose gap its last operation sits (NMF: the tail) */
     int max_gap;           /* most fillers in one gap outside flush points (2 by construction) */
     int shadowed, total;   /* fillers placed in gaps / all fillers (NOP16 excluded) */
@@ -289,5 +291,11 @@ constexpr auto mfm3l_make_plan()
         emit(stg[stg_h++], NMF);
     }
     p.tail_hi = nf;
+    p.tail_mid = p.tail_lo;
+    for (int i = p.tail_lo; i < p.tail_hi; i++) {
+        if (p.fl[i].kind == MFM3L_F_STG) {
+            p.tail_mid = i + 1;
+        }
+    }
     return p;
 }
