@@ -93,8 +93,8 @@ extern "C" {
                                   than 64 channels when two row blocks' taps fit 128 registers); same bits; parity tests, A/B timing */
 #define MFM_F_SLICE_128 0x800u  /* 128-tap filters (filter/direct_fir.c:363-384 at multifm's 2.4 MS/s -> 25 kS/s geometry) on slices of
                                   128 channels - two row blocks per wave share every B fragment and every staged image
-                                  (mfm_kernel_v3l.hip) - whatever the channel count; the default takes them from the channel count
-                                  at which they measured faster than slices of 64.  Same bits; parity tests, A/B timing */
+                                  (mfm_kernel_v3l.hip) - whatever the channel count; the default takes them from 512 channels on,
+                                  where they measured faster than slices of 64 (by 0.6-1.4 %).  Same bits; parity tests, A/B timing */
 #define MFM_F_SLICE_64 0x1000u  /* ... never: slices of 64 channels (mfm_kernel_v3.hip) at any channel count */
 #define MFM_F_PCM_WRITE_BACK 0x2000u /* second-generation kernels: PCM stores never go through to memory with system scope (the default does
                                   that for launches of 512 channels and more: less L2-miss traffic there); same bits; A/B timing */

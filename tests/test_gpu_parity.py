@@ -396,6 +396,27 @@ def test_long_filters_on_8bit_blocks_resident_and_streamed(pkg, ora, fmt, decim,
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("nch", [130, 192, 320])
+def test_work_items_of_a_launch_fit_one_round_of_workgroups(pkg, ora, nch):
+    """Round 6: the second-generation kernels deal (chunk, slice) items chunk-major over the eight XCDs; with 3 or 5 slices the
+    engine's 'slots / slices' chunks per slice was not a multiple of 8, the grid overflowed the 512 workgroup slots and a few
+    workgroups ran a second chunk behind everybody else's only one (a launch took up to twice its work,
+    profiles/r06_ab_chunking.txt).  The chunk count is a multiple of 8 now: the last launch's grid is chunks x slices, within the
+    slots - and the PCM is still the oracle's."""
+    fs, decim, taps, offs, gains = pkg.synth.plan("cfg3_1024ch", nr_channels=nch)
+    block = 96 * 64 * 700
+    iq = pkg.synth.synth_iq(block + 128, fs, offs[:3], seed=nch)
+    eng = _mk_engine(pkg, fs, decim, taps, offs, gains, max_block=block + 128, want_iq=False)
+    pcm, _ = eng.run(iq, block + 128)
+    st = eng.stats()
+    cre, cim, incr = _oracle_tables(eng, nch)
+    eng.close()
+    nslices = -(-nch // 64)
+    assert st["kernel_variant"] == 2 and st["grid_last"] == ((512 // nslices) & ~7) * nslices, st
+    ref, _ = ora.run_channels(iq, cre, cim, incr, decim, threads=8)
+    assert np.array_equal(pcm, ref)
+
+
 @pytest.mark.parametrize("nch", [1, 7, 61, 65, 130])
 def test_channel_counts_that_do_not_fill_row_blocks(pkg, ora, nch):
     """The matrix kernel works on blocks of 8 channels per wave and 64 per workgroup slice: counts that leave a row

@@ -264,8 +264,9 @@ def load_library():
     lib.mfm_engine_get_launch_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]
     lib.mfm_engine_get_launch_cycles.restype = C.c_size_t
     lib.mfm_engine_stream.restype = vp
-    lib.mfm_group_exchange_detail.argtypes = [vp, C.c_uint32, vp]
-    lib.mfm_group_rccl_library.argtypes = [C.c_char_p, C.c_size_t]
+    if hasattr(lib, "mfm_group_exchange_detail"):   # (an older library under MFM_LIB, tools/exp/ab.py: same-box A/B against it)
+        lib.mfm_group_exchange_detail.argtypes = [vp, C.c_uint32, vp]
+        lib.mfm_group_rccl_library.argtypes = [C.c_char_p, C.c_size_t]
     lib.mfm_strerror.argtypes = [C.c_int]
     lib.mfm_strerror.restype = C.c_char_p
     lib.mfm_last_error.restype = C.c_char_p

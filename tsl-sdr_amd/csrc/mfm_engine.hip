@@ -79,7 +79,8 @@ constexpr uint64_t kCycleRing = 1024; /* launches whose shader-clock stamps are 
 constexpr size_t kLaunchRing = 4096; /* per-launch durations kept for mfm_engine_get_launch_ms() */
 constexpr uint32_t kMaxOutputsPerTile = 128;
 /* 128-tap filters: slices of 128 channels from this many channels on (below, slices of 64: MFM_F_SLICE_128 / _64 override) */
-constexpr uint32_t kSlice128MinChannels = 0xffffffffu; /* measured (profiles/r06_slice128_ab.txt): slices of 64 stay ahead at every count */
+constexpr uint32_t kSlice128MinChannels = 512; /* the measured crossover (profiles/r06_slice128_ab.txt): +1.8 % at 128, +1.7 % at 256,
+                                                 -0.6 % at 512, -0.8 % at 768, -1.4 % at 1024 channels */
 /* second-generation kernels: PCM stores with system scope from this many channels per launch on (profiles/r05_store_policy.txt,
  * r06_hbm_traffic_1024ch.json: L2-miss traffic 1.27 -> 1.16 x algorithmic at 1024 channels at unchanged time; +0.4 % time at 256
  * channels and 1.5-5 % at 64, where there is nothing to gain: profiles/r06_ab_store_policy.txt) */
@@ -1971,7 +1972,12 @@ int launch_locked(mfm_engine *e)
             /* (the long-filter kernel's small 8-bit instances are built for two workgroups per CU, the others for one) */
             const uint32_t wg_per_cu = (3u == e->v_layout && 2u * e->v_lds_bytes <= 160u * 1024u) ? mfm_v3l_wg_per_cu(&V) : e->v_wg_per_cu;
             const uint32_t slots = 256u * wg_per_cu;
-            const uint32_t per_slice = std::max(1u, slots / V.nslices);
+            /* (a multiple of 8: the items are dealt chunk-major over the eight XCDs - item = 8 * (chunk / 8 * nslices + slice) +
+             * chunk % 8, mfm3_decode_item - so a chunk count that is not one leaves holes in the last group of eight, the grid
+             * overflows the slots and a few workgroups run a SECOND chunk while the others are done: with 3, 5, 6 or 12 slices
+             * (130-192, 257-320, ... channels) a launch took up to twice as long as its work, profiles/r06_ab_chunking.txt) */
+            uint32_t per_slice = std::max(1u, slots / V.nslices);
+            per_slice = per_slice >= 8u ? per_slice & ~7u : per_slice;
             /* one chunk per slot: shorter chunks (3..10 tiles, several rounds) were 2-6 % slower on MI355X */
             V.nchunks = std::min(V.ntiles, per_slice);
             V.cl = (V.ntiles + V.nchunks - 1u) / V.nchunks;
