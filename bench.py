@@ -312,8 +312,9 @@ def library_sha16(pkg):
 
 def instance_name(pkg, st, in8):
     """key of a (kernel, geometry) in profiles/r*_issue_model.json"""
-    return "variant%d_ch%d_taps%d_ksteps%d_mask%x_tile%d%s" % (st["kernel_variant"], st["nr_channels"], st["nr_taps"], st["k_steps"],
-                                                                st["tap_hi_mask"], st["outputs_per_tile"], "_in8" if in8 else "")
+    return "variant%d_ch%d_taps%d_ksteps%d_mask%x_tile%d%s%s" % (st["kernel_variant"], st["nr_channels"], st["nr_taps"], st["k_steps"],
+                                                                  st["tap_hi_mask"], st["outputs_per_tile"], "_in8" if in8 else "",
+                                                                  "_slice128" if st.get("slice_channels") == 128 else "")
 
 
 BOARD_SAMPLE_AFTER_S = float(os.environ.get("BENCH_BOARD_SAMPLE_AFTER_S", "0.6"))
@@ -503,6 +504,7 @@ def north_star_shape(pkg, torch, block, steps=12, settle_s=0.3):
                "value": block * nch / ms / 1e3, "unit": "MSamp/s x channels", "kernel_ms": ms,
                "kernel_ms_min": float(per.min()), "kernel_ms_max": float(per.max()), "wall_ms_per_block": wall_ms,
                "kernel_variant": st["kernel_variant"], "rot_exact_channels": st["rot_exact_channels"],
+               "slice_channels": st.get("slice_channels"),   # 128: the long-filter kernel's two-row-block form (from 512 channels on)
                "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": frac, "bytes_per_launch": bytes_alg},
                "compute_roofline": {
@@ -1412,7 +1414,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "timed_launches": int(timed), "launches": int(launches),
-                         "kernel": kname, "kernel_ms": k_ms,
+                         "kernel": kname, "slice_channels": st1.get("slice_channels"), "kernel_ms": k_ms,
                          "kernel_ms_min": float(per_launch[0]) if len(per_launch) else None,
                          "kernel_ms_median": float(np.median(per_launch)) if len(per_launch) else None,
                          "kernel_ms_p95": float(np.percentile(per_launch, 95)) if len(per_launch) >= 20 else None,

@@ -165,7 +165,9 @@ struct mfm_stats {
     uint32_t taps_resident;    /* first-generation matrix kernel, filters of 129..512 taps: 1 = int16 blocks run an instance that
                                   keeps every k-step of taps in registers, 0 = the taps are streamed from L2 (MFM_F_STREAM_TAPS,
                                   or no resident instance for the geometry) */
-    uint32_t reserved0;
+    uint32_t slice_channels;   /* matrix kernels: channels whose workgroup shares one staged image: 64, or 128 on the long-filter kernel with
+                                  two row blocks per wave (129..512 taps at more than 64 channels; 128 taps from 512 channels on or with
+                                  MFM_F_SLICE_128); 0: the v_dot2 kernel */
     uint64_t submits;          /* blocks accepted (mfm_engine_submit / push); with coalesce_samples several of them share a launch */
     uint64_t pending_samples;  /* samples accepted and not yet launched (coalesce_samples; mfm_engine_flush launches them) */
 };

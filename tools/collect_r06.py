@@ -52,6 +52,8 @@ what = collections.OrderedDict([
     ("c128", "128 channels (configs[2] shard of 8)"), ("c256", "256 channels"), ("c1024", "1024 channels on one GPU (north star's shape)"),
     ("c128_slice128", "128 channels on 128-channel slices (MFM_F_SLICE_128: long-filter kernel, two row blocks per wave)"),
     ("c256_slice128", "256 channels on 128-channel slices"), ("c1024_slice128", "1024 channels on 128-channel slices"),
+    ("c128_slice64", "128 channels on 64-channel slices (MFM_F_SLICE_64: mfm_kernel_v3.hip)"), ("c256_slice64", "256 channels on 64-channel slices"),
+    ("c1024_slice64", "1024 channels on 64-channel slices (round 5's form of north star's shape)"),
     ("cfg5_auto", "configs[4] per-GPU share: 256 ch, D = 400, 512 taps - long-filter kernel, two row blocks per wave"),
     ("cfg5_v3l1", "the same, one row block per wave forced"), ("cfg5_mfma1", "the same, first generation (rounds 3-4)"),
     ("d25_auto", "pocsag_rtlsdr + its 256-tap file: 64 ch, D = 25 - long-filter kernel"), ("d25_mfma1", "the same, first generation"),
@@ -114,7 +116,8 @@ ks = stats_avg(os.path.join(P, "r06_rocprofv3_kernel_stats.csv"), "channel_kerne
 ks1024 = stats_avg(os.path.join(P, "r06_rocprofv3_kernel_stats_1024ch.csv"), "channel_kernel")
 
 # ---- PMC passes, per shape ----------------------------------------------------------------------------------------------
-shapes = collections.OrderedDict([("head", "driverflags"), ("c1024", "c1024"), ("c1024s128", "c1024_slice128"), ("c1024wb", "c1024"),
+shapes = collections.OrderedDict([("head", "driverflags"), ("c1024", "c1024"), ("c1024s128", "c1024_slice128"), ("c1024s64", "c1024_slice64"),
+                                  ("c1024wb", "c1024"),
                                   ("cfg5", "cfg5_auto"), ("d25", "d25_auto"),
                                   ("d100", "d100_auto"), ("d120", "d120_auto")])
 pmc, raw, traffic, issue_shapes, pmc_lines = {}, [], {}, {}, {}
@@ -153,7 +156,7 @@ for tag, line_key in shapes.items():
         traffic[tag] = t
     if d and "SQ_INSTS_MFMA" in m and "SQ_INSTS_VALU" in m:
         inst = d["roofline"].get("instance")
-        if inst and tag not in ("c1024s128", "c1024wb"):  # (the forced forms share the default's instance key)
+        if inst and tag != "c1024wb":  # (slices of 64 and of 128 have keys of their own; the write-back run shares the default's)  # (the forced forms share the default's instance key)
             issue_shapes[inst] = {"tag": tag, "kernel": kn, "workload": d["config"]["workload"], "mfma_insts_per_launch": m["SQ_INSTS_MFMA"],
                                   "other_valu_insts_per_launch": m["SQ_INSTS_VALU"] - m["SQ_INSTS_MFMA"],
                                   "launch_cycles_in_profiled_run": m.get("GRBM_GUI_ACTIVE", nan) / 8.0,
@@ -216,8 +219,8 @@ for tag, (m, kn) in pmc.items():
 open(os.path.join(P, "r06_rocprofv3_pmc_summary.txt"), "w").write("\n".join(summ + raw) + "\n")
 print("\n".join(summ))
 
-# ---- long filters: second generation against first, targets of VERDICT r04 item 2 ----------------------------------------
-targets = {"cfg5": 0.23, "d25": 0.72, "d100": 0.20, "d120": 0.17}
+# ---- long filters: second generation against first, targets of VERDICT r05 item 2 ----------------------------------------
+targets = {"cfg5": 0.205, "d25": 0.63, "d120": 0.18}  # VERDICT r05, "Next round" item 2
 lf = ["# Long filters (129-512 taps): the second-generation long-filter kernel (mfm_kernel_v3l.hip, `auto`) against the first-generation",
       "# resident-tap kernel that rounds 3-4 ran them on (`--kernel mfma1`), same box, same call (tools/prof_r06.sh), 2^26-sample blocks,",
       "# 40 steps, kernel ms by the engine's HIP events.  Counters from the --pmc passes of the same call (r06_rocprofv3_pmc_summary.txt).",
@@ -225,7 +228,7 @@ lf = ["# Long filters (129-512 taps): the second-generation long-filter kernel (
       "shape  geometry                                   v3l ms   v1 ms    ratio   target  met   lane-instr/(ch,out)  matrix busy  busy(3-cyc)  HBM ratio"]
 geo = {"cfg5": "256 ch, D = 400, 512 taps (configs[4])", "d25": "64 ch, D = 25, 256 taps", "d100": "64 ch, D = 100, 256 taps",
        "d120": "64 ch, D = 120, 512 taps", "t512": "64 ch, D = 96, 512 taps", "t256": "64 ch, D = 96, 256 taps"}
-lf_md = ["| shape | long-filter kernel (ms) | first generation (ms) | ratio | VERDICT r04 target | lane-instr per (ch, out) | matrix busy | busy (3-cycle) |", "|---|---|---|---|---|---|---|---|"]
+lf_md = ["| shape | long-filter kernel (ms) | first generation (ms) | ratio | VERDICT r05 target | lane-instr per (ch, out) | matrix busy | busy (3-cycle) |", "|---|---|---|---|---|---|---|---|"]
 for s in ("cfg5", "d25", "d100", "d120", "t512", "t256"):
     a, b = lines.get(s + "_auto"), lines.get(s + "_mfma1")
     if not a or not b:

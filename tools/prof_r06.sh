@@ -16,6 +16,7 @@ timeout 300 python bench.py --config cfg2_64ch_grid $N > $O/bench_grid64.json 2>
 for c in 128 256 1024; do
   timeout 600 python bench.py --config cfg3_1024ch --channels-per-gpu $c --steps 40 --warmup 5 $N > $O/bench_c$c.json 2> $O/bench_c$c.err
   timeout 600 python bench.py --config cfg3_1024ch --channels-per-gpu $c --kernel slice128 --steps 40 --warmup 5 $N > $O/bench_c${c}_slice128.json 2> $O/bench_c${c}_slice128.err
+  timeout 600 python bench.py --config cfg3_1024ch --channels-per-gpu $c --kernel slice64 --steps 40 --warmup 5 $N > $O/bench_c${c}_slice64.json 2> $O/bench_c${c}_slice64.err
 done
 # long filters: the second-generation long-filter kernel (auto) against the first generation (mfma1, what rounds 3-4 ran)
 for s in "cfg5 cfg5_airspy 256" "t512 cfg2_64ch_512taps 64" "t256 cfg2_64ch_256taps 64" "d25 pocsag_rtlsdr_256taps 64" "d100 pocsag_airspy 64" "d120 multifm_airspy 64"; do
@@ -47,6 +48,7 @@ pmc() { # tag, bench flags...
 pmc head
 pmc c1024 --config cfg3_1024ch --channels-per-gpu 1024
 pmc c1024s128 --config cfg3_1024ch --channels-per-gpu 1024 --kernel slice128
+pmc c1024s64 --config cfg3_1024ch --channels-per-gpu 1024 --kernel slice64
 pmc c1024wb --config cfg3_1024ch --channels-per-gpu 1024 --pcm-write-back
 pmc cfg5 --config cfg5_airspy --channels-per-gpu 256
 pmc d25 --config pocsag_rtlsdr_256taps --channels-per-gpu 64

@@ -113,7 +113,7 @@ class Stats(C.Structure):
                 ("launches_8bit", C.c_uint64), ("timed_launches", C.c_uint64),
                 ("rot_exact_channels", C.c_uint32), ("rot_fast_slices", C.c_uint32),
                 ("k_steps", C.c_uint32), ("tap_hi_mask", C.c_uint32),
-                ("taps_resident", C.c_uint32), ("reserved0", C.c_uint32),
+                ("taps_resident", C.c_uint32), ("slice_channels", C.c_uint32),
                 ("submits", C.c_uint64), ("pending_samples", C.c_uint64)]
 
 

@@ -2943,7 +2943,7 @@ int mfm_engine_get_stats(struct mfm_engine *e, struct mfm_stats *st)
     st->k_steps = e->use_mfma ? e->m_ks : 0u;
     st->tap_hi_mask = e->use_mfma ? e->m_ah_mask : 0u;
     st->taps_resident = ((e->use_mfma && !e->use_v3 && e->m_resident_taps) || (e->use_v3 && 3u == e->v_layout)) ? 1u : 0u;
-    st->reserved0 = 0;
+    st->slice_channels = e->use_v3 ? ((3u == e->v_layout) ? 64u * e->v_rb : 64u) : e->use_mfma ? 64u : 0u;
     st->submits = e->submits;
     st->nr_channels = (uint32_t)e->chans.size();
     st->nr_taps = e->nr_taps;
