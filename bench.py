@@ -1114,18 +1114,6 @@ def group_main(args, pkg, devices, shared, world_for_line):
     return line
 
 
-def idle_rank(args):
-    """`--exchange group` under torch.distributed.run: rank 0 drives every GPU of the node through the device group; the other
-    ranks the driver started take part in the barriers and nothing else (they never touch a GPU)."""
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-    dist.barrier()   # start
-    dist.barrier()   # rank 0 is through
-    dist.destroy_process_group()
-
-
 def start_watchdog(args):
     """N > 1 only: a run that does not finish (a collective that never completes on hardware this code has not met) ends with
     a message and a non-zero exit instead of sitting there until the driver's limit.  BENCH_WATCHDOG_S, default 900."""
@@ -1148,34 +1136,52 @@ def main():
     args = parse()
     start_watchdog(args)
     group = args.exchange == "group" and (args.gpus > 1 or args.group_shards > 0)
+    group_error = None
     if group:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
-        if world > 1 and rank != 0:
-            return idle_rank(args)
-        from __graft_entry__ import load_package
-        pkg = load_package()
+        line = None
         if world > 1:
+            # the ranks the driver started: rank 0 drives every GPU of the node through the device group, the others wait for its
+            # word (they have not touched a GPU).  Should the group not come up on this node - a librccl that does not load, a
+            # communicator that cannot be made in one process - rank 0 says so and EVERY rank goes on to the per-rank form below
+            # (one engine per rank, torch.distributed = RCCL moves the block): a line with the reason in it instead of none.
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("gloo", rank=0, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
-        shared = args.group_shards > 0
-        devices = [0] * args.group_shards if shared else list(range(args.gpus))
-        line = group_main(args, pkg, devices, shared, args.gpus)
+        if rank == 0:
+            from __graft_entry__ import load_package
+            pkg = load_package()
+            shared = args.group_shards > 0
+            devices = [0] * args.group_shards if shared else list(range(args.gpus))
+            try:
+                if os.environ.get("BENCH_TEST_GROUP_FAILS") == "1":   # (tests/test_group.py: the hand-over below, without a broken node)
+                    raise RuntimeError("BENCH_TEST_GROUP_FAILS=1")
+                line = group_main(args, pkg, devices, shared, args.gpus)
+            except Exception as ex:   # noqa: BLE001 - whatever it was, the other ranks must hear of it
+                if world == 1:
+                    raise
+                group_error = f"{type(ex).__name__}: {ex}"
+                sys.stderr.write(f"bench.py: the device group did not come up ({group_error}); falling back to one engine per rank\n")
         if world > 1:
+            word = [group_error]
+            dist.broadcast_object_list(word, src=0)
+            group_error = word[0]
             dist.barrier()
             dist.destroy_process_group()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(line), flush=True)
-        if not line["verified"]:
-            raise SystemExit(f"bench.py: the timed kernel's output differs from the oracle: {line['verification']}")
-        return
+        if group_error is None:
+            if rank == 0:
+                try:
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:
+                    pass
+                print(json.dumps(line), flush=True)
+                if not line["verified"]:
+                    raise SystemExit(f"bench.py: the timed kernel's output differs from the oracle: {line['verification']}")
+            return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
     import torch
@@ -1434,6 +1440,9 @@ def main():
             # N > 1: every step moves the whole block to each of the other N - 1 GPUs; the bench replays blocks as fast
             # as the GPUs take them, so this - not the kernel - is what an N > 1 line is usually bound by (a live
             # 2.4 MS/s stream is 10 MB/s).  xGMI: 7 links x ~153 GB/s per GPU, point to point.
+            # set when `--exchange group` (the default at N > 1) could not bring the device group up on this node and the ranks went
+            # on with one engine each: what the group said
+            "group_error": group_error,
             "exchange": None if not use_dist else {
                 "algo": exchange.algo, "algo_timings_s": exchange.timings, "bytes_per_step_per_peer": block * (2 if in8 else 4),
                 "peers": world - 1,

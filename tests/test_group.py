@@ -314,6 +314,45 @@ def test_bench_group_path_over_the_fake_transport(tmp_path, shards):
 
 
 @pytest.mark.gpu
+def test_bench_group_path_as_the_driver_launches_it(tmp_path):
+    """the driver's launch form for N > 1 - `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` - with two ranks on
+    the one GPU of the box: rank 0 drives both shards (one device, fake transport), rank 1 waits for its word over gloo without
+    touching the GPU; ONE JSON line, exit code 0."""
+    so = tmp_path / "librccl.so"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
+                        os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--group-shards", "2",
+                        "--channels-per-gpu", "40", "--steps", "5", "--warmup", "2", "--settle-seconds", "0", "--block-log2", "21"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified"] is True and len(line["group"]["shards"]) == 2
+    assert line["verification"]["shards_verified"] == [True, True] and line["scaling_efficiency"] > 0
+
+
+def test_bench_ranks_leave_the_group_path_together_when_it_fails():
+    """N > 1 under torch.distributed.run, the device group does not come up (BENCH_TEST_GROUP_FAILS=1 stands for a node whose RCCL
+    cannot make the communicator in one process): rank 0 tells the other ranks over gloo and ALL of them go on to the per-rank form.
+    Here (no GPU in this container, or one on the box) that form stops at its own first check - on both ranks, with the reason of
+    the fall-back in rank 0's stderr, and without anybody waiting for a barrier the other side never reaches."""
+    env = dict(os.environ, BENCH_TEST_GROUP_FAILS="1", BENCH_WATCHDOG_S="240")
+    r = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--settle-seconds", "0", "--block-log2", "20", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and "giving up" not in out, out[-3000:]
+    assert "the device group did not come up (RuntimeError: BENCH_TEST_GROUP_FAILS=1); falling back to one engine per rank" in out, out[-3000:]
+    # both ranks reached the per-rank form: without a second GPU it ends at the device check / at set_device of rank 1
+    assert out.count("bench.py needs a GPU") == 2 or "invalid device ordinal" in out or "device" in out.lower(), out[-3000:]
+
+
+@pytest.mark.gpu
 def test_bench_line_carries_the_group_path_and_the_north_star_shape():
     """the N = 1 line: `group_path` - the same workload through mfm_group_* on one device - the same rate as `value` (loosely here: small
     blocks; 2 % at the driver's size), and `north_star_shape` - 1024 channels on the one GPU - with its matrix-instruction bound"""
