@@ -437,7 +437,8 @@ struct mfm_exchange_detail {
 #define MFM_BOUND_KERNEL 1u
 #define MFM_BOUND_EXCHANGE 2u
 int mfm_group_exchange_detail(struct mfm_group *g, uint32_t shard, struct mfm_exchange_detail *out);
-/* Which RCCL a device group of more than one GPU uses: loads it as mfm_group_commit() would - a librccl that is mapped into the
+/* Which RCCL a device group of more than one GPU uses: loads it as mfm_group_commit() would - the file the environment variable
+ * MFM_RCCL_LIBRARY names, if it is set (nothing else is tried then); else a librccl that is mapped into the
  * process already (PyTorch brings its own), else the loader's search for the bare name (LD_LIBRARY_PATH, the cache), then
  * $ROCM_PATH/lib/librccl.so and /opt/rocm/lib/librccl.so - and writes the file's path.  MFM_E_DEVICE when none can be loaded. */
 int mfm_group_rccl_library(char *path, size_t cap);

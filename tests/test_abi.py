@@ -69,6 +69,17 @@ def test_rccl_loader_prefers_a_mapped_library_then_the_search_path(pkg, tmp_path
     # 2. first on LD_LIBRARY_PATH
     got = _rccl_probe("print(pkg.binding.rccl_library())", dict(base, LD_LIBRARY_PATH=str(so.parent)))
     assert os.path.realpath(got) == os.path.realpath(so)
+    # 3. named by the operator: wins over a mapped copy (here: a second double under another name, mapped first)
+    other = _fake_rccl(tmp_path, "librccl.so.1")
+    got = _rccl_probe("import ctypes; ctypes.CDLL(%r)\nprint(pkg.binding.rccl_library())" % str(other),
+                      dict(base, LD_LIBRARY_PATH="", MFM_RCCL_LIBRARY=str(so)))
+    assert os.path.realpath(got) == os.path.realpath(so)
+    # ... and a name that cannot be loaded is an error, not a reason to look elsewhere
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as ge\npkg = ge.load_package()\n"
+                        "print(pkg.binding.rccl_library())" % ROOT], capture_output=True, text=True, timeout=300,
+                       env=dict(base, LD_LIBRARY_PATH=str(so.parent), MFM_RCCL_LIBRARY=str(tmp_path / "nowhere.so")))
+    assert r.returncode != 0 and "MFM_RCCL_LIBRARY" in r.stdout + r.stderr, r.stdout[-800:] + r.stderr[-800:]
 
 
 def test_error_codes_and_messages(pkg):

@@ -322,7 +322,8 @@ def test_bench_group_path_as_the_driver_launches_it(tmp_path):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", str(so),
                         os.path.join(ROOT, "tests", "hoststub", "fake_rccl.cpp")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    # (rank 0 has torch.distributed - and with it PyTorch's librccl - mapped by the time the group loads RCCL: the double is named)
+    env = dict(os.environ, MFM_RCCL_LIBRARY=str(so))
     r = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--group-shards", "2",
                         "--channels-per-gpu", "40", "--steps", "5", "--warmup", "2", "--settle-seconds", "0", "--block-log2", "21"],

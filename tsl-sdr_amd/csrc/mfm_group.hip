@@ -91,7 +91,7 @@ int find_mapped_rccl(struct dl_phdr_info *info, size_t, void *out)
 }
 
 /* One process may carry several copies of RCCL (PyTorch ships its own beside /opt/rocm's); two of them in one address space
- * each bring their own device state.  So: whatever is mapped already wins; else the loader's own search for the bare name
+ * each bring their own device state.  So: the file MFM_RCCL_LIBRARY names, if set; else whatever is mapped already; else the loader's own search for the bare name
  * (LD_LIBRARY_PATH, the cache), and where that finds nothing the ROCm tree the environment names and the usual place. */
 std::mutex g_rccl_mu;
 RcclApi g_rccl;
@@ -104,7 +104,17 @@ int load_rccl(RcclApi *api)
         void *h = nullptr;
         std::string tried;
         char mapped[1024] = "";
-        if (dl_iterate_phdr(find_mapped_rccl, mapped) && mapped[0]) {
+        /* MFM_RCCL_LIBRARY: the operator names the file (a site build of RCCL; the tests' transport double under a launcher that
+         * has mapped PyTorch's copy already) - taken as given, nothing else is tried behind it */
+        if (const char *named = getenv("MFM_RCCL_LIBRARY")) {
+            if (*named) {
+                h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+                if (!h) {
+                    return gfail(MFM_E_DEVICE, "cannot load MFM_RCCL_LIBRARY=%s: %s", named, dlerror());
+                }
+            }
+        }
+        if (!h && dl_iterate_phdr(find_mapped_rccl, mapped) && mapped[0]) {
             h = dlopen(mapped, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             tried += std::string(mapped) + " (mapped); ";
         }
