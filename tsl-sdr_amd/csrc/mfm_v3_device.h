@@ -251,6 +251,13 @@ static __device__ __forceinline__ uint32_t mfm3_fold64(uint64_t k, uint32_t mu, 
  * T[floor(alpha)] - which saves the conversion and the shift.
  * lut_addr: LDS byte address of the table: {T[i], dT[i]} pairs (MFM3_LUT_MODE 0: T[0], with dT[0] 1024 bytes behind it).
  */
+/* ASM_READS (the long-filter kernel's instances of one row block per wave, two waves per SIMD): the four table reads of a call are
+ * single asm statements, waited for ONCE, behind the quadrant arithmetic of all four outputs.  Left to the compiler, ONE of the four
+ * reads is sunk into an exec-masked branch of its own - s_and_saveexec / ds_read / s_waitcnt lgkmcnt(0) / s_or - a whole LDS round
+ * trip with nothing else of the wave in flight, per channel and four outputs.  Measured (tools/exp/ab.py, profiles/r06_ab_asm_reads.txt):
+ * -0.8 ... -1.2 % on the 64-channel long-filter shapes, neutral on configs[4]'s share, +4 % on 128-channel slices of 128-tap filters
+ * (two row blocks per wave), +0.7 ... +1.3 % in mfm_kernel_v3.hip (four waves per SIMD) - so: only where it was kept. */
+template <bool ASM_READS = false>
 static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], const int s_im[4], uint32_t lut_addr, int pcm[4])
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -277,6 +284,46 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         z[i] = __builtin_fmaf(__builtin_fmaf(-mx[i], z[i], mn[i]), r1, z[i]);
 #endif
     }
+    if constexpr (ASM_READS && MFM3_LUT_MODE == 1) {
+    typedef float mfm3_f2 __attribute__((ext_vector_type(2)));
+    mfm3_f2 pr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
+        fr[i] = __builtin_amdgcn_fractf(alpha);        /* :127 (alpha - floor(alpha), exact) */
+        const float fl = alpha - fr[i];                /* floor(alpha), 0..255 (NaN for (0, 0)) */
+        const float m = fl + 1048576.0f;               /* bits 0x49800000 + 8 * floor(alpha) */
+        /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
+        const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x49800000u);
+        asm volatile("ds_read_b64 %0, %1" : "=v"(pr[i]) : "v"(addr));
+    }
+    /* :134-163: sign(y) * (K + u), K in {0, pi, pi/2}, u = +-base - what of it does not need the table, while the reads are
+     * under way (inputs of the wait below, so that it is computed in front of it) */
+    float k[4];
+    /* (x and y pass through an empty statement behind the reads: what is computed from them from here on stays behind the reads) */
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool x_nonneg = s_re[i] >= 0, wide = __builtin_fabsf(x[i]) > __builtin_fabsf(y[i]);
+        k[i] = wide ? (x_nonneg ? 0.0f : MFM_PI_F) : MFM_HALF_PI_F;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]) : "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float prod = pr[i].y * fr[i];
+        const float interp = pr[i].x + prod;           /* :130-131, unfused */
+        const float base = (z[i] < MFM_TAN_MAP_RES_F) ? z[i] : interp;
+        const bool x_nonneg = s_re[i] >= 0, wide = __builtin_fabsf(x[i]) > __builtin_fabsf(y[i]);
+        const float u = (x_nonneg ^ wide) ? -base : base;
+        const float mag = k[i] + u;
+        const float lo = mag * MFM_Q14_OVER_PI_LO;
+        const float sc = __builtin_fmaf(mag, MFM_Q14_OVER_PI_HI, lo);
+        int signed_sc;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(signed_sc) : "s"(0x7fffffff), "v"(sc), "v"(s_im[i]));
+        pcm[i] = (int)__int_as_float(signed_sc);       /* NaN (from (0, 0)) converts to 0 = fast_atan2f.c:111-112 */
+    }
+    (void)t0, (void)dt;
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
@@ -321,6 +368,7 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         int signed_sc;
         asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(signed_sc) : "s"(0x7fffffff), "v"(sc), "v"(s_im[i]));
         pcm[i] = (int)__int_as_float(signed_sc);       /* NaN (from (0, 0)) converts to 0 = fast_atan2f.c:111-112 */
+    }
     }
 #else
     (void)s_re, (void)s_im, (void)lut_addr, (void)pcm;
