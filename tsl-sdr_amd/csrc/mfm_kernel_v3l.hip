@@ -50,8 +50,12 @@ typedef unsigned int mfm_v2u __attribute__((ext_vector_type(2)));
                          discriminator arithmetic, bit 7 = no PCM stores */
 #endif
 #ifndef MFM3L_LUT_ASM
-#define MFM3L_LUT_ASM 1 /* the discriminator's table reads as asm statements, waited for once, in the instances of one row block per wave
-                           (mfm_v3_device.h: mfm3_discriminate4) */
+#define MFM3L_LUT_ASM 1     /* the discriminator's table reads as asm statements (mfm_v3_device.h: mfm3_discriminate4<ASM_READS>), instances of one
+                               row block per wave: 1 = the four reads in one batch behind the four divisions */
+#endif
+#ifndef MFM3L_LUT_ASM_RB2
+#define MFM3L_LUT_ASM_RB2 2 /* ... of two row blocks per wave: 2 = each read behind its own division.  Both by measurement:
+                               profiles/r06_ab_asm_reads.txt */
 #endif
 #ifndef MFM3L_PF
 #define MFM3L_PF 4 /* k-steps of B fragments in flight ahead of the matrix instructions (2 where all 128 tap registers are in use) */
@@ -1027,7 +1031,7 @@ __global__ __launch_bounds__(MFM3_NT, mfm3l_waves_per_simd(KQ, NH, RB, SHIFT, IN
 #if MFM3L_KNOCK & 64
                     pcm[0] = s_re[0] + s_im[1], pcm[1] = s_re[1] + s_im[2], pcm[2] = s_re[2] + s_im[3], pcm[3] = s_re[3] + s_im[0];
 #else
-                    mfm3_discriminate4<(RB == 1) && (MFM3L_LUT_ASM != 0)>(s_re, s_im, lut_addr, pcm);
+                    mfm3_discriminate4<(RB == 1) ? MFM3L_LUT_ASM : MFM3L_LUT_ASM_RB2>(s_re, s_im, lut_addr, pcm);
 #endif
                     /* lane 0 of each row of 16 lanes gets lane 15's last sample: the next tile's history */
                     hist[r][c] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q[3][c], 0x121 /* row_ror:1 */, 0xf, 0xf, true);

@@ -251,13 +251,15 @@ static __device__ __forceinline__ uint32_t mfm3_fold64(uint64_t k, uint32_t mu, 
  * T[floor(alpha)] - which saves the conversion and the shift.
  * lut_addr: LDS byte address of the table: {T[i], dT[i]} pairs (MFM3_LUT_MODE 0: T[0], with dT[0] 1024 bytes behind it).
  */
-/* ASM_READS (the long-filter kernel's instances of one row block per wave, two waves per SIMD): the four table reads of a call are
- * single asm statements, waited for ONCE, behind the quadrant arithmetic of all four outputs.  Left to the compiler, ONE of the four
- * reads is sunk into an exec-masked branch of its own - s_and_saveexec / ds_read / s_waitcnt lgkmcnt(0) / s_or - a whole LDS round
- * trip with nothing else of the wave in flight, per channel and four outputs.  Measured (tools/exp/ab.py, profiles/r06_ab_asm_reads.txt):
- * -0.8 ... -1.2 % on the 64-channel long-filter shapes, neutral on configs[4]'s share, +4 % on 128-channel slices of 128-tap filters
- * (two row blocks per wave), +0.7 ... +1.3 % in mfm_kernel_v3.hip (four waves per SIMD) - so: only where it was kept. */
-template <bool ASM_READS = false>
+/* ASM_READS (the long-filter kernel, two waves per SIMD): the four table reads of a call are single asm statements, waited for ONCE,
+ * behind the quadrant arithmetic of all four outputs.  Left to the compiler (0), ONE of the four reads is sunk into an exec-masked
+ * branch of its own - s_and_saveexec / ds_read / s_waitcnt lgkmcnt(0) / s_or - a whole LDS round trip with nothing else of the wave
+ * in flight, per channel and four outputs.  1: the reads go out in one batch behind the four divisions; 2: each behind its own
+ * division, the later divisions to arrive behind.  Measured (tools/exp/ab.py, profiles/r06_ab_asm_reads.txt): instances of one row
+ * block per wave -0.6 ... -1.5 % with 1 (2: the same within the noise); two row blocks per wave: 1 is neutral (configs[4]'s share) or
+ * +4 % (128-channel slices at 1024 channels), 2 is -0.6 ... -0.8 % on both; mfm_kernel_v3.hip (four waves per SIMD) +0.7 ... +1.3 %
+ * with 1 - so: 1, 2 and 0 there. */
+template <int ASM_READS = 0> /* 0: the compiler's reads; 1: asm reads in one batch behind the four divisions; 2: each behind its own division */
 static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], const int s_im[4], uint32_t lut_addr, int pcm[4])
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -270,8 +272,18 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx[i]) : "v"(x[i]), "v"(y[i]));
         asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn[i]) : "v"(x[i]), "v"(y[i]));
     }
+    typedef float mfm3_f2 __attribute__((ext_vector_type(2)));
+    mfm3_f2 pr[4];
+    (void)pr;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+        if constexpr (ASM_READS == 2 && MFM3_LUT_MODE == 1) {
+            if (i > 0) {
+                /* (this division stays behind the previous output's read: the reads go out one by one, each with the later
+                 * divisions to arrive behind) */
+                asm volatile("" : "+v"(mx[i]), "+v"(mn[i]));
+            }
+        }
         /* mfm_div_unit: correctly rounded mn / mx (one residual step behind the quotient estimate: mfm_numerics.h has the
          * argument and tools/div_proof.c the enumeration behind it) */
         const float r0 = __builtin_amdgcn_rcpf(mx[i]);
@@ -283,10 +295,17 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
 #if MFM3_DIV_STEPS > 1
         z[i] = __builtin_fmaf(__builtin_fmaf(-mx[i], z[i], mn[i]), r1, z[i]);
 #endif
+        if constexpr (ASM_READS == 2 && MFM3_LUT_MODE == 1) {
+            const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
+            fr[i] = __builtin_amdgcn_fractf(alpha);        /* :127 (alpha - floor(alpha), exact) */
+            const float fl = alpha - fr[i];                /* floor(alpha), 0..255 (NaN for (0, 0)) */
+            const float m = fl + 1048576.0f;               /* bits 0x49800000 + 8 * floor(alpha) */
+            const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x49800000u);
+            asm volatile("ds_read_b64 %0, %1" : "=v"(pr[i]) : "v"(addr));
+        }
     }
-    if constexpr (ASM_READS && MFM3_LUT_MODE == 1) {
-    typedef float mfm3_f2 __attribute__((ext_vector_type(2)));
-    mfm3_f2 pr[4];
+    if constexpr (ASM_READS != 0 && MFM3_LUT_MODE == 1) {
+    if constexpr (ASM_READS == 1) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const float alpha = z[i] * 255.0f;             /* fast_atan2f.c:125 */
@@ -296,6 +315,7 @@ static __device__ __forceinline__ void mfm3_discriminate4(const int s_re[4], con
         /* (0, 0): NaN bits land far outside LDS; such a read returns 0 and the result is discarded below */
         const uint32_t addr = __float_as_uint(m) + (lut_addr - 0x49800000u);
         asm volatile("ds_read_b64 %0, %1" : "=v"(pr[i]) : "v"(addr));
+    }
     }
     /* :134-163: sign(y) * (K + u), K in {0, pi, pi/2}, u = +-base - what of it does not need the table, while the reads are
      * under way (inputs of the wait below, so that it is computed in front of it) */
