@@ -1347,7 +1347,9 @@ def main():
     # its own rocprofv3 --pmc run, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): only quoted for the
     # exact workload and kernel they were collected on
     traffic, traffic_source = None, None
-    for rnd in ("r05", "r04", "r03", "r02"):
+    import glob as _glob
+    rounds = sorted({os.path.basename(f)[:3] for f in _glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json"))}, reverse=True)
+    for rnd in rounds:   # the newest round's passes first
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
         if st1["kernel_variant"] == 2 and world == 1 and args.block_log2 == 26 and cpg == 64 and not in8 and \
                 args.config == "cfg2_64ch" and os.path.exists(tpath):
