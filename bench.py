@@ -1433,7 +1433,12 @@ def main():
                          "instance": instance_name(pkg, st1, in8), "library_sha16": library_sha16(pkg),
                          # the kernel's own clocks for the timed launches, and one sysfs sample taken while they ran
                          "clocks": cycles, "board_sample": smi,
-                         "energy": energy_figures(smi, dt / args.steps * 1e3, len(offs), outs)},
+                         "energy": energy_figures(smi, dt / args.steps * 1e3, len(offs), outs),
+                         # the same three as plain numbers (a record that keeps only scalars of this object still says which regime
+                         # the run was in: the clock inside the timed launches, the board's power against its cap, SIMDs busy)
+                         "sclk_mhz_in_launches": (cycles or {}).get("sclk_mhz_effective"),
+                         "board_power_w": (smi or {}).get("power_w"), "board_power_cap_w": (smi or {}).get("power_cap_w"),
+                         "simd_busy_fraction": (ceiling or {}).get("simd_busy_fraction")},
             "verified": verified["verified"], "verification": verified,
             "rotators": {"exact_channels": st1["rot_exact_channels"], "channels": len(offs)},
             "protocol": {"settle_seconds": args.settle_seconds, "settle_steps": settle_steps + 8,
